@@ -1,0 +1,196 @@
+"""bench.py -- headline benchmark of the ubdvss hot path on MI355X.
+
+Metric (BASELINE.json): images/sec at 512x512 for forward + CCL postprocess.
+Workload at every N: BASELINE.json configs[1] per GPU -- batch=32 512x512x3 fp32 forward + device
+postprocess (threshold -> external components -> quads).  A "step" = one pass of that path over one
+synthetic batch already resident in HBM.  Multi-GPU: images shard by rank with no data-path
+collective (replicas), weak scaling (32 images per GPU), value = all ranks' images / max-over-ranks
+time.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (dense dilated 3x3 conv, fp32 MFMA), timed live with HIP events
+  cpu_baseline -- the torch-CPU restatement (oracle/, kind "port") on a bounded sample, rank 0, N=1
+  parts        -- net-only / postprocess-only timings of the same step
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH, SIDE, C_IN = 32, 512, 3
+BYTES_PER_IMAGE_FP32 = 50.40e6            # layer-wise compulsory traffic, 512x512x3, n_cls = 0
+FLOP_PER_IMAGE = 1.1627e9
+PEAK_MFMA_F32 = 157.3                     # TFLOP/s, MI355X_MICROARCH.md (f32-input MFMA = vector peak)
+PEAK_HBM = 8000.0                         # GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """torch-CPU restatement of the same path (forward fp32 + C restatement of the OpenCV
+    postprocess) on a bounded sample: batches of 4 images 512x512x3, all host threads."""
+    from oracle import net_numpy as onet, net_torch as otorch, cv_post as ocv
+    from ubdvss_amd import synthetic
+    torch.set_num_threads(os.cpu_count() or 1)
+    w = onet.init_weights(1, C_IN, 0)
+    tw = otorch.to_torch_weights(w, torch.float32)
+    nb = 4
+    labels = synthetic.rectangle_maps(3, nb, SIDE // 4, SIDE // 4)
+    x = torch.from_numpy(synthetic.textured_images(4, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0)
+
+    def step():
+        with torch.no_grad():
+            lg = otorch.forward(x, tw).numpy()
+        det = (lg[..., 0] > -0.0).astype(np.uint8)
+        return [ocv.postprocess(det[i], None, 4, 5) for i in range(nb)]
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} batches of {nb} textured 512x512x3 images, torch-CPU fp32 forward (oneDNN) + C "
+                      f"restatement of the OpenCV postprocess, {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+
+    from ubdvss_amd import NetConfig, Model, ModelRunner, synthetic, _lib
+    cfg = NetConfig(grey=False)
+    model = Model(cfg, seed=1)                               # glorot-uniform random init, zero biases
+    runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
+
+    # synthetic batch resident in HBM: stripe-textured rectangles on noise
+    labels = synthetic.rectangle_maps(3 + rank, BATCH, SIDE // 4, SIDE // 4)
+    x = torch.from_numpy(synthetic.textured_images(4 + rank, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
+    rect_logits = torch.from_numpy(synthetic.logits_from_maps(labels, 0, seed=5)).to(dev)
+
+    def step():
+        return runner.predict_on_device(model, x)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH * args.steps / elapsed
+
+    line = None
+    if rank == 0:
+        # ---- parts: net only / postprocess only (rectangle maps) -- HIP events on the launch stream
+        def timed(fn, reps):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        reps = max(5, min(args.steps, 20))
+        net_ms = timed(lambda: model.predict_on_device(x), reps)
+        logits = model.predict_on_device(x)
+        post_ms = timed(lambda: model.postprocess_on_device(logits, runner.logit_threshold, 4, 5, cap=1024), reps)
+        post_rect_ms = timed(lambda: model.postprocess_on_device(rect_logits, runner.logit_threshold, 4, 5, cap=1024), reps)
+        counts = out[4].cpu().numpy()
+
+        # ---- roofline of the dominant kernel: one dense dilated layer on the real L3 activations
+        lib = _lib.load()
+        n, mh, mw = BATCH, SIDE // 4, SIDE // 4
+        act_in = torch.rand((n, mh, mw, 24), device=dev) - 0.3
+        act_out = torch.empty_like(act_in)
+        ws = torch.empty(int(lib.ubd_forward_workspace_bytes(model._h, 1, 4, 4)), dtype=torch.uint8, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.ubd_pack_weights(model._h, model.params.data_ptr(), ws.data_ptr(), ws.numel(), stream), "pack")
+        layer_ms = []
+        for layer in range(6):
+            layer_ms.append(timed(lambda: _lib.check(lib.ubd_dilated_layer(
+                model._h, model.params.data_ptr(), layer, act_in.data_ptr(), act_out.data_ptr(), n, mh, mw,
+                ws.data_ptr(), stream), "dil"), reps))
+        t_layer = float(np.mean(layer_ms)) * 1e-3
+        flop_layer = 2.0 * 216 * 24 * n * mh * mw
+        bytes_layer = 2.0 * n * mh * mw * 24 * 4
+        roofline = {"bound": "mfma", "kernel": "dilconv_f32_kernel", "achieved": round(flop_layer / t_layer / 1e12, 3),
+                    "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
+                    "traffic": None, "avg_launch_us": round(t_layer * 1e6, 2),
+                    "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
+                    "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
+        fwd_hbm = {"bound": "hbm", "achieved": round(BATCH * BYTES_PER_IMAGE_FP32 / (net_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM,
+                   "unit": "GB/s", "frac": round(BATCH * BYTES_PER_IMAGE_FP32 / (net_ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                   "note": "whole forward pass, algorithmic bytes 50.40 MB/image (SURVEY 8(d))",
+                   "mfma_frac": round(BATCH * FLOP_PER_IMAGE / (net_ms * 1e-3) / 1e12 / PEAK_MFMA_F32, 4)}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_seconds)
+
+        line = {
+            "metric": "images/sec (512x512) fwd+CCL", "value": round(value, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
+                                   "(stripe-textured rectangle images, random-init weights)",
+                       "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu,
+            "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
+                      "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
+                      "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/* ubd.h -- C ABI of libubd_hip.so: the MI355X (gfx950) implementation of the
+ * ubdvss hot path (dilated-FCN forward -> threshold map -> external components ->
+ * rotated quads; train step = forward + loss + backward + Adam).
+ *
+ * The reference (asmekal/ubdvss) has no FFI: the path sits behind three Python
+ * seams.  Each entry point below names the seam it replaces (paths relative to
+ * the reference root).  All pointers are raw DEVICE pointers owned by the caller
+ * (e.g. torch tensors' data_ptr()) unless marked HOST; the library owns only its
+ * handle.  Every call enqueues work on the caller's HIP stream (`stream` is a
+ * hipStream_t passed as void*, NULL = default stream) and returns without
+ * synchronising.  Return value: 0 = ok, non-zero = error (see ubd_last_error()).
+ * No torch types, no C++ types.
+ */
+#ifndef UBD_H
+#define UBD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UBD_ABI_VERSION 1
+
+/* activation storage / compute dtype (weights, logits, loss and gradients are fp32) */
+enum { UBD_F32 = 0, UBD_BF16 = 1, UBD_F16 = 2 };
+/* input image dtype for ubd_forward */
+enum { UBD_IN_F32 = 0, UBD_IN_U8 = 1 };
+/* preprocessing fused into the first layer's load (net.py:217-218, NetConfig.get_preprocessing_fn) */
+enum { UBD_PRE_NONE = 0, UBD_PRE_MOBILENET = 1 };
+
+/* Mirrors the fields of NetConfig that reach the kernels (net.py:98-132):
+ * grey -> c_in, fml_compatible, n_classes (0 = detection only). */
+typedef struct ubd_config {
+    int32_t c_in;            /* 1 (grey=True, the reference default) or 3 */
+    int32_t n_classes;       /* 0..UBD_MAX_CLASSES */
+    int32_t fml_compatible;  /* 1: ZeroPadding2D((1,0),(1,0)) + 'valid' for stride 2 (net.py:229-232) */
+    int32_t dtype;           /* UBD_F32 / UBD_BF16 / UBD_F16 */
+} ubd_config;
+
+#define UBD_MAX_CLASSES 31
+#define UBD_N_FILTERS 24
+
+typedef struct ubd_handle ubd_handle;
+
+/* --- lifecycle ----------------------------------------------------------- */
+int ubd_abi_version(void);
+const char *ubd_last_error(void);                       /* thread-local message of the last failure */
+int ubd_create(const ubd_config *cfg, ubd_handle **out); /* replaces NetManager.build_model (net.py:273-314) */
+void ubd_destroy(ubd_handle *h);
+
+/* Number of fp32 parameters; flat order = Keras model.get_weights() order
+ * (SURVEY.md 9.2): per separable layer [depthwise(3,3,C,1), pointwise(1,1,C,24), bias],
+ * per Conv2D [kernel HWIO, bias]; head last. */
+size_t ubd_param_count(const ubd_handle *h);
+
+/* Bytes of caller-provided device workspace needed by ubd_forward / ubd_train_step
+ * for a batch of n images of height x width (multiples of 4). */
+size_t ubd_forward_workspace_bytes(const ubd_handle *h, int n, int height, int width);
+size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int height, int width);
+size_t ubd_postprocess_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w, int cap);
+
+/* --- inference ----------------------------------------------------------- */
+/* Replaces keras Model.predict(images) at model_runner.py:119 / predict.py:74-76.
+ * images: NHWC, (n, height, width, c_in), in_dtype UBD_IN_F32 (already preprocessed, or raw with
+ *         preprocessing != NONE) or UBD_IN_U8.
+ * logits: fp32 NHWC (n, height/4, width/4, 1+n_classes): channel 0 detection logit. */
+int ubd_forward(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                int n, int height, int width, float *logits,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Layer-level entry points (profiling / roofline measurement of the dominant kernel; the
+ * reference has no counterpart -- Keras runs the whole graph in one session.run).
+ * ubd_pack_weights fills the packed-fragment region at the start of a forward workspace;
+ * ubd_dilated_layer then runs ONE dense dilated 3x3 layer (layer = 0..5 -> net.py:298-304,
+ * dilation 1,2,4,8,16,1) + bias + ReLU on (n, map_h, map_w, 24) activations. */
+int ubd_pack_weights(ubd_handle *h, const float *params, void *workspace, size_t workspace_bytes, void *stream);
+int ubd_dilated_layer(ubd_handle *h, const float *params, int layer, const void *in, void *out,
+                      int n, int map_h, int map_w, const void *workspace, void *stream);
+
+/* Replaces ModelRunner.predict's host tail (model_runner.py:121-134) and
+ * SegmapManager.postprocess (segmap_manager.py:41-69) + utils.get_contours_and_boxes
+ * (utils.py:51-60) for the whole batch:
+ *   map = logits[...,0] > logit_threshold (strict);
+ *   external 8-connected components (cv2.findContours RETR_EXTERNAL semantics);
+ *   keep contourArea > min_area; minAreaRect -> boxPoints -> round(x*scale) half-to-even;
+ *   optional class vote: argmax of mean softmax(class logits) over the filled contour.
+ * Outputs (device):
+ *   binary_map : int32 (n, map_h, map_w) values {0,1}              (may be NULL)
+ *   quads      : int32 (n, cap, 8)  x1,y1,...,x4,y4 in cv2.boxPoints order, objects in cv2's
+ *                return order (last raster-discovered first)
+ *   classes    : int32 (n, cap)     (ignored when n_classes == 0; may be NULL then)
+ *   counts     : int32 (n)          number of objects found; if counts[i] > cap the list of
+ *                image i was truncated to cap entries and the caller must treat it as an error. */
+int ubd_postprocess(ubd_handle *h, const float *logits, int n, int map_h, int map_w,
+                    float logit_threshold, int scale, float min_area,
+                    int32_t *binary_map, int32_t *quads, int32_t *classes, int32_t *counts, int cap,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* --- training ------------------------------------------------------------ */
+/* Replaces the loss callable losses.get_loss(classification_mode)(y_true, y_pred)
+ * (losses.py:20-24, :33-126) together with its autodiff gradient.
+ *   y_true : int32 (n, map_h, map_w) labels 0..n_classes (0 = background)
+ *   loss   : fp32 [4] = {total, detection, classification, n_hard_k}
+ *   dlogits: fp32 like logits (may be NULL for loss only)
+ * Batch-global reductions and top-k run over the n images given (per-replica semantics). */
+int ubd_loss(ubd_handle *h, const float *logits, const int32_t *y_true, int n, int map_h, int map_w,
+             float *loss, float *dlogits, void *workspace, size_t workspace_bytes, void *stream);
+
+/* One pass fwd -> loss -> backward (replaces the body of Keras train_on_batch driven by
+ * fit_generator, train.py:176-188, up to but excluding the optimiser update).
+ *   grads : fp32 [param_count], same flat order as params (overwritten)
+ *   loss  : fp32 [4] as in ubd_loss
+ * The caller may all-reduce `grads` across ranks before ubd_adam_step. */
+int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                   const int32_t *y_true, int n, int height, int width,
+                   float *grads, float *loss, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Keras 2.2 Adam (train.py:110): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updated in place;
+ * p -= lr_t*m/(sqrt(v)+eps); grads are multiplied by grad_scale first (1/world for DP mean). */
+int ubd_adam_step(float *params, const float *grads, float *m, float *v, size_t count,
+                  int t, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UBD_H */

@@ -1,0 +1,156 @@
+"""GPU parity: device postprocess (threshold -> external components -> contourArea filter ->
+minAreaRect -> boxPoints -> rounded quads -> class vote) vs the C oracle, bit-exact on the integer
+outputs, through the C ABI (Model.postprocess_on_device / SegmapManager.postprocess / ModelRunner)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage as ndi
+
+from oracle import cv_post as ocv, net_numpy as onet
+from ubdvss_amd import NetConfig, Model, ModelRunner, SegmapManager, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(ncls=0, cin=3):
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
+    return Model(cfg, seed=0)
+
+
+def _run(model, logits, thr=0.0, scale=4, min_area=5, cap=256):
+    lt = torch.from_numpy(np.ascontiguousarray(logits, dtype=np.float32)).cuda()
+    bmap, quads, classes, counts = model.postprocess_on_device(lt, thr, scale, min_area, cap=cap)
+    counts = counts.cpu().numpy(); quads = quads.cpu().numpy()
+    classes = classes.cpu().numpy() if classes is not None else None
+    out = []
+    for i in range(len(counts)):
+        n = min(int(counts[i]), cap)
+        out.append((quads[i, :n], classes[i, :n] if classes is not None else None))
+    return bmap.cpu().numpy(), out, counts
+
+
+def _compare(model, logits, n_cls, thr=0.0, min_area=5, cap=256):
+    bmap, out, counts = _run(model, logits, thr, 4, min_area, cap)
+    det = (logits[..., 0] > thr).astype(np.int32)
+    assert np.array_equal(bmap, det)
+    for i in range(logits.shape[0]):
+        q, c = ocv.postprocess(det[i], logits[i, ..., 1:] if n_cls else None, 4, min_area)
+        assert int(counts[i]) == len(q), (i, int(counts[i]), len(q))
+        assert np.array_equal(out[i][0], q), (i, out[i][0], q)
+        if n_cls:
+            assert np.array_equal(out[i][1], c), (i, out[i][1], c)
+
+
+def test_golden_rectangles(golden_dir, manifest):
+    maps = np.load(os.path.join(golden_dir, "post_rect.npz"))["maps"].astype(np.int32)
+    lg = synthetic.logits_from_maps(maps, 4, seed=5, noise=0.0)
+    bmap, out, counts = _run(_model(4), lg, thr=0.0)
+    for (q, c), gold in zip(out, manifest["post_rect"]):
+        assert q.tolist() == gold["quads"] and c.tolist() == gold["classes"]
+
+
+def test_golden_stress_maps(golden_dir, manifest):
+    stress = np.load(os.path.join(golden_dir, "post_stress_maps.npy"))
+    lg = np.where(stress[..., None] > 0, 1.0, -1.0).astype(np.float32)
+    _, out, _ = _run(_model(0), lg, cap=2048)
+    for (q, _), gold in zip(out, manifest["post_stress"]):
+        assert q.tolist() == gold
+
+
+@pytest.mark.parametrize("n_cls", [0, 3])
+def test_rectangles_vs_oracle(n_cls):
+    maps = synthetic.rectangle_maps(21, 16, 128, 128, n_classes=n_cls)
+    lg = synthetic.logits_from_maps(maps, n_cls, seed=22)
+    _compare(_model(n_cls), lg, n_cls)
+
+
+def test_random_noise_maps_vs_oracle():
+    """Pathological maps: thousands of tiny components, holes, nesting, frame contact."""
+    rng = np.random.default_rng(5)
+    for p, hw in [(0.5, (64, 64)), (0.62, (48, 80)), (0.8, (40, 40)), (0.3, (64, 32))]:
+        m = (rng.random((6,) + hw) < p)
+        m[1] = ndi.binary_dilation(m[1]); m[2] = ndi.binary_erosion(m[2]); m[3] = ndi.binary_closing(m[3])
+        lg = np.where(m[..., None], 2.0, -2.0).astype(np.float32)
+        _compare(_model(0), lg, 0, cap=2048)
+        _compare(_model(0), lg, 0, min_area=0, cap=2048)
+
+
+def test_nested_rings_and_class_vote():
+    m = np.zeros((1, 64, 64), bool)
+    m[0, 4:60, 4:60] = 1; m[0, 10:54, 10:54] = 0; m[0, 16:48, 16:48] = 1; m[0, 22:42, 22:42] = 0; m[0, 28:36, 28:36] = 1
+    rng = np.random.default_rng(3)
+    lg = np.concatenate([np.where(m[..., None], 3.0, -3.0), rng.normal(0, 1, (1, 64, 64, 3))], axis=-1).astype(np.float32)
+    lg[0, 20:44, 20:44, 2] += 4.0          # enclosed pixels vote too (filled contour includes holes)
+    _compare(_model(3), lg, 3)
+
+
+def test_threshold_strictness_and_probability():
+    model = _model(0)
+    lg = np.full((1, 16, 16, 1), -1.0, np.float32)
+    lg[0, 4:12, 4:12, 0] = 0.0               # exactly at the p=0.5 threshold: NOT positive (strict >)
+    _, out, counts = _run(model, lg, thr=float(onet.logit_threshold(0.5)))
+    assert counts[0] == 0
+    lg[0, 4:12, 4:12, 0] = 2.5
+    thr = float(onet.logit_threshold(0.9))   # log(9) = 2.197
+    _, out, counts = _run(model, lg, thr=thr)
+    assert counts[0] == 1 and sorted(map(tuple, out[0][0].reshape(4, 2).tolist())) == [(16, 16), (16, 44), (44, 16), (44, 44)]
+
+
+def test_capacity_overflow_is_reported():
+    rng = np.random.default_rng(1)
+    m = np.zeros((1, 64, 64), bool)
+    for by in range(0, 60, 6):
+        for bx in range(0, 60, 6):
+            m[0, by:by + 4, bx:bx + 4] = 1          # 100 blocks of area 9
+    lg = np.where(m[..., None], 1.0, -1.0).astype(np.float32)
+    _, _, counts = _run(_model(0), lg, cap=16)
+    assert counts[0] == 100
+    cfg = NetConfig(grey=False)
+    runner = ModelRunner(cfg, max_objects_per_image=16)
+    assert rng is not None and runner.logit_threshold == 0
+
+
+def test_segmap_manager_static_api():
+    m = np.zeros((32, 32, 1), np.int64)
+    m[5:12, 8:20, 0] = 1
+    objs = SegmapManager.postprocess(m, None, scale=4, min_area_threshold=5)
+    assert len(objs) == 1 and sorted(map(tuple, np.asarray(objs[0].bbox).reshape(4, 2).tolist())) == [(32, 20), (32, 44), (76, 20), (76, 44)]
+    cl = np.zeros((32, 32, 3), np.float32); cl[..., 1] = 2.0
+    objs = SegmapManager.postprocess(m, cl, scale=4)
+    assert objs[0].object_type == 1
+    ref_q, ref_c = ocv.postprocess(m[..., 0], cl, 4, 5)
+    assert np.array_equal(np.asarray(objs[0].bbox), ref_q[0]) and objs[0].object_type == ref_c[0]
+
+
+def test_model_runner_predict_end_to_end():
+    """image -> boxes with the reference's return triple (model_runner.py:105-138); logits compared
+    with tolerance, then the postprocess of the GPU's own map compared bit-exact with the oracle."""
+    cfg = NetConfig(class_names=["a", "b"], grey=False)
+    model = Model(cfg, seed=3)
+    w = onet.init_weights(31, 3, 2, bias_scale=0.3)
+    model.set_weights(w)
+    labels = synthetic.rectangle_maps(8, 3, 32, 32)
+    x = synthetic.textured_images(4, labels, 4, 3).astype(np.float32) / 127.5 - 1.0
+    runner = ModelRunner(cfg, pixel_threshold=0.5)
+    det, cls_logits, found = runner.predict(model, x)
+    ref = onet.forward(x.astype(np.float64), w)
+    assert det.shape == (3, 32, 32, 1) and cls_logits.shape == (3, 32, 32, 2)
+    far = np.abs(ref[..., 0]) > 1e-3
+    assert np.array_equal(det[..., 0][far], (ref[..., 0] > 0)[far].astype(det.dtype))
+    for i in range(3):
+        q, c = ocv.postprocess(det[i], cls_logits[i], 4, 5)
+        assert len(found[i]) == len(q)
+        for o, qq, cc in zip(found[i], q, c):
+            assert np.array_equal(np.asarray(o.bbox), qq) and o.object_type == cc
+
+
+def test_large_map_1024_input_shape():
+    """cfg5 shape (1024^2 input -> 256x256 map) and idempotence of the quads under re-run."""
+    maps = synthetic.rectangle_maps(33, 4, 256, 256)
+    lg = synthetic.logits_from_maps(maps, 0, seed=1)
+    model = _model(0)
+    _compare(model, lg, 0)
+    a = _run(model, lg)[1]; b = _run(model, lg)[1]
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(a, b))

@@ -1,0 +1,64 @@
+"""ctypes binding of libubd_hip.so (include/ubd.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libubd_hip.so")
+
+UBD_F32, UBD_BF16, UBD_F16 = 0, 1, 2
+UBD_IN_F32, UBD_IN_U8 = 0, 1
+UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
+ABI_VERSION = 1
+
+
+class UbdConfig(ctypes.Structure):
+    _fields_ = [("c_in", ctypes.c_int32), ("n_classes", ctypes.c_int32),
+                ("fml_compatible", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+
+
+# every symbol include/ubd.h declares: name -> (restype, argtypes)
+_vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+_f = ctypes.c_float
+SIGNATURES = {
+    "ubd_abi_version": (_i, []),
+    "ubd_last_error": (ctypes.c_char_p, []),
+    "ubd_create": (_i, [ctypes.POINTER(UbdConfig), ctypes.POINTER(_vp)]),
+    "ubd_destroy": (None, [_vp]),
+    "ubd_param_count": (_sz, [_vp]),
+    "ubd_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "ubd_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "ubd_postprocess_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "ubd_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ubd_pack_weights": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "ubd_dilated_layer": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ubd_postprocess": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ubd_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ubd_train_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ubd_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  ubdvss_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError = stale build, surface it
+            fn.restype = res
+            fn.argtypes = args
+        if lib.ubd_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libubd_hip.so ABI {lib.ubd_abi_version()} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {load().ubd_last_error().decode()}")

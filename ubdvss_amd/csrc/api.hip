@@ -1,0 +1,61 @@
+// Handle lifecycle and error reporting of libubd_hip.so.
+#include <stdarg.h>
+#include <stdlib.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ubd_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ubd_last_error(void) { return g_err; }
+extern "C" int ubd_abi_version(void) { return UBD_ABI_VERSION; }
+
+extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
+{
+    UBD_REQUIRE(cfg && out, "ubd_create: null argument");
+    UBD_REQUIRE(cfg->c_in == 1 || cfg->c_in == 3, "ubd_create: c_in must be 1 (grey) or 3, got %d", cfg->c_in);
+    UBD_REQUIRE(cfg->n_classes >= 0 && cfg->n_classes <= UBD_MAX_CLASSES, "ubd_create: n_classes %d out of range [0,%d]", cfg->n_classes, UBD_MAX_CLASSES);
+    UBD_REQUIRE(cfg->dtype == UBD_F32 || cfg->dtype == UBD_BF16 || cfg->dtype == UBD_F16, "ubd_create: bad dtype %d", cfg->dtype);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    UBD_REQUIRE(e == hipSuccess && ndev > 0, "ubd_create: no HIP device visible (%s); this library has no CPU fallback", hipGetErrorString(e));
+    int dev = 0;
+    UBD_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    UBD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    UBD_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "ubd_create: device arch %s is not gfx950; this library is built for MI355X only", prop.gcnArchName);
+
+    ubd_handle *h = (ubd_handle *)calloc(1, sizeof(ubd_handle));
+    UBD_REQUIRE(h, "ubd_create: out of host memory");
+    h->cfg = *cfg;
+    h->k_out = 1 + cfg->n_classes;
+    h->num_cus = prop.multiProcessorCount;
+    // Keras model.get_weights() order
+    size_t off = 0;
+    int cin = cfg->c_in;
+    for (int s = 0; s < 3; ++s) {
+        h->off_sep_dw[s] = off; off += (size_t)9 * cin;
+        h->off_sep_pw[s] = off; off += (size_t)cin * UBD_C;
+        h->off_sep_b[s] = off;  off += UBD_C;
+        cin = UBD_C;
+    }
+    for (int k = 0; k < UBD_NUM_DIL; ++k) {
+        h->off_dil_k[k] = off; off += (size_t)9 * UBD_C * UBD_C;
+        h->off_dil_b[k] = off; off += UBD_C;
+    }
+    h->off_head_k = off; off += (size_t)UBD_C * h->k_out;
+    h->off_head_b = off; off += h->k_out;
+    h->n_params = off;
+    *out = h;
+    return 0;
+}
+
+extern "C" void ubd_destroy(ubd_handle *h) { free(h); }
+
+extern "C" size_t ubd_param_count(const ubd_handle *h) { return h ? h->n_params : 0; }

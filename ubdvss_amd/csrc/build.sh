@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libubd_hip.so (gfx950 only) in-tree next to the Python host package.
+set -e
+cd "$(dirname "$0")"
+OUT=../libubd_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+mkdir -p _obj
+pids=()
+for f in api forward postprocess train; do
+  [ -f $f.hip ] || continue
+  extra=""
+  # OpenCV-exact float geometry: no FMA contraction in postprocess
+  [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
+  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ common.h -nt _obj/$f.o ] || [ ../../include/ubd.h -nt _obj/$f.o ]; then
+    ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj/$f.o ${UBD_SAVE_TEMPS:+-save-temps=obj} ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+objs=""
+for f in api forward postprocess train; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+echo "built $OUT"

@@ -1,0 +1,59 @@
+// Shared host/device definitions of libubd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/ubd.h"
+
+#define UBD_C 24              // n_filters (net.py:289)
+#define UBD_NUM_DIL 6         // dense dilated layers L4..L9 (net.py:298-304)
+
+struct ubd_handle {
+    ubd_config cfg;
+    int k_out;                // 1 + n_classes
+    // offsets (in floats) into the flat Keras-ordered parameter vector
+    size_t off_sep_dw[3], off_sep_pw[3], off_sep_b[3];
+    size_t off_dil_k[UBD_NUM_DIL], off_dil_b[UBD_NUM_DIL];
+    size_t off_head_k, off_head_b;
+    size_t n_params;
+    int num_cus;
+};
+
+static const int UBD_DILATIONS[UBD_NUM_DIL] = {1, 2, 4, 8, 16, 1};
+
+void ubd_set_error(const char *fmt, ...);
+
+#define UBD_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ubd_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,             \
+                          hipGetErrorString(_e));                                        \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+#define UBD_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            ubd_set_error(__VA_ARGS__);                                                  \
+            return 2;                                                                    \
+        }                                                                                \
+    } while (0)
+
+static inline size_t ubd_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- workspace carving (all offsets 256-byte aligned) -------------------------------
+// packed MFMA weight fragments, see forward.hip
+#define UBD_DIL_FRAG_FLOATS (9 * 6 * 2 * 64)     // per dilated layer
+#define UBD_SEP_FRAG_FLOATS (6 * 2 * 64)         // pointwise fragments per separable layer
+#define UBD_SEP_DW_FLOATS (9 * 6 * 64)           // per-lane depthwise taps per separable layer
+
+struct ubd_fwd_layout {
+    size_t off_wfrag;     // packed weights
+    size_t off_a1, off_a2;   // (n, H/2, W/2, 24) activations: L1 out, L2 out
+    size_t off_b[2];         // (n, H/4, W/4, 24) ping-pong for L3..L9 outputs (inference)
+    size_t off_acts[7];      // training: L3..L9 outputs kept
+    size_t total;
+};

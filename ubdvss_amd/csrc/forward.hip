@@ -1,0 +1,463 @@
+// Forward pass of the ubdvss dilated FCN on gfx950 (MI355X), fp32 path.
+//
+// Reference semantics: semantic_segmentation/net.py:225-252 (conv_bn) and :278-314
+// (_build_dilated_conv_model); SURVEY.md section 9.1.  NHWC activations, Keras-ordered
+// flat fp32 parameters.
+//
+// Kernel plan (one launch per layer, every kernel MFMA-based, 64-wide waves):
+//   pack_weights_kernel   flat params -> per-lane MFMA B-fragments (tiny, once per call)
+//   sepconv_kernel        L1..L3: depthwise 3x3 on the VALU directly in MFMA A-operand
+//                         layout (lane = (pixel i, k-quarter q)), pointwise 1x1 as
+//                         v_mfma_f32_16x16x4_f32, bias + ReLU epilogue.  HBM-bound.
+//   dilconv_kernel        L4..L9: implicit GEMM M = 16 pixels, N = 24 (padded to 2x16),
+//                         K = 216, the whole layer's weights resident in 108 VGPRs per
+//                         lane, A fragments loaded straight from global memory with
+//                         buffer loads (hardware zero fill = 'same' padding), register
+//                         double buffering across persistent tiles.  fp32-MFMA-bound.
+//   head_kernel           1x1 conv 24 -> 1+n_classes, no activation.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------
+// Packed weight fragments.
+//  dilated layer L, tap t (ky*3+kx), sub-step j (0..5), N-tile nt (0..1), lane:
+//     ci = j < 4 ? 4*q + j : 16 + 2*q + (j-4)      (q = lane>>4)
+//     co = (lane & 15) + 16*nt                      (zero for co >= 24)
+//     frag[((t*6 + j)*2 + nt)*64 + lane] = k[ky][kx][ci][co]
+//  separable layer s: channel of (lane, step): CIN==24 ? 6*q + step : (step==0 && q<CIN ? q : none)
+//     pwfrag[(step*2 + nt)*64 + lane] = pw[ch][co]
+//     dwlane[(tap*6 + step)*64 + lane] = dw[tap][ch]
+// ------------------------------------------------------------------------------------
+struct pack_args {
+    size_t off_sep_dw[3], off_sep_pw[3];
+    size_t off_dil_k[UBD_NUM_DIL];
+    int c_in;
+};
+
+__global__ void pack_weights_kernel(const float *__restrict__ params, float *__restrict__ wfrag, pack_args a)
+{
+    const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
+    const int total = 3 * per_sep + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (idx < 3 * per_sep) {
+            int s = idx / per_sep, r = idx % per_sep;
+            int cin = s == 0 ? a.c_in : UBD_C;
+            if (r < UBD_SEP_FRAG_FLOATS) {
+                int lane = r & 63, nt = (r >> 6) & 1, step = r >> 7;
+                int q = lane >> 4, co = (lane & 15) + 16 * nt;
+                int ch = cin == UBD_C ? 6 * q + step : ((step == 0 && q < cin) ? q : -1);
+                if (ch >= 0 && co < UBD_C) v = params[a.off_sep_pw[s] + (size_t)ch * UBD_C + co];
+            } else {
+                r -= UBD_SEP_FRAG_FLOATS;
+                int lane = r & 63, ts = r >> 6, step = ts % 6, tap = ts / 6;
+                int q = lane >> 4;
+                int ch = cin == UBD_C ? 6 * q + step : ((step == 0 && q < cin) ? q : -1);
+                if (ch >= 0) v = params[a.off_sep_dw[s] + (size_t)tap * cin + ch];
+            }
+        } else {
+            int r = idx - 3 * per_sep;
+            int L = r / UBD_DIL_FRAG_FLOATS;
+            r %= UBD_DIL_FRAG_FLOATS;
+            int lane = r & 63, nt = (r >> 6) & 1, tj = r >> 7, j = tj % 6, t = tj / 6;
+            int q = lane >> 4, co = (lane & 15) + 16 * nt;
+            int ci = j < 4 ? 4 * q + j : 16 + 2 * q + (j - 4);
+            if (co < UBD_C) v = params[a.off_dil_k[L] + ((size_t)t * UBD_C + ci) * UBD_C + co];
+        }
+        wfrag[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Epilogue shared by sepconv and dilconv: D layout of v_mfma_f32_16x16x4_f32 is
+// col = lane & 15 (output channel), row = 4*(lane>>4) + reg (pixel in the 16-pixel tile).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t row_base_elems, int x0, int ow,
+                                                int lane, f32x4 acc0, f32x4 acc1, float b0, float b1)
+{
+    const int co = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int px = x0 + 4 * q + r;
+        if (px < ow) {
+            float *p = y + (row_base_elems + (size_t)px) * UBD_C;
+            p[co] = fmaxf(acc0[r] + b0, 0.f);
+            if (co < 8) p[16 + co] = fmaxf(acc1[r] + b1, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Separable 3x3 conv (+bias+ReLU).  One wave = one tile of 16 consecutive output pixels.
+// lane = (i = lane&15 : pixel, q = lane>>4 : channel group).
+// ------------------------------------------------------------------------------------
+template <int CIN, int STRIDE, int IN_U8>
+__global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
+                                                      const float *__restrict__ frag,  // pwfrag then dwlane
+                                                      const float *__restrict__ bias, int n, int H, int W, int OH,
+                                                      int OW, int pad_lo, float pre_sub, float pre_div)
+{
+    constexpr int CPL = (CIN == UBD_C) ? 6 : 1;   // channels per lane
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const float *pwfrag = frag;
+    const float *dwlane = frag + UBD_SEP_FRAG_FLOATS;
+
+    float dwk[9][CPL];
+    float pwf[CPL][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) {
+        pwf[s][0] = pwfrag[(s * 2 + 0) * 64 + lane];
+        pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane];
+    }
+    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const bool ch_ok = (CIN == UBD_C) || (q < CIN);
+    const int cb = (CIN == UBD_C) ? 6 * q : q;
+
+    const int tiles_x = (OW + 15) >> 4;
+    const long total = (long)n * OH * tiles_x;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
+        const int xt = (int)(tile % tiles_x);
+        const long rowid = tile / tiles_x;
+        const int oy = (int)(rowid % OH);
+        const long img = rowid / OH;
+        const int x0 = xt * 16;
+        const int ox = x0 + i;
+
+        float dwv[CPL];
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * STRIDE + ky - pad_lo;
+            const bool rok = (iy >= 0) && (iy < H);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * STRIDE + kx - pad_lo;
+                const bool ok = rok && ch_ok && (ix >= 0) && (ix < W) && (ox < OW);
+                const size_t e = (((size_t)img * H + (size_t)(rok ? iy : 0)) * W + (size_t)(ok ? ix : 0)) * CIN + cb;
+                if constexpr (CIN == UBD_C) {
+                    const f32x2 *p = (const f32x2 *)((const float *)xin + e);
+                    f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
+                    if (ok) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+                    const int t = ky * 3 + kx;
+                    dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]);
+                    dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
+                    dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]);
+                    dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
+                    dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]);
+                    dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
+                } else {
+                    float v = 0.f;
+                    if (ok) {
+                        if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[e] - pre_sub) / pre_div;
+                        else v = (((const float *)xin)[e] - pre_sub) / pre_div;
+                    }
+                    dwv[0] = fmaf(v, dwk[ky * 3 + kx][0], dwv[0]);
+                }
+            }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
+        }
+        store_tile_relu(y, ((size_t)img * OH + oy) * OW, x0, OW, lane, acc0, acc1, b0, b1);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Dense dilated 3x3 conv 24 -> 24 (+bias+ReLU), fp32 MFMA, weights resident in VGPRs.
+// ------------------------------------------------------------------------------------
+struct a_frags {
+    f32x4 v4[9];
+    f32x2 v2[9];
+};
+
+__device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, long tile,
+                                         int tiles_x, int h, int w, int d, int lane)
+{
+    const int i = lane & 15, q = lane >> 4;
+    const int xt = (int)(tile % tiles_x);
+    const long rowid = tile / tiles_x;
+    const int yy = (int)(rowid % h);
+    const long img = rowid / h;
+    const int px = xt * 16 + i;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yy + (ky - 1) * d;
+        const bool rok = (iy >= 0) && (iy < h);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = px + (kx - 1) * d;
+            const bool ok = rok && (ix >= 0) && (ix < w);
+            const unsigned byte_off = (unsigned)((((size_t)img * h + (size_t)iy) * w + (size_t)ix) * (UBD_C * 4));
+            const unsigned o4 = ok ? byte_off + 16u * q : oob;
+            const unsigned o2 = ok ? byte_off + 64u + 8u * q : oob;
+            u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o4, 0, 0);
+            u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o2, 0, 0);
+            a.v4[ky * 3 + kx] = __builtin_bit_cast(f32x4, r4);
+            a.v2[ky * 3 + kx] = __builtin_bit_cast(f32x2, r2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             const float *__restrict__ wfrag,
+                                                             const float *__restrict__ bias, int n, int h, int w,
+                                                             int d, unsigned in_bytes)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    float wr[9][6][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wr[t][j][0] = wfrag[((t * 6 + j) * 2 + 0) * 64 + lane];
+            wr[t][j][1] = wfrag[((t * 6 + j) * 2 + 1) * 64 + lane];
+        }
+    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+
+    const int tiles_x = (w + 15) >> 4;
+    const long total = (long)n * h * tiles_x;
+    // XCD-aware split: blocks b and b+8 share an XCD (and its L2); give each XCD group one
+    // contiguous eighth of the tile range so that halo rows are re-read from the same L2.
+    const int xcd = blockIdx.x & 7;
+    const int nblk_x = (gridDim.x + 7 - xcd) >> 3;        // blocks in this XCD group
+    const long chunk = (total + 7) >> 3;
+    const long t_begin = (long)xcd * chunk;
+    const long t_end = (t_begin + chunk < total) ? t_begin + chunk : total;
+    const long stride = (long)nblk_x * 4;
+    long tile = t_begin + (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    if (tile >= t_end) return;
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
+    const unsigned oob = in_bytes;   // offset >= num_records -> hardware returns 0
+
+    auto compute_store = [&](const a_frags &a, long tl) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v4[t][j], wr[t][j][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v4[t][j], wr[t][j][1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v2[t][j], wr[t][4 + j][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v2[t][j], wr[t][4 + j][1], acc1, 0, 0, 0);
+            }
+        }
+        const int xt = (int)(tl % tiles_x);
+        const long rowid = tl / tiles_x;     // = img*h + y
+        store_tile_relu(y, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1, b0, b1);
+    };
+
+    a_frags A0, A1;
+    dil_load(A0, rsrc, oob, tile, tiles_x, h, w, d, lane);
+    for (;;) {
+        long nxt = tile + stride;
+        if (nxt < t_end) dil_load(A1, rsrc, oob, nxt, tiles_x, h, w, d, lane);
+        compute_store(A0, tile);
+        tile = nxt;
+        if (tile >= t_end) break;
+        nxt = tile + stride;
+        if (nxt < t_end) dil_load(A0, rsrc, oob, nxt, tiles_x, h, w, d, lane);
+        compute_store(A1, tile);
+        tile = nxt;
+        if (tile >= t_end) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Head: 1x1 conv 24 -> k_out, no activation (net.py:311).  Thread per pixel.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, float *__restrict__ logits,
+                                                   const float *__restrict__ hk, const float *__restrict__ hb,
+                                                   long npix, int k_out)
+{
+    __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
+    __shared__ float s_b[UBD_MAX_CLASSES + 1];
+    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
+    for (int t = threadIdx.x; t < k_out; t += blockDim.x) s_b[t] = hb[t];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const f32x4 *px = (const f32x4 *)(x + p * UBD_C);
+        float v[UBD_C];
+#pragma unroll
+        for (int c4 = 0; c4 < 6; ++c4) {
+            f32x4 t = px[c4];
+            v[c4 * 4 + 0] = t[0]; v[c4 * 4 + 1] = t[1]; v[c4 * 4 + 2] = t[2]; v[c4 * 4 + 3] = t[3];
+        }
+        for (int ko = 0; ko < k_out; ++ko) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < UBD_C; ++c) acc = fmaf(v[c], s_k[c * k_out + ko], acc);
+            logits[p * k_out + ko] = acc + s_b[ko];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------
+static size_t act_bytes(const ubd_handle *, long n, long hh, long ww) { return (size_t)(n * hh * ww) * UBD_C * sizeof(float); }
+
+void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L)
+{
+    const size_t wf = (3 * (UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS) + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS) * sizeof(float);
+    size_t off = 0;
+    L->off_wfrag = off; off += ubd_align_up(wf, 256);
+    const size_t a = ubd_align_up(act_bytes(h, n, H / 2, W / 2), 256);
+    const size_t b = ubd_align_up(act_bytes(h, n, H / 4, W / 4), 256);
+    L->off_a1 = off; off += a;
+    L->off_a2 = off; off += a;
+    if (training) {
+        for (int k = 0; k < 7; ++k) { L->off_acts[k] = off; off += b; }
+        L->off_b[0] = L->off_acts[0]; L->off_b[1] = L->off_acts[1];
+    } else {
+        L->off_b[0] = off; off += b;
+        L->off_b[1] = off; off += b;
+        for (int k = 0; k < 7; ++k) L->off_acts[k] = L->off_b[k & 1];
+    }
+    L->total = off;
+}
+
+extern "C" size_t ubd_forward_workspace_bytes(const ubd_handle *h, int n, int height, int width)
+{
+    ubd_fwd_layout L;
+    ubd_fwd_layout_compute(h, n, height, width, 0, &L);
+    return L.total;
+}
+
+static int grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu)
+{
+    long blocks = (waves_needed + waves_per_block - 1) / waves_per_block;
+    long cap = (long)num_cus * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int CIN, int STRIDE>
+static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, const float *frag, const float *bias,
+                       int n, int H, int W, int OH, int OW, int pad_lo, float sc, float sh, hipStream_t st)
+{
+    long tiles = (long)n * OH * ((OW + 15) / 16);
+    int grid = grid_for(tiles, h->num_cus, 4, 8);
+    if (in_u8)
+        hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
+    else
+        hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
+}
+
+static void launch_pack(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st)
+{
+    pack_args pa;
+    for (int s = 0; s < 3; ++s) { pa.off_sep_dw[s] = h->off_sep_dw[s]; pa.off_sep_pw[s] = h->off_sep_pw[s]; }
+    for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
+    pa.c_in = h->cfg.c_in;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, st, params, wfrag, pa);
+}
+
+static void launch_dil(const ubd_handle *h, const float *params, const float *wfrag, int k, const float *in, float *out,
+                       int n, int H4, int W4, hipStream_t st)
+{
+    const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
+    const float *dfrag = wfrag + 3 * per_sep;
+    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
+    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
+    int grid = grid_for(tiles, h->num_cus, 4, 1);
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(dilconv_f32_kernel, dim3(grid), dim3(256), 0, st, in, out, dfrag + (size_t)k * UBD_DIL_FRAG_FLOATS,
+                       params + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], in_bytes);
+}
+
+extern "C" int ubd_pack_weights(ubd_handle *h, const float *params, void *workspace, size_t workspace_bytes, void *stream)
+{
+    UBD_REQUIRE(h && params && workspace, "ubd_pack_weights: null argument");
+    ubd_fwd_layout L;
+    ubd_fwd_layout_compute(h, 1, 4, 4, 0, &L);
+    UBD_REQUIRE(workspace_bytes >= L.off_a1, "ubd_pack_weights: workspace too small");
+    launch_pack(h, params, (float *)((char *)workspace + L.off_wfrag), (hipStream_t)stream);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ubd_dilated_layer(ubd_handle *h, const float *params, int layer, const void *in, void *out, int n,
+                                 int map_h, int map_w, const void *workspace, void *stream)
+{
+    UBD_REQUIRE(h && params && in && out && workspace, "ubd_dilated_layer: null argument");
+    UBD_REQUIRE(layer >= 0 && layer < UBD_NUM_DIL, "ubd_dilated_layer: layer %d out of range", layer);
+    UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_dilated_layer: only UBD_F32 in this build");
+    UBD_REQUIRE((size_t)n * map_h * map_w * UBD_C * 4 < 0xFFFFFFFFull, "ubd_dilated_layer: tensor too large");
+    launch_dil(h, params, (const float *)workspace, layer, (const float *)in, (float *)out, n, map_h, map_w, (hipStream_t)stream);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Runs L1..L9 + head.  acts[0..8] receive the hidden activations (L1..L9 outputs).
+int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st)
+{
+    UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_forward: only UBD_F32 activations are implemented in this build");
+    UBD_REQUIRE(n > 0 && H > 0 && W > 0 && (H % 4) == 0 && (W % 4) == 0, "ubd_forward: height and width must be positive multiples of 4 (got %d x %d)", H, W);
+    UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
+    UBD_REQUIRE(!(in_dtype == UBD_IN_U8 && h->cfg.c_in == UBD_C), "ubd_forward: u8 input needs c_in 1 or 3");
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    UBD_REQUIRE((size_t)n * H4 * W4 * UBD_C * 4 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
+    float *wfrag = (float *)(ws + L.off_wfrag);
+    float *a1 = (float *)(ws + L.off_a1), *a2 = (float *)(ws + L.off_a2);
+
+    launch_pack(h, params, wfrag, st);
+
+    const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
+    const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
+    const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;
+    // (image - 127.5) / 127.5 (net.py:217-218); identity otherwise.  sc = subtrahend, sh = divisor.
+    float sc = 0.f, sh = 1.f;
+    if (preprocessing == UBD_PRE_MOBILENET) { sc = 127.5f; sh = 127.5f; }
+    const int u8 = in_dtype == UBD_IN_U8;
+    if (h->cfg.c_in == 1)
+        launch_sep<1, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
+    else
+        launch_sep<3, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
+    launch_sep<UBD_C, 1>(h, a1, 0, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+    float *cur = (float *)(ws + L.off_acts[0]);
+    launch_sep<UBD_C, 2>(h, a2, 0, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+
+    for (int k = 0; k < UBD_NUM_DIL; ++k) {
+        float *nxt = (float *)(ws + L.off_acts[k + 1]);
+        launch_dil(h, params, wfrag, k, cur, nxt, n, H4, W4, st);
+        cur = nxt;
+    }
+    const long npix = (long)n * H4 * W4;
+    int hgrid = (int)((npix + 255) / 256);
+    if (hgrid > h->num_cus * 8) hgrid = h->num_cus * 8;
+    hipLaunchKernelGGL(head_kernel, dim3(hgrid), dim3(256), 0, st, cur, logits, params + h->off_head_k, params + h->off_head_b, npix, h->k_out);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ubd_forward(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                           int n, int height, int width, float *logits, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    UBD_REQUIRE(h && params && images && logits && workspace, "ubd_forward: null argument");
+    ubd_fwd_layout L;
+    ubd_fwd_layout_compute(h, n, height, width, 0, &L);
+    UBD_REQUIRE(workspace_bytes >= L.total, "ubd_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    return ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, L, (hipStream_t)stream);
+}

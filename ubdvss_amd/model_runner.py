@@ -1,0 +1,77 @@
+"""ModelRunner.predict -- host mirror of semantic_segmentation/model_runner.py:31-38, :105-148.
+
+The reference runs ``model.predict`` on the device, then thresholds with numpy and calls
+``SegmapManager.postprocess`` (OpenCV) image by image on the host.  Here the forward pass, the
+threshold, the component labelling and the box fitting all run on the MI355X; only the final
+(count, quads, classes) lists cross PCIe.
+"""
+import numpy as np
+import torch
+
+from . import utils
+from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
+
+
+class ModelRunner:
+    def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256):
+        """model_runner.py:31-38: pixel_probability > pixel_threshold is positive."""
+        self._net_config = net_config
+        eps = 1e-9
+        self._logit_threshold = - np.log(1 / np.clip(pixel_threshold, eps, 1 - eps) - 1)
+        self._cap = max_objects_per_image
+
+    @property
+    def logit_threshold(self):
+        return self._logit_threshold
+
+    def predict_on_device(self, model, images):
+        """images: device tensor (N,H,W,C).  Returns device tensors
+        (logits, binary_map (N,h,w) int32, quads (N,cap,8), classes or None, counts (N))."""
+        logits = model.predict_on_device(images)
+        bmap, quads, classes, counts = model.postprocess_on_device(
+            logits, self._logit_threshold, self._net_config.get_scale(),
+            self._net_config.get_min_pixels_for_detection(), cap=self._cap)
+        return logits, bmap, quads, classes, counts
+
+    def predict(self, model, images, rescale=False, meta_infos=None):
+        """Same contract as the reference (model_runner.py:105-138): returns
+        (detection map (N,h,w,1) of {0,1}, classification_logits (N,h,w,n_cls), found_objects)."""
+        assert not rescale or (meta_infos is not None and len(images) == len(meta_infos))
+        x = np.asarray(images)
+        if x.dtype != np.uint8:
+            x = x.astype(np.float32)
+        xt = torch.from_numpy(np.ascontiguousarray(x)).to(model.device)
+        if xt.dtype == torch.uint8:
+            xt = xt.float()                 # numpy images arrive already preprocessed, as in the reference
+        logits, bmap, quads, classes, counts = self.predict_on_device(model, xt)
+        counts_h = counts.cpu().numpy()
+        if (counts_h > self._cap).any():
+            raise RuntimeError(f"more than max_objects_per_image={self._cap} objects in an image "
+                               f"(max found {int(counts_h.max())}); raise the capacity")
+        quads_h = quads.cpu().numpy()
+        classes_h = classes.cpu().numpy() if classes is not None else None
+        logits_h = logits.cpu().numpy()
+        detection_logits = bmap.cpu().numpy().astype(np.int64)[..., None]
+        classification_logits = logits_h[..., 1:]
+        with_cls = self._net_config.is_classification_supported()
+        found_objects = []
+        for i in range(x.shape[0]):
+            objs = []
+            for j in range(int(counts_h[i])):
+                bbox = quads_h[i, j].astype(int)
+                objs.append(ClassifiedObjectMarkup(bbox, classes_h[i, j]) if with_cls else ObjectMarkup(bbox))
+            found_objects.append(objs)
+        if rescale:
+            found_objects = self.rescale(found_objects, meta_infos)
+        return detection_logits, classification_logits, found_objects
+
+    @staticmethod
+    def rescale(found_objects, meta_infos):
+        """model_runner.py:140-148."""
+        assert len(found_objects) == len(meta_infos)
+        return [[
+            found_objects[i][j].create_same_markup(
+                utils.rescale_bbox(found_objects[i][j].bbox,
+                                   xscale=meta_infos[i].xscale,
+                                   yscale=meta_infos[i].yscale)
+            ) for j in range(len(found_objects[i]))] for i in range(len(found_objects))]

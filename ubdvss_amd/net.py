@@ -1,0 +1,368 @@
+"""Network definition + config -- host mirror of semantic_segmentation/net.py.
+
+``NetConfig`` keeps the reference's constructor and getters (net.py:73-214).
+``NetManager.build_model`` (net.py:273-314) creates a ``Model`` whose ``predict`` replaces
+``keras.Model.predict`` (called at model_runner.py:119 and predict.py:74-76) with the HIP
+forward pass of libubd_hip.so.  Weights live in one flat fp32 device vector in Keras
+``get_weights()`` order; ``get_weights`` / ``set_weights`` use the Keras shapes.
+"""
+import copy
+import ctypes
+import logging
+import os
+import pickle
+from enum import Enum
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_FILTERS = 24                      # net.py:289
+DILATIONS = (1, 2, 4, 8, 16, 1)     # net.py:298-304
+
+
+class PreprocessingType(Enum):      # net.py:62-64
+    NONE = 0
+    MOBILENET_LIKE = 1
+
+
+supported_preprocessing_types = {
+    "none": PreprocessingType.NONE,
+    "mobilenet_like": PreprocessingType.MOBILENET_LIKE,
+}
+
+
+def preprocess_image_mobilenet(image):      # net.py:217-218
+    return (image - 127.5) / 127.5
+
+
+def depreprocess_image_mobilenet(image):    # net.py:221-222
+    return image * 127.5 + 127.5
+
+
+class NetConfig:
+    """Same fields, defaults and getters as the reference NetConfig (net.py:73-214).
+    ``class_names`` may be given directly instead of ``object_types_fname``."""
+
+    @staticmethod
+    def from_others(base_config, side_multiple=None, max_image_side=None, min_pixels_for_detection=None):
+        new_config = copy.deepcopy(base_config)
+        if side_multiple:
+            new_config._side_multiple = side_multiple
+        if max_image_side:
+            new_config._max_side = max_image_side
+        if min_pixels_for_detection:
+            new_config._min_pixels_for_detection = min_pixels_for_detection
+        return new_config
+
+    def __init__(self, object_types_fname=None, scale=4, fml_compatible=True, no_classification=False,
+                 side_multiple=64, max_image_side=512, min_pixels_for_detection=5,
+                 preprocessing=PreprocessingType.NONE, grey=True, class_names=None):
+        if object_types_fname is None and class_names is None:
+            self._class_names = None
+            self._is_classification_supported = False
+        else:
+            self._is_classification_supported = not no_classification
+            if class_names is not None:
+                self._class_names = list(class_names)
+                self._class_name_to_id = dict((c, i) for i, c in enumerate(self._class_names))
+            else:
+                self._read_classnames_from_file(object_types_fname)
+        self._grey = grey
+        self._scale = scale
+        self._fml_compatible = fml_compatible
+        self._preprocessing = preprocessing
+        self._side_multiple = side_multiple
+        self._max_side = max_image_side
+        self._min_pixels_for_detection = min_pixels_for_detection
+
+    def is_grey(self):
+        return self._grey
+
+    def get_scale(self):
+        return self._scale
+
+    def get_min_pixels_for_detection(self):
+        return self._min_pixels_for_detection
+
+    def get_side_multiple(self):
+        return self._side_multiple
+
+    def get_max_side(self):
+        return self._max_side
+
+    def is_fml_compatible(self):
+        return self._fml_compatible
+
+    def get_preprocessing_type(self):
+        return self._preprocessing
+
+    def get_preprocessing_fn(self):
+        if self._preprocessing == PreprocessingType.NONE:
+            return lambda x: x
+        elif self._preprocessing == PreprocessingType.MOBILENET_LIKE:
+            return preprocess_image_mobilenet
+        raise ValueError("Unknown preprocessing type")
+
+    def get_depreprocessing_fn(self):
+        if self._preprocessing == PreprocessingType.NONE:
+            return lambda x: x
+        elif self._preprocessing == PreprocessingType.MOBILENET_LIKE:
+            return depreprocess_image_mobilenet
+        raise ValueError("Unknown preprocessing type")
+
+    def get_class_names(self):
+        return self._class_names
+
+    def get_n_classes(self):
+        return len(self._class_names)
+
+    def get_class_name(self, class_id):
+        return self._class_names[class_id]
+
+    def get_class_id(self, class_name):
+        return self._class_name_to_id[class_name]
+
+    def is_class_supported(self, class_name):
+        return self._class_names is None or class_name in self._class_name_to_id
+
+    def is_classification_supported(self):
+        return self._is_classification_supported
+
+    def _read_classnames_from_file(self, path):
+        assert os.path.exists(path), f"File with object class names {path} does not exist"
+        class_names = []
+        with open(path, 'r') as f:
+            for line in f:
+                if line.strip():
+                    class_names.append(line.strip())
+        self._class_names = class_names
+        self._class_name_to_id = dict((class_name, i) for i, class_name in enumerate(class_names))
+
+    def __str__(self):
+        sb = ["Net Config:"]
+        for key in self.__dict__:
+            if key.startswith('_'):
+                sb.append("\t{key}={value}".format(key=key[1:], value=self.__dict__[key]))
+        return '\n'.join(sb)
+
+
+def weight_shapes(c_in, n_classes):
+    """Keras ``model.get_weights()`` order and shapes of the built model (net.py:292-311)."""
+    shapes, cin = [], c_in
+    for _ in range(3):
+        shapes += [(3, 3, cin, 1), (1, 1, cin, N_FILTERS), (N_FILTERS,)]
+        cin = N_FILTERS
+    for _ in DILATIONS:
+        shapes += [(3, 3, N_FILTERS, N_FILTERS), (N_FILTERS,)]
+    shapes += [(1, 1, N_FILTERS, 1 + n_classes), (1 + n_classes,)]
+    return shapes
+
+
+_DTYPES = {"float32": _lib.UBD_F32, "bfloat16": _lib.UBD_BF16, "float16": _lib.UBD_F16}
+
+
+class Model:
+    """The dilated FCN on one MI355X.  ``predict`` has ``keras.Model.predict`` semantics
+    (numpy NHWC in, numpy logits out); ``predict_on_device`` keeps everything in HBM."""
+
+    def __init__(self, net_config, dtype="float32", device=None, seed=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ubdvss_amd.Model needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
+        self._lib = _lib.load()
+        self.net_config = net_config
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.c_in = 1 if net_config.is_grey() else 3
+        self.n_classes = net_config.get_n_classes() if net_config.is_classification_supported() else 0
+        self.k_out = 1 + self.n_classes
+        self.dtype = dtype
+        cfg = _lib.UbdConfig(self.c_in, self.n_classes, int(net_config.is_fml_compatible()), _DTYPES[dtype])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ubd_create(ctypes.byref(cfg), ctypes.byref(handle)), "ubd_create")
+        self._h = handle
+        n = self._lib.ubd_param_count(self._h)
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._pp_ws = None
+        self.set_weights(self._glorot_init(seed))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ubd_destroy(h)
+
+    # ---------------------------------------------------------------- weights
+    def _glorot_init(self, seed):
+        """Keras defaults: glorot_uniform kernels, zero biases (net.py:226,245)."""
+        rng = np.random.default_rng(seed)
+        out = []
+        for shape in weight_shapes(self.c_in, self.n_classes):
+            if len(shape) == 1:
+                out.append(np.zeros(shape, np.float32))
+            else:
+                kh, kw, cin, cout = shape
+                lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+                out.append(rng.uniform(-lim, lim, shape).astype(np.float32))
+        return out
+
+    def count_params(self):
+        return int(self.params.numel())
+
+    def get_weights(self):
+        flat = self.params.detach().cpu().numpy()
+        out, off = [], 0
+        for shape in weight_shapes(self.c_in, self.n_classes):
+            k = int(np.prod(shape))
+            out.append(flat[off:off + k].reshape(shape).copy())
+            off += k
+        return out
+
+    def set_weights(self, weights):
+        shapes = weight_shapes(self.c_in, self.n_classes)
+        if len(weights) != len(shapes):
+            raise ValueError(f"expected {len(shapes)} weight arrays, got {len(weights)}")
+        for w, s in zip(weights, shapes):
+            if tuple(np.shape(w)) != tuple(s):
+                raise ValueError(f"weight shape {np.shape(w)} != expected {s}")
+        flat = np.concatenate([np.asarray(w, np.float32).reshape(-1) for w in weights])
+        self.params.copy_(torch.from_numpy(flat))
+
+    def save_weights(self, path):
+        np.savez(path, params=self.params.detach().cpu().numpy(), c_in=self.c_in, n_classes=self.n_classes)
+
+    def load_weights(self, path):
+        d = np.load(path)
+        if int(d["c_in"]) != self.c_in or int(d["n_classes"]) != self.n_classes:
+            raise ValueError("weight file was saved for a different architecture")
+        self.params.copy_(torch.from_numpy(d["params"]))
+
+    # ---------------------------------------------------------------- forward
+    def _workspace(self, attr, nbytes):
+        ws = getattr(self, attr)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            setattr(self, attr, ws)
+        return ws
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def predict_on_device(self, images, out=None, preprocessing=None):
+        """images: torch tensor (N,H,W,C_in) on this device, float32 (fed as is) or uint8 (the
+        NetConfig preprocessing is fused into the first layer).  Returns fp32 logits (N,H/4,W/4,K)."""
+        if images.device != self.device:
+            raise ValueError("images must live on the model's device")
+        if images.dim() != 4 or images.shape[3] != self.c_in:
+            raise ValueError(f"expected NHWC images with {self.c_in} channels, got {tuple(images.shape)}")
+        images = images.contiguous()
+        n, hh, ww, _ = images.shape
+        if hh % 4 or ww % 4:
+            raise ValueError("image height and width must be multiples of 4")
+        if images.dtype == torch.uint8:
+            in_dtype = _lib.UBD_IN_U8
+            pre = self.net_config.get_preprocessing_type() if preprocessing is None else preprocessing
+            pre = _lib.UBD_PRE_MOBILENET if pre == PreprocessingType.MOBILENET_LIKE else _lib.UBD_PRE_NONE
+        elif images.dtype == torch.float32:
+            in_dtype, pre = _lib.UBD_IN_F32, _lib.UBD_PRE_NONE
+        else:
+            raise ValueError(f"unsupported image dtype {images.dtype}")
+        if out is None:
+            out = torch.empty((n, hh // 4, ww // 4, self.k_out), dtype=torch.float32, device=self.device)
+        nbytes = self._lib.ubd_forward_workspace_bytes(self._h, n, hh, ww)
+        ws = self._workspace("_ws", nbytes)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ubd_forward(self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre,
+                                             n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       "ubd_forward")
+        return out
+
+    def predict(self, images, batch_size=None):
+        """keras.Model.predict: numpy (N,H,W,C_in) float -> numpy float32 logits (N,H/4,W/4,K)."""
+        x = np.asarray(images)
+        if x.dtype != np.uint8:
+            x = x.astype(np.float32)
+        xt = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        pre = PreprocessingType.NONE      # numpy float input is already preprocessed (data_generators.py:113,148)
+        return self.predict_on_device(xt, preprocessing=pre).cpu().numpy()
+
+    # ---------------------------------------------------------------- postprocess
+    def postprocess_on_device(self, logits, logit_threshold, scale, min_area, cap=256, want_map=True):
+        """logits: fp32 (N,h,w,K) device tensor.  Returns (binary_map int32 (N,h,w) or None,
+        quads int32 (N,cap,8), classes int32 (N,cap) or None, counts int32 (N))."""
+        logits = logits.contiguous()
+        n, mh, mw, k = logits.shape
+        if k != self.k_out:
+            raise ValueError(f"logits have {k} channels, model has {self.k_out}")
+        dev = self.device
+        bmap = torch.empty((n, mh, mw), dtype=torch.int32, device=dev) if want_map else None
+        quads = torch.zeros((n, cap, 8), dtype=torch.int32, device=dev)
+        classes = torch.zeros((n, cap), dtype=torch.int32, device=dev) if self.n_classes > 0 else None
+        counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        nbytes = self._lib.ubd_postprocess_workspace_bytes(self._h, n, mh, mw, cap)
+        ws = self._workspace("_pp_ws", nbytes)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.ubd_postprocess(
+                self._h, logits.data_ptr(), n, mh, mw, float(logit_threshold), int(scale), float(min_area),
+                bmap.data_ptr() if bmap is not None else None, quads.data_ptr(),
+                classes.data_ptr() if classes is not None else None, counts.data_ptr(), cap,
+                ws.data_ptr(), ws.numel(), self._stream()), "ubd_postprocess")
+        return bmap, quads, classes, counts
+
+
+class NetManager:
+    """Builds / saves / loads the model (net.py:255-494).  File formats are this package's own
+    (flat fp32 ``.npz`` + pickled NetConfig); Keras HDF5 interchange is out of scope here."""
+
+    CURRENT_MODEL_FILENAME = "model.npz"
+    INFERENCE_MODEL_FILENAME = "inference_model.npz"
+    PICKLED_CONFIG_FILENAME = "config.pkl"
+
+    def __init__(self, log_dir, net_config=None):
+        self._log_dir = log_dir
+        if net_config is not None:
+            self._net_config = net_config
+        else:
+            self.load_config()
+        self._model = None
+
+    def build_model(self, dtype="float32", seed=None):
+        self._model = Model(self._net_config, dtype=dtype, seed=seed)
+        self._net_config._scale = 4                     # net.py:314
+        return self._net_config
+
+    def get_keras_model(self):                          # name kept for drop-in use (net.py:415-416)
+        return self._model
+
+    def get_model(self):
+        return self._model
+
+    def save_model(self):
+        self._model.save_weights(os.path.join(self._log_dir, self.CURRENT_MODEL_FILENAME))
+        self.save_config()
+
+    def save_inference(self):                           # net.py:422-427
+        self._model.save_weights(os.path.join(self._log_dir, self.INFERENCE_MODEL_FILENAME))
+
+    def load_model(self, model_path=None, dtype="float32"):
+        if model_path is None:                          # loader preference of net.py:460-466
+            for name in (self.INFERENCE_MODEL_FILENAME, self.CURRENT_MODEL_FILENAME):
+                cand = os.path.join(self._log_dir, name)
+                if os.path.exists(cand):
+                    model_path = cand
+                    break
+        if model_path is None:
+            raise FileNotFoundError(f"no model file in {self._log_dir}")
+        logging.info(f"Loading model from {model_path}")
+        self._model = Model(self._net_config, dtype=dtype)
+        self._model.load_weights(model_path)
+        return self._net_config
+
+    def save_config(self):                              # net.py:468-469
+        with open(os.path.join(self._log_dir, self.PICKLED_CONFIG_FILENAME), 'wb') as f:
+            pickle.dump(self._net_config, f)
+
+    def load_config(self):                              # net.py:471-472
+        with open(os.path.join(self._log_dir, self.PICKLED_CONFIG_FILENAME), 'rb') as f:
+            self._net_config = pickle.load(f)

@@ -1,0 +1,65 @@
+"""SegmapManager.postprocess -- host mirror of semantic_segmentation/segmap_manager.py:41-69.
+
+Same static-method signature as the reference; the work (external components, contourArea
+filter, minAreaRect, boxPoints, class vote) runs in libubd_hip.so on the MI355X.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
+
+_handles = {}
+
+
+def _handle(n_classes, device):
+    key = (n_classes, str(device))
+    if key not in _handles:
+        lib = _lib.load()
+        cfg = _lib.UbdConfig(1, n_classes, 1, _lib.UBD_F32)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.ubd_create(ctypes.byref(cfg), ctypes.byref(h)), "ubd_create")
+        _handles[key] = h
+    return _handles[key]
+
+
+class SegmapManager:
+    @staticmethod
+    def postprocess(seg_map, seg_map_class_logits=None, scale=1, min_area_threshold=5, max_objects=1024):
+        """seg_map: (h,w,1) or (h,w) array of {0,1}; seg_map_class_logits: (h,w,n_cls) or None.
+        Returns list[ObjectMarkup] / list[ClassifiedObjectMarkup] like the reference."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("SegmapManager.postprocess needs an MI355X; there is no CPU fallback")
+        lib = _lib.load()
+        device = torch.device(f"cuda:{torch.cuda.current_device()}")
+        m = np.asarray(seg_map)
+        m = m.reshape(m.shape[0], m.shape[1])
+        h, w = m.shape
+        n_cls = 0 if seg_map_class_logits is None else int(np.shape(seg_map_class_logits)[-1])
+        # pack (map, class logits) as a (1,h,w,1+n_cls) logits tensor; map != 0 <=> "logit" 1 > 0.5
+        lg = np.zeros((1, h, w, 1 + n_cls), np.float32)
+        lg[0, :, :, 0] = (m != 0)
+        if n_cls:
+            lg[0, :, :, 1:] = np.asarray(seg_map_class_logits, np.float32)
+        lgt = torch.from_numpy(lg).to(device)
+        hd = _handle(n_cls, device)
+        cap = max_objects
+        quads = torch.zeros((1, cap, 8), dtype=torch.int32, device=device)
+        classes = torch.zeros((1, cap), dtype=torch.int32, device=device)
+        counts = torch.zeros((1,), dtype=torch.int32, device=device)
+        ws = torch.empty(int(lib.ubd_postprocess_workspace_bytes(hd, 1, h, w, cap)), dtype=torch.uint8, device=device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(lib.ubd_postprocess(hd, lgt.data_ptr(), 1, h, w, 0.5, int(scale), float(min_area_threshold),
+                                       None, quads.data_ptr(), classes.data_ptr(), counts.data_ptr(), cap,
+                                       ws.data_ptr(), ws.numel(), stream), "ubd_postprocess")
+        n = int(counts.cpu()[0])
+        if n > cap:
+            raise RuntimeError(f"more than max_objects={cap} objects found ({n})")
+        q = quads.cpu().numpy()[0, :n].astype(int)
+        if seg_map_class_logits is None:
+            return [ObjectMarkup(bbox) for bbox in q]
+        c = classes.cpu().numpy()[0, :n]
+        return [ClassifiedObjectMarkup(bbox, class_id) for bbox, class_id in zip(q, c)]

@@ -1,0 +1,96 @@
+"""Train step -- host mirror of ``model.compile(Adam(lr), loss)`` + the per-step body of
+``fit_generator`` (train.py:110-112, :176-188): forward, loss, backward, (data-parallel gradient
+all-reduce), Adam.
+
+Multi-GPU: one process per GPU; when ``torch.distributed`` is initialised the flat fp32 gradient
+vector (33 028 floats for the RGB model) is summed with ONE all-reduce over RCCL/xGMI and divided
+by the world size inside the fused Adam kernel.  The loss (incl. its batch-global top-k) is
+evaluated per replica (option 1).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .net import PreprocessingType
+
+
+class Adam:
+    """keras.optimizers.Adam defaults (train.py:110): beta1 .9, beta2 .999, epsilon 1e-7."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+
+
+class Trainer:
+    def __init__(self, model, optimizer=None, process_group=None):
+        self.model = model
+        self.opt = optimizer or Adam()
+        self._lib = _lib.load()
+        n = model.count_params()
+        dev = model.device
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.iterations = 0
+        self._ws = None
+        self._pg = process_group
+
+    def _world(self):
+        return dist.get_world_size(self._pg) if dist.is_available() and dist.is_initialized() else 1
+
+    def broadcast_weights(self, src=0):
+        if self._world() > 1:
+            dist.broadcast(self.model.params, src=src, group=self._pg)
+
+    def backward_on_device(self, images, targets):
+        """images: device tensor (N,H,W,C) float32 or uint8; targets: device int32 (N,H/4,W/4[,1]).
+        Leaves gradients in self.grads and [total, det, cls, k] in self.loss."""
+        mdl = self.model
+        images = images.contiguous()
+        n, hh, ww, _ = images.shape
+        targets = targets.reshape(n, hh // 4, ww // 4).to(torch.int32).contiguous()
+        if images.dtype == torch.uint8:
+            in_dtype = _lib.UBD_IN_U8
+            pre = _lib.UBD_PRE_MOBILENET if mdl.net_config.get_preprocessing_type() == PreprocessingType.MOBILENET_LIKE else _lib.UBD_PRE_NONE
+        else:
+            in_dtype, pre = _lib.UBD_IN_F32, _lib.UBD_PRE_NONE
+        nbytes = self._lib.ubd_train_workspace_bytes(mdl._h, n, hh, ww)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=mdl.device)
+        with torch.cuda.device(mdl.device):
+            _lib.check(self._lib.ubd_train_step(mdl._h, mdl.params.data_ptr(), images.data_ptr(), in_dtype, pre,
+                                                targets.data_ptr(), n, hh, ww, self.grads.data_ptr(),
+                                                self.loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                mdl._stream()), "ubd_train_step")
+
+    def apply_gradients(self):
+        world = self._world()
+        if world > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._pg)
+        self.iterations += 1
+        o = self.opt
+        with torch.cuda.device(self.model.device):
+            _lib.check(self._lib.ubd_adam_step(self.model.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                                               self.v.data_ptr(), self.grads.numel(), self.iterations, o.lr, o.beta_1,
+                                               o.beta_2, o.epsilon, 1.0 / world, self.model._stream()), "ubd_adam_step")
+
+    def train_step_on_device(self, images, targets):
+        self.backward_on_device(images, targets)
+        self.apply_gradients()
+        return self.loss
+
+    def train_on_batch(self, images, targets):
+        """Keras ``train_on_batch``: numpy batch in, scalar loss out."""
+        dev = self.model.device
+        x = np.asarray(images)
+        if x.dtype != np.uint8:
+            x = x.astype(np.float32)
+        xt = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        if xt.dtype == torch.uint8:
+            xt = xt.float()
+        yt = torch.from_numpy(np.ascontiguousarray(np.asarray(targets)).astype(np.int32)).to(dev)
+        return float(self.train_step_on_device(xt, yt)[0].item())
