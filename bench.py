@@ -49,7 +49,6 @@ def cpu_baseline(seconds):
     postprocess) on a bounded sample: batches of 4 images 512x512x3, all host threads."""
     from oracle import net_numpy as onet, net_torch as otorch, cv_post as ocv
     from ubdvss_amd import synthetic
-    torch.set_num_threads(os.cpu_count() or 1)
     w = onet.init_weights(1, C_IN, 0)
     tw = otorch.to_torch_weights(w, torch.float32)
     nb = 4
@@ -62,6 +61,19 @@ def cpu_baseline(seconds):
         det = (lg[..., 0] > -0.0).astype(np.uint8)
         return [ocv.postprocess(det[i], None, 4, 5) for i in range(nb)]
 
+    # thread count: oneDNN on these small convolutions does not scale to hundreds of host threads, so
+    # probe a few counts briefly and time the sample with the fastest (reported as "cores")
+    ncpu = os.cpu_count() or 1
+    best = (None, 1e30)
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(nt)
+        step()
+        t0 = time.perf_counter(); step(); dt = time.perf_counter() - t0
+        if dt < best[1]:
+            best = (nt, dt)
+        if dt > 4.0:
+            break
+    torch.set_num_threads(best[0])
     step()
     t0 = time.perf_counter()
     n = 0
@@ -69,7 +81,7 @@ def cpu_baseline(seconds):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
+        if el >= seconds or n >= 2000:
             break
     return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} batches of {nb} textured 512x512x3 images, torch-CPU fp32 forward (oneDNN) + C "

@@ -59,6 +59,7 @@ size_t ubd_param_count(const ubd_handle *h);
 size_t ubd_forward_workspace_bytes(const ubd_handle *h, int n, int height, int width);
 size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int height, int width);
 size_t ubd_postprocess_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w, int cap);
+size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
 
 /* --- inference ----------------------------------------------------------- */
 /* Replaces keras Model.predict(images) at model_runner.py:119 / predict.py:74-76.

@@ -1,0 +1,78 @@
+"""GPU parity: fused HIP loss (value + gradient wrt logits) vs the fp64 numpy oracle.
+Tolerances (fp32 kernel vs fp64 oracle): loss relative error <= 1e-4 (SURVEY 8(d) gate; observed
+~1e-6), gradient max abs error <= 1e-6 + 1e-4 * max|grad|."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_numpy as oloss
+from ubdvss_amd import losses, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(yt, yp, cls_mode):
+    l_ref, g_ref = oloss.total_loss(yt[..., None], yp, cls_mode)
+    loss4, grad = losses.loss_and_grad(yt, yp)
+    loss4 = loss4.cpu().numpy(); grad = grad.cpu().numpy()
+    got = loss4[0] if cls_mode else loss4[1]
+    assert abs(got - l_ref) <= 1e-4 * abs(l_ref) + 1e-6, (got, l_ref)
+    gerr = np.abs(grad - g_ref).max()
+    assert gerr <= 1e-6 + 1e-4 * np.abs(g_ref).max(), gerr
+    return loss4
+
+
+def test_golden_loss(golden_dir, manifest):
+    d = np.load(os.path.join(golden_dir, "loss_case.npz"))
+    yt = d["y_true"].astype(np.int32)
+    l4 = _check(yt, d["y_pred"][..., :1].copy(), False)
+    assert abs(l4[1] - manifest["loss_case"]["det"]) < 1e-4 * manifest["loss_case"]["det"]
+    l4 = _check(yt, d["y_pred"], True)
+    assert abs(l4[0] - manifest["loss_case"]["total"]) < 1e-4 * manifest["loss_case"]["total"]
+    g = losses.loss_and_grad(yt, d["y_pred"])[1].cpu().numpy()
+    assert np.abs(g - d["g_all"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n_cls,n,h,w", [(0, 4, 32, 48), (3, 2, 64, 64), (1, 1, 16, 16), (8, 2, 128, 128)])
+def test_random_vs_oracle(n_cls, n, h, w):
+    rng = np.random.default_rng(n_cls + n)
+    yt = synthetic.rectangle_maps(40 + n_cls, n, h, w, n_classes=n_cls)
+    yp = rng.normal(0, 3.0, (n, h, w, 1 + n_cls)).astype(np.float32)
+    yp.reshape(-1)[:: 97] *= 8.0                      # some logits beyond the Keras clip points
+    _check(yt, yp, n_cls > 0)
+
+
+def test_degenerate_and_ties():
+    rng = np.random.default_rng(0)
+    yp = rng.normal(0, 1, (1, 16, 16, 1)).astype(np.float32)
+    for fill in (0, 1):                                # no positives / no negatives (counts clamp to 1, k = 1)
+        _check(np.full((1, 16, 16), fill, np.int32), yp, False)
+    # massive ties: constant logits -> the k hard negatives are the k lowest flat indices (tf.nn.top_k)
+    yt = np.zeros((2, 16, 16), np.int32); yt[0, 4:8, 4:8] = 1; yt[1, 0:2, 0:3] = 1
+    yp = np.full((2, 16, 16, 1), 0.25, np.float32)
+    _check(yt, yp, False)
+    yp[..., 0] = 40.0                                  # everything clipped: zero gradient, finite loss
+    l4, g = losses.loss_and_grad(yt, yp)
+    assert torch.isfinite(l4).all() and float(g.abs().max()) == 0.0
+
+
+def test_full_size_batch_property():
+    """cfg3-sized label batch (64 x 128 x 128 = 1M pixels): loss of the oracle on the full tensor
+    (numpy fp64 finishes in seconds) and the selected-count invariant k = min(n_pos, n_neg)."""
+    rng = np.random.default_rng(5)
+    yt = synthetic.rectangle_maps(50, 64, 128, 128, n_classes=0)
+    yp = rng.normal(-1.0, 2.0, (64, 128, 128, 1)).astype(np.float32)
+    l4 = _check(yt, yp, False)
+    n_pos = int((yt > 0).sum())
+    assert int(l4[3]) == min(max(n_pos, 1), max(yt.size - n_pos, 1))
+
+
+def test_get_loss_callable_api():
+    yt = synthetic.rectangle_maps(60, 2, 32, 32, n_classes=2)[..., None]
+    yp = np.random.default_rng(1).normal(0, 2, (2, 32, 32, 3)).astype(np.float32)
+    f = losses.get_loss(classification_mode=True)
+    assert abs(float(f(yt, yp)) - oloss.total_loss(yt, yp, True)[0]) < 1e-3
+    f = losses.get_loss(classification_mode=False)
+    assert abs(float(f(yt, yp)) - oloss.total_loss(yt, yp[..., :1], False)[0]) < 1e-3

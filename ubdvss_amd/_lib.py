@@ -28,6 +28,7 @@ SIGNATURES = {
     "ubd_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_postprocess_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "ubd_loss_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ubd_pack_weights": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "ubd_dilated_layer": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),

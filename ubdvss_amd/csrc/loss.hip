@@ -1,0 +1,329 @@
+// Fused training loss (forward value + gradient w.r.t. the logits) on gfx950.
+//
+// Reference: semantic_segmentation/losses.py
+//   :13-17   weights 15 (positive) / 1 (negative) / 5 (hard negative), detection 1, classification 1
+//   :27-30   z = y_true > 0, p = sigmoid(y_pred[...,0])
+//   :86-126  binary_classification_loss: K.binary_crossentropy (Keras clips p to [1e-7, 1-1e-7] in
+//            fp32 and maps back to logits => x' = clamp(x, -16.118095, +15.942385), zero gradient
+//            where the clamp is active), mean over positives, mean over negatives, mean of
+//            tf.nn.top_k(ce * (1-z), k = min(max(n_pos,1), max(n_neg,1))) over the flattened batch
+//   :65-83   classification_loss: masked sparse softmax CE over channels 1.., / max(n_pos,1)
+//   :47-62   total = 1*detection + 1*classification
+// The batch-global top-k is an exact 3-pass radix select (11/11/10 bits) on the fp32 bit pattern of
+// ce*(1-z) (non-negative => monotone), ties at the k-th value resolved toward the lower flat index
+// like tf.nn.top_k.
+#include "common.h"
+
+#define LOSS_BLOCK 256
+#define LOSS_MAX_BLOCKS 1024
+
+struct loss_hdr {
+    double sum_pos, sum_neg, sum_hard, sum_cls;   // 0..31
+    int n_pos;                                    // 32
+    unsigned k;                                   // top-k size
+    unsigned prefix;                              // radix-select prefix so far
+    unsigned k_rem;                               // rank still to resolve inside the prefix bin
+    unsigned T;                                   // final threshold bits (k-th largest value)
+    unsigned need_eq;                             // how many elements == T are selected
+    unsigned pad[2];
+};
+#define LOSS_HDR_BYTES 256
+
+struct loss_layout {
+    size_t off_hdr, off_hist, off_blockties, off_ce, total;
+};
+
+static void loss_layout_compute(long npix, loss_layout *L)
+{
+    size_t off = 0;
+    L->off_hdr = off;       off += LOSS_HDR_BYTES;
+    L->off_hist = off;      off += 3 * 2048 * sizeof(unsigned);
+    L->off_blockties = off; off += ubd_align_up((LOSS_MAX_BLOCKS + 1) * sizeof(unsigned), 256);
+    L->off_ce = off;        off += ubd_align_up((size_t)npix * sizeof(float), 256);
+    L->total = off;
+}
+
+extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *, int n, int map_h, int map_w)
+{
+    loss_layout L;
+    loss_layout_compute((long)n * map_h * map_w, &L);
+    return L.total;
+}
+
+// Keras clip points evaluated in fp32
+#define LOGIT_LO (-16.11809539794922f)
+#define LOGIT_HI (15.942384719848633f)
+
+__device__ __forceinline__ float bce_from_logit(float x, float z, float &xc)
+{
+    xc = fminf(fmaxf(x, LOGIT_LO), LOGIT_HI);
+    return fmaxf(xc, 0.f) - xc * z + log1pf(expf(-fabsf(xc)));
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+    return r;       // valid in thread 0
+}
+
+// ---- pass 1: per-pixel BCE, batch sums, first-level histogram ------------------------------
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_stats_kernel(const float *__restrict__ logits, int k_out,
+                                                                const int *__restrict__ y_true, long npix,
+                                                                loss_hdr *hdr, unsigned *__restrict__ hist,
+                                                                float *__restrict__ ce_buf)
+{
+    __shared__ unsigned s_hist[2048];
+    __shared__ double s_red[LOSS_BLOCK / 64];
+    for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+    double sp = 0, sn = 0;
+    int np = 0;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const float x = logits[p * k_out];
+        const float z = y_true[p] > 0 ? 1.f : 0.f;
+        float xc;
+        const float ce = bce_from_logit(x, z, xc);
+        const float cn = ce * (1.f - z);
+        ce_buf[p] = cn;
+        sp += (double)(ce * z);
+        sn += (double)cn;
+        np += (z > 0.f);
+        atomicAdd(&s_hist[__float_as_uint(cn) >> 21], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2048; t += blockDim.x)
+        if (s_hist[t]) atomicAdd(&hist[t], s_hist[t]);
+    double r = block_reduce_sum(sp, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_pos, r);
+    r = block_reduce_sum(sn, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_neg, r);
+    r = block_reduce_sum((double)np, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->n_pos, (int)r);
+}
+
+// ---- radix-select scan: pick the bin that holds the k_rem-th largest element -----------------
+// level 0: bins = bits >> 21 (2048), level 1: (bits >> 10) & 2047, level 2: bits & 1023
+__global__ __launch_bounds__(256) void loss_select_kernel(loss_hdr *hdr, const unsigned *__restrict__ hist, int level,
+                                                          long npix)
+{
+    __shared__ unsigned s_part[256];
+    const int nbins = level == 2 ? 1024 : 2048;
+    const int per = nbins / 256;
+    // thread t sums bins [nbins - (t+1)*per, nbins - t*per)  (descending order)
+    unsigned s = 0;
+    for (int j = 0; j < per; ++j) s += hist[nbins - 1 - (threadIdx.x * per + j)];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned k_rem;
+        if (level == 0) {
+            const long n_pos = hdr->n_pos;
+            const long n_neg = npix - n_pos;
+            const long a = n_pos > 1 ? n_pos : 1, b = n_neg > 1 ? n_neg : 1;
+            const unsigned k = (unsigned)(a < b ? a : b);       // losses.py:110
+            hdr->k = k;
+            k_rem = k;
+        } else {
+            k_rem = hdr->k_rem;
+        }
+        unsigned acc = 0;
+        int seg = 0;
+        for (; seg < 255; ++seg) {
+            if (acc + s_part[seg] >= k_rem) break;
+            acc += s_part[seg];
+        }
+        int bin = nbins - 1 - seg * per;
+        for (int j = 0; j < per - 1; ++j, --bin) {
+            const unsigned c = hist[bin];
+            if (acc + c >= k_rem) break;
+            acc += c;
+        }
+        // `bin` holds the k_rem-th largest; `acc` elements are strictly above it
+        k_rem -= acc;
+        if (level == 0) hdr->prefix = (unsigned)bin;
+        else if (level == 1) hdr->prefix = (hdr->prefix << 11) | (unsigned)bin;
+        else { hdr->T = (hdr->prefix << 10) | (unsigned)bin; hdr->need_eq = k_rem; }
+        hdr->k_rem = k_rem;
+    }
+}
+
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__restrict__ ce_buf, long npix,
+                                                               const loss_hdr *hdr, unsigned *__restrict__ hist, int level)
+{
+    __shared__ unsigned s_hist[2048];
+    for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+    const unsigned prefix = hdr->prefix;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const unsigned b = __float_as_uint(ce_buf[p]);
+        if (level == 1) {
+            if ((b >> 21) == prefix) atomicAdd(&s_hist[(b >> 10) & 2047u], 1u);
+        } else {
+            if ((b >> 10) == prefix) atomicAdd(&s_hist[b & 1023u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2048; t += blockDim.x)
+        if (s_hist[t]) atomicAdd(&hist[t], s_hist[t]);
+}
+
+// ---- ties: per-chunk count of elements == T (chunks are contiguous index ranges) --------------
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *__restrict__ ce_buf, long npix, long chunk,
+                                                                   const loss_hdr *hdr, unsigned *__restrict__ blockties)
+{
+    __shared__ double s_red[LOSS_BLOCK / 64];
+    const unsigned T = hdr->T;
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
+    int c = 0;
+    for (long p = lo + threadIdx.x; p < hi; p += blockDim.x) c += (__float_as_uint(ce_buf[p]) == T);
+    const double r = block_reduce_sum((double)c, s_red);
+    if (threadIdx.x == 0) blockties[blockIdx.x] = (unsigned)r;
+}
+
+__global__ void loss_tiescan_kernel(unsigned *blockties, int nblocks)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned acc = 0;
+        for (int b = 0; b < nblocks; ++b) { const unsigned c = blockties[b]; blockties[b] = acc; acc += c; }
+        blockties[nblocks] = acc;
+    }
+}
+
+// ---- gradient + hard-negative / classification sums --------------------------------------------
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
+                                                               const int *__restrict__ y_true, long npix, long chunk,
+                                                               loss_hdr *hdr, const unsigned *__restrict__ blockties,
+                                                               const float *__restrict__ ce_buf, float *__restrict__ dlogits)
+{
+    __shared__ double s_red[LOSS_BLOCK / 64];
+    __shared__ unsigned s_wave_ties[LOSS_BLOCK / 64];
+    const unsigned T = hdr->T, need_eq = hdr->need_eq;
+    const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
+    const long n_neg_l = npix - hdr->n_pos;
+    const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
+    const float w_pos = (float)(15.0 / n_pos), w_neg = (float)(1.0 / n_neg), w_hard = (float)(5.0 / (double)hdr->k);
+    const float w_cls = (float)(1.0 / n_pos);
+    const int n_cls = k_out - 1;
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
+    unsigned tie_base = blockties[blockIdx.x];          // ties before this iteration of this block
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double s_hard = 0, s_cls = 0;
+    for (long base = lo; base < hi; base += blockDim.x) {
+        const long p = base + threadIdx.x;
+        const bool active = p < hi;
+        unsigned bits = 0;
+        if (active) bits = __float_as_uint(ce_buf[p]);
+        const bool is_tie = active && (bits == T);
+        // rank of this tie among all ties in flat-index order
+        const unsigned long long bal = __ballot(is_tie);
+        const unsigned before_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) s_wave_ties[wid] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before_waves = 0, total_iter = 0;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) {
+            const unsigned c = s_wave_ties[w2];
+            if (w2 < wid) before_waves += c;
+            total_iter += c;
+        }
+        const unsigned tie_rank = tie_base + before_waves + before_in_wave;
+        tie_base += total_iter;
+        if (!active) continue;
+        const float x = logits[p * k_out];
+        const int yt = y_true[p];
+        const float z = yt > 0 ? 1.f : 0.f;
+        const bool sel = (bits > T) || (is_tie && tie_rank < need_eq);
+        if (sel) s_hard += (double)__uint_as_float(bits);
+        const float xc = fminf(fmaxf(x, LOGIT_LO), LOGIT_HI);
+        const bool inside = (x >= LOGIT_LO) && (x <= LOGIT_HI);
+        if (dlogits) {
+            const float sig = 1.f / (1.f + expf(-xc));
+            const float coef = z * w_pos + (1.f - z) * (w_neg + (sel ? w_hard : 0.f));
+            dlogits[p * k_out] = inside ? (sig - z) * coef : 0.f;
+        }
+        if (n_cls > 0) {
+            const float *lg = logits + p * k_out + 1;
+            if (yt > 0) {
+                float mx = lg[0];
+                for (int c = 1; c < n_cls; ++c) mx = fmaxf(mx, lg[c]);
+                float sum = 0.f;
+                for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
+                const float lse = mx + logf(sum);
+                const int lab = yt - 1 < n_cls ? yt - 1 : n_cls - 1;
+                s_cls += (double)(lse - lg[lab]);
+                if (dlogits)
+                    for (int c = 0; c < n_cls; ++c)
+                        dlogits[p * k_out + 1 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * w_cls;
+            } else if (dlogits) {
+                for (int c = 0; c < n_cls; ++c) dlogits[p * k_out + 1 + c] = 0.f;
+            }
+        }
+    }
+    double r = block_reduce_sum(s_hard, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_hard, r);
+    r = block_reduce_sum(s_cls, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_cls, r);
+}
+
+__global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, float *loss4)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
+    const long n_neg_l = npix - hdr->n_pos;
+    const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
+    double hard = hdr->sum_hard / (double)hdr->k;
+    if (hard != hard) hard = 0.0;                                  // losses.py:117-121
+    const double det = 15.0 * hdr->sum_pos / n_pos + 1.0 * hdr->sum_neg / n_neg + 5.0 * hard;
+    const double cls = n_cls > 0 ? hdr->sum_cls / n_pos : 0.0;
+    loss4[0] = (float)(1.0 * det + (n_cls > 0 ? 1.0 * cls : 0.0));
+    loss4[1] = (float)det;
+    loss4[2] = (float)cls;
+    loss4[3] = (float)hdr->k;
+}
+
+int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
+                  char *ws, hipStream_t st)
+{
+    loss_layout L;
+    loss_layout_compute(npix, &L);
+    loss_hdr *hdr = (loss_hdr *)(ws + L.off_hdr);
+    unsigned *hist = (unsigned *)(ws + L.off_hist);
+    unsigned *blockties = (unsigned *)(ws + L.off_blockties);
+    float *ce = (float *)(ws + L.off_ce);
+    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_blockties, st));     // header + 3 histograms
+    int grid = (int)((npix + LOSS_BLOCK - 1) / LOSS_BLOCK);
+    if (grid > LOSS_MAX_BLOCKS) grid = LOSS_MAX_BLOCKS;
+    long chunk = (npix + grid - 1) / grid;
+    chunk = (chunk + LOSS_BLOCK - 1) / LOSS_BLOCK * LOSS_BLOCK;
+    const int cgrid = (int)((npix + chunk - 1) / chunk);
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce);
+    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist, 0, npix);
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, 1);
+    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist + 2048, 1, npix);
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 4096, 2);
+    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist + 4096, 2, npix);
+    hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, blockties);
+    hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(64), 0, st, blockties, cgrid);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix, k_out - 1, loss);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ubd_loss(ubd_handle *h, const float *logits, const int32_t *y_true, int n, int map_h, int map_w,
+                        float *loss, float *dlogits, void *workspace, size_t workspace_bytes, void *stream)
+{
+    UBD_REQUIRE(h && logits && y_true && loss && workspace, "ubd_loss: null argument");
+    UBD_REQUIRE(n > 0 && map_h > 0 && map_w > 0, "ubd_loss: bad sizes");
+    const long npix = (long)n * map_h * map_w;
+    UBD_REQUIRE(npix < (1L << 31), "ubd_loss: too many pixels");
+    UBD_REQUIRE(workspace_bytes >= ubd_loss_workspace_bytes(h, n, map_h, map_w), "ubd_loss: workspace too small");
+    return ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, (char *)workspace, (hipStream_t)stream);
+}

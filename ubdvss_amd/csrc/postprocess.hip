@@ -1,69 +1,79 @@
 // Device postprocess of the ubdvss hot path on gfx950: logits -> binary map -> external
 // 8-connected components -> contourArea filter -> minAreaRect -> boxPoints -> rounded quads
-// (+ optional per-object class vote), all without leaving the GPU.
+// (+ optional per-object class vote), all without leaving the GPU and without any serial
+// border following.
 //
 // Reference call sites: semantic_segmentation/model_runner.py:121-134,
 // segmap_manager.py:41-69, utils.py:51-60, :135-138 (cv2.findContours RETR_EXTERNAL /
 // CHAIN_APPROX_SIMPLE, contourArea, minAreaRect, boxPoints, drawContours fill).
-// OpenCV 3.4 semantics are restated from its published algorithms (see oracle/cv_post.c
-// for the sequential restatement this file is tested against; parity vs cv2 itself is
-// unpinned because OpenCV is not available in the build environment).
+// OpenCV 3.4 semantics are restated from its published algorithms (oracle/cv_post.c holds the
+// sequential restatement this file is tested against; parity vs cv2 itself is unpinned because
+// OpenCV is not available in the build environment).
 //
-// Parallel formulation:
-//   1. threshold_init : fg = logit0 > thr; one union-find node per pixel (+ node 0 = the
-//                       image frame / outside).
-//   2. ccl_merge      : lock-free union-find (atomicMin, min-index roots): foreground
-//                       8-connected, background 4-connected, border background pixels are
-//                       merged with node 0.  ccl_flatten: label = root.
-//   3. find_roots     : a foreground root (raster-first pixel of its component) is an
-//                       *external* contour start iff the pixel north of it is outside the
-//                       image or belongs to the outside background (root 0).  This is
-//                       exactly cv2's RETR_EXTERNAL rule (components nested in holes are
-//                       dropped); verified against the sequential scan in tests.
-//   4. trace_boxes    : one lane per external component follows its outer border with the
-//                       Suzuki-Abe / icvFetchContour stepping rule, accumulating the
-//                       shoelace sum (contourArea) exactly in int64 and the per-row x
-//                       extents; kept components get their convex hull from the row extents
-//                       (monotone chains), ordered like cv::convexHull(clockwise=true), then
-//                       rotatingCalipers / minAreaRect / boxPoints in the same float32 /
-//                       float64 operation order as OpenCV, np.round (half-to-even) * scale.
-//   5. class_vote     : (n_classes > 0) per pixel, the enclosing external component is found
-//                       through the hole/nesting parent chain; softmax probabilities are
-//                       accumulated per object; argmax of the mean.
-//   6. emit           : objects ordered like cv2 returns them (last discovered first).
+// Fully parallel formulation (all equivalences are checked against the sequential restatement in
+// tests/test_oracle_post.py on thousands of random maps):
+//   * RETR_EXTERNAL: a component is returned iff the pixel north of its raster-first pixel is the
+//     image frame or OUTSIDE background (4-connected background region touching the frame).
+//   * filled contour (drawContours thickness=-1) = every pixel enclosed by the component = pixels
+//     whose nesting chain (region -> region north of its raster-first pixel -> ...) ends in it.
+//   * contourArea of the traced outer border = Q4 + Q3/2 over the 2x2 pixel quads of the FILLED
+//     region (Gray's bit-quad area): quads with 4 corners inside count 1, with 3 corners 1/2.
+//   * minAreaRect needs only the convex hull, which is the hull of the per-row x extents.
+// Pipeline (one launch each, grid over all pixels of the batch unless noted):
+//   init      fg = logit0 > thr (strict); union-find node per pixel (+ node 0 = frame/outside),
+//             initialised to the start of the pixel's horizontal run via wave ballots
+//   merge     lock-free union-find (atomicMin, min-index roots), only the non-redundant links:
+//             foreground 8-connected, background 4-connected, frame contact
+//   flatten   label = root
+//   roots     external roots get a slot; owner: per pixel, slot of the enclosing external component
+//   area      bit-quad area per slot (wave-aggregated atomics); keep: contourArea > min_area
+//   extents   per-row min/max x of every kept object; boxes (one lane per object): hull from the
+//             row extents ordered like cv::convexHull(clockwise=true), then rotatingCalipers /
+//             minAreaRect / boxPoints in OpenCV's float32/float64 operation order, np.round(x*scale)
+//   vote      (n_classes > 0) mean softmax over the filled region, argmax
+//   emit      objects ordered like cv2 returns them (last discovered first)
 #include "common.h"
 
 #pragma clang fp contract(off)
 
 #define CV_PI 3.1415926535897932384626433832795
+#define STAGE_INTS 10     // root, quad[8], spare
 
 struct pp_layout {
-    size_t off_label;    // int32 [n][hw+1]
-    size_t off_fg;       // uint8 [n][hw]
-    size_t off_nroots;   // int32 [n]
-    size_t off_nkept;    // int32 [n]
-    size_t off_roots;    // int32 [n][root_cap]
-    size_t off_stage;    // int32 [n][cap][STAGE_INTS]
-    size_t off_rows;     // int32 [n][cap][6*h]: row extents (2h) + hull points (2h points)
-    size_t off_vote;     // float [n][cap][n_cls+1]
+    size_t off_nroots, off_nkept;   // int32 [n] each (zeroed every call, start of the workspace)
+    size_t off_label;               // int32 [n][hw+1]
+    size_t off_fg;                  // uint8 [n][hw]
+    size_t off_owner;               // int32 [n][hw]    slot of the enclosing external component or -1
+    size_t off_rootslot;            // int32 [n][hw]    valid at external root pixels
+    size_t off_roots;               // int32 [n][root_cap]  root pixel of slot
+    size_t off_area2;               // int32 [n][root_cap]  2 * contourArea
+    size_t off_kept;                // int32 [n][root_cap]  kept index or -1
+    size_t off_stage;               // int32 [n][cap][STAGE_INTS]
+    size_t off_ymax;                // int32 [n][cap]
+    size_t off_rows;                // int32 [n][cap][6*h]: row extents (2h) + hull points (2h points)
+    size_t off_vote;                // float [n][cap][n_cls+1]
     size_t total;
     int root_cap;
 };
-#define STAGE_INTS 10     // root, quad[8], class
 
 static void pp_layout_compute(int n, int h, int w, int cap, int n_cls, pp_layout *L)
 {
     const size_t hw = (size_t)h * w;
     size_t off = 0;
     L->root_cap = (int)(hw / 4 + 2);
-    L->off_nroots = off; off += ubd_align_up(sizeof(int) * n, 256);
-    L->off_nkept = off;  off += ubd_align_up(sizeof(int) * n, 256);
-    L->off_label = off;  off += ubd_align_up(sizeof(int) * n * (hw + 1), 256);
-    L->off_fg = off;     off += ubd_align_up(n * hw, 256);
-    L->off_roots = off;  off += ubd_align_up(sizeof(int) * (size_t)n * L->root_cap, 256);
-    L->off_stage = off;  off += ubd_align_up(sizeof(int) * (size_t)n * cap * STAGE_INTS, 256);
-    L->off_rows = off;   off += ubd_align_up(sizeof(int) * (size_t)n * cap * 6 * h, 256);
-    L->off_vote = off;   off += ubd_align_up(sizeof(float) * (size_t)n * cap * (n_cls + 1), 256);
+    L->off_nroots = off;   off += ubd_align_up(sizeof(int) * n, 256);
+    L->off_nkept = off;    off += ubd_align_up(sizeof(int) * n, 256);
+    L->off_label = off;    off += ubd_align_up(sizeof(int) * n * (hw + 1), 256);
+    L->off_fg = off;       off += ubd_align_up(n * hw, 256);
+    L->off_owner = off;    off += ubd_align_up(sizeof(int) * n * hw, 256);
+    L->off_rootslot = off; off += ubd_align_up(sizeof(int) * n * hw, 256);
+    L->off_roots = off;    off += ubd_align_up(sizeof(int) * (size_t)n * L->root_cap, 256);
+    L->off_area2 = off;    off += ubd_align_up(sizeof(int) * (size_t)n * L->root_cap, 256);
+    L->off_kept = off;     off += ubd_align_up(sizeof(int) * (size_t)n * L->root_cap, 256);
+    L->off_stage = off;    off += ubd_align_up(sizeof(int) * (size_t)n * cap * STAGE_INTS, 256);
+    L->off_ymax = off;     off += ubd_align_up(sizeof(int) * (size_t)n * cap, 256);
+    L->off_rows = off;     off += ubd_align_up(sizeof(int) * (size_t)n * cap * 6 * h, 256);
+    L->off_vote = off;     off += ubd_align_up(sizeof(float) * (size_t)n * cap * (n_cls + 1), 256);
     L->total = off;
 }
 
@@ -74,23 +84,41 @@ extern "C" size_t ubd_postprocess_workspace_bytes(const ubd_handle *h, int n, in
     return L.total;
 }
 
-// ------------------------------------------------------------------------------------ 1
-__global__ void threshold_init_kernel(const float *__restrict__ logits, int k_out, float thr, long npix, int hw,
-                                      unsigned char *__restrict__ fg, int *__restrict__ label,
-                                      int *__restrict__ binary_map)
+// ------------------------------------------------------------------------------------ init
+// blockDim must be a multiple of 64; lanes of a wave hold 64 consecutive flat pixels.
+__global__ __launch_bounds__(256) void pp_init_kernel(const float *__restrict__ logits, int k_out, float thr, long npix,
+                                                      int hw, int w, unsigned char *__restrict__ fg,
+                                                      int *__restrict__ label, int *__restrict__ binary_map)
 {
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
-        const int img = (int)(p / hw), loc = (int)(p % hw);
-        const int f = logits[p * k_out] > thr ? 1 : 0;    // strict >, model_runner.py:124
-        fg[p] = (unsigned char)f;
-        if (binary_map) binary_map[p] = f;
-        int *lab = label + (size_t)img * (hw + 1);
-        lab[loc + 1] = loc + 1;
-        if (loc == 0) lab[0] = 0;
+    const int lane = threadIdx.x & 63;
+    const long nround = (npix + 63) / 64 * 64;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < nround; p += (long)gridDim.x * blockDim.x) {
+        const bool valid = p < npix;
+        int f = 0, img = 0, loc = 0, x = 0;
+        if (valid) {
+            img = (int)(p / hw); loc = (int)(p % hw); x = loc % w;
+            f = logits[p * k_out] > thr ? 1 : 0;                 // strict >, model_runner.py:124
+            fg[p] = (unsigned char)f;
+            if (binary_map) binary_map[p] = f;
+        }
+        // same class as the pixel to the left (same row)?
+        int fl = __shfl_up(f, 1, 64);
+        if (lane == 0 && valid && x > 0) fl = logits[(p - 1) * k_out] > thr ? 1 : 0;
+        const bool same_left = valid && x > 0 && fl == f;
+        const unsigned long long breaks = __ballot(!same_left);  // bit l: lane l starts a run (or is invalid)
+        if (valid) {
+            const unsigned long long below = breaks & ((2ull << lane) - 1ull);   // lanes <= mine
+            int start_off;                                        // distance back to the run start
+            if (below) start_off = lane - (63 - __clzll(below));
+            else start_off = lane + 1;                            // run continues into the previous wave: link there
+            int *lab = label + (size_t)img * (hw + 1);
+            lab[loc + 1] = loc + 1 - start_off;
+            if (loc == 0) lab[0] = 0;
+        }
     }
 }
 
-// ------------------------------------------------------------------------------------ 2
+// ------------------------------------------------------------------------------------ union-find
 __device__ __forceinline__ int uf_find(int *lab, int a)
 {
     int p = __hip_atomic_load(&lab[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,7 +142,9 @@ __device__ __forceinline__ void uf_union(int *lab, int a, int b)
     }
 }
 
-__global__ void ccl_merge_kernel(const unsigned char *__restrict__ fg, int *__restrict__ label, long npix, int h, int w)
+// Only links that are not implied by the run initialisation or by a neighbour's links.
+__global__ __launch_bounds__(256) void pp_merge_kernel(const unsigned char *__restrict__ fg, int *__restrict__ label,
+                                                       long npix, int h, int w)
 {
     const int hw = h * w;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
@@ -123,22 +153,34 @@ __global__ void ccl_merge_kernel(const unsigned char *__restrict__ fg, int *__re
         const unsigned char *m = fg + (size_t)img * hw;
         int *lab = label + (size_t)img * (hw + 1);
         const int me = loc + 1;
-        if (m[loc]) {
-            if (x > 0 && m[loc - 1]) uf_union(lab, me, me - 1);
+        const int c = m[loc];
+        const bool W = x > 0 && m[loc - 1] == c;
+        if (c) {
             if (y > 0) {
-                if (m[loc - w]) uf_union(lab, me, me - w);
-                if (x > 0 && m[loc - w - 1]) uf_union(lab, me, me - w - 1);
-                if (x < w - 1 && m[loc - w + 1]) uf_union(lab, me, me - w + 1);
+                const bool N = m[loc - w];
+                const bool NW = x > 0 && m[loc - w - 1];
+                if (N) {
+                    if (!(W && NW)) uf_union(lab, me, me - w);
+                } else {
+                    if (NW && !W) uf_union(lab, me, me - w - 1);
+                    const bool NE = x < w - 1 && m[loc - w + 1];
+                    const bool E = x < w - 1 && m[loc + 1];
+                    if (NE && !E) uf_union(lab, me, me - w + 1);
+                }
             }
         } else {
-            if (x == 0 || y == 0 || x == w - 1 || y == h - 1) uf_union(lab, me, 0);
-            if (x > 0 && !m[loc - 1]) uf_union(lab, me, me - 1);
-            if (y > 0 && !m[loc - w]) uf_union(lab, me, me - w);
+            if (y > 0 && !m[loc - w]) {
+                const bool NW = x > 0 && !m[loc - w - 1];
+                if (!(W && NW)) uf_union(lab, me, me - w);
+            }
+            // frame contact: one link per run on the first / last row, the row ends elsewhere
+            const bool row_edge = (y == 0 || y == h - 1) && !W;
+            if (row_edge || x == 0 || x == w - 1) uf_union(lab, me, 0);
         }
     }
 }
 
-__global__ void ccl_flatten_img_kernel(int *__restrict__ label, int n, int hw)
+__global__ __launch_bounds__(256) void pp_flatten_kernel(int *__restrict__ label, int n, int hw)
 {
     const long total = (long)n * (hw + 1);
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
@@ -149,74 +191,145 @@ __global__ void ccl_flatten_img_kernel(int *__restrict__ label, int n, int hw)
     }
 }
 
-// ------------------------------------------------------------------------------------ 3
-__global__ void find_roots_kernel(const unsigned char *__restrict__ fg, const int *__restrict__ label, long npix,
-                                  int h, int w, int *__restrict__ nroots, int *__restrict__ roots, int root_cap)
+// ------------------------------------------------------------------------------------ roots / owner
+__global__ __launch_bounds__(256) void pp_roots_kernel(const unsigned char *__restrict__ fg, const int *__restrict__ label,
+                                                       long npix, int h, int w, int *__restrict__ nroots,
+                                                       int *__restrict__ roots, int *__restrict__ rootslot,
+                                                       int *__restrict__ area2, int root_cap)
 {
     const int hw = h * w;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         const int img = (int)(p / hw), loc = (int)(p % hw);
         if (!fg[p]) continue;
         const int *lab = label + (size_t)img * (hw + 1);
-        if (lab[loc + 1] != loc + 1) continue;             // not the raster-first pixel
-        const int y = loc / w;
-        const bool external = (y == 0) || (lab[loc + 1 - w] == 0);
+        if (lab[loc + 1] != loc + 1) continue;             // not the raster-first pixel of its component
+        const bool external = (loc < w) || (lab[loc + 1 - w] == 0);
         if (!external) continue;
-        const int idx = atomicAdd(&nroots[img], 1);
-        if (idx < root_cap) roots[(size_t)img * root_cap + idx] = loc;
+        const int idx = atomicAdd(&nroots[img], 1);        // idx < root_cap always: at most hw/4 components
+        roots[(size_t)img * root_cap + idx] = loc;
+        area2[(size_t)img * root_cap + idx] = 0;
+        rootslot[p] = idx;
     }
 }
 
-// ------------------------------------------------------------------------------------ 4
-__constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-__constant__ int c_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-
-struct trace_result {
-    long long a2;            // signed shoelace sum (2 * area)
-    int xmin, xmax, ymin, ymax;
-};
-
-// Follows the outer border starting at the raster-first pixel (x0,y0) with the stepping rule of
-// OpenCV's icvFetchContour (outer border: first search clockwise from W, then counter-clockwise
-// sweeps from the direction of the previous pixel).  rows != nullptr: also records per-row
-// x extents into rows[2*(y-ymin0)] (min) / rows[2*(y-ymin0)+1] (max).
-template <typename MapT>
-__device__ void trace_border(const MapT &map, int h, int w, int x0, int y0, trace_result &res, int *rows)
+// owner[p] = slot of the external component that encloses pixel p, or -1.
+__global__ __launch_bounds__(256) void pp_owner_kernel(const unsigned char *__restrict__ fg, const int *__restrict__ label,
+                                                       const int *__restrict__ rootslot, long npix, int h, int w,
+                                                       int *__restrict__ owner)
 {
-    auto pix = [&](int x, int y) -> int { return (x >= 0 && x < w && y >= 0 && y < h) ? (int)map[y * w + x] : 0; };
-    res.a2 = 0;
-    res.xmin = res.xmax = x0;
-    res.ymin = res.ymax = y0;
-    if (rows) { rows[0] = x0; rows[1] = x0; }
-    int s = 4, s_end = 4;
-    int nbx = 0, nby = 0;
-    do {
-        s = (s - 1) & 7;
-        nbx = x0 + c_dx[s]; nby = y0 + c_dy[s];
-    } while (pix(nbx, nby) == 0 && s != s_end);
-    if (s == s_end) return;                               // single pixel
-    const int i1x = nbx, i1y = nby;
-    int cx = x0, cy = y0;
-    const long max_steps = 8L * h * w + 16;
-    for (long step = 0; step < max_steps; ++step) {
-        int nx = cx, ny = cy;
-        s_end = s;
-        while (s < 15) {
-            ++s;
-            nx = cx + c_dx[s & 7]; ny = cy + c_dy[s & 7];
-            if (pix(nx, ny) != 0) break;
+    const int hw = h * w;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int img = (int)(p / hw), loc = (int)(p % hw);
+        const unsigned char *m = fg + (size_t)img * hw;
+        const int *lab = label + (size_t)img * (hw + 1);
+        int node = lab[loc + 1];
+        int own = -1;
+        for (int guard = 0; guard < 4096; ++guard) {
+            if (node == 0) break;                           // outside background
+            const int r = node - 1;                         // raster-first pixel of this region
+            if (r < w) { if (m[r]) own = rootslot[(size_t)img * hw + r]; break; }
+            const int up = lab[r - w + 1];                  // region north of it
+            if (m[r] && up == 0) { own = rootslot[(size_t)img * hw + r]; break; }
+            node = up;
         }
-        s &= 7;
-        res.a2 += (long long)cx * ny - (long long)cy * nx;
-        if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) break;
-        cx = nx; cy = ny;
-        res.xmin = min(res.xmin, cx); res.xmax = max(res.xmax, cx);
-        res.ymax = max(res.ymax, cy);
-        if (rows) {
-            int *r = rows + 2 * (cy - y0);
-            r[0] = min(r[0], cx); r[1] = max(r[1], cx);
+        owner[p] = own;
+    }
+}
+
+// ------------------------------------------------------------------------------------ area
+// Adds `val` to acc[key] for all lanes with key >= 0, one atomic per distinct key in the wave.
+__device__ __forceinline__ void wave_atomic_add_by_key(int *acc, int key, int val)
+{
+    unsigned long long todo = __ballot(key >= 0 && val != 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const bool mine = (key == k) && (val != 0);
+        int v = mine ? val : 0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&acc[k], v);
+        todo &= ~__ballot(mine);
+    }
+}
+
+__global__ __launch_bounds__(256) void pp_area_kernel(const int *__restrict__ owner, long npix, int h, int w,
+                                                      int *__restrict__ area2, int root_cap)
+{
+    const int hw = h * w;
+    const long nround = (npix + 63) / 64 * 64;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < nround; p += (long)gridDim.x * blockDim.x) {
+        int key = -1, val = 0;
+        if (p < npix) {
+            const int img = (int)(p / hw), loc = (int)(p % hw);
+            const int y = loc / w, x = loc % w;
+            if (x < w - 1 && y < h - 1) {
+                const int o0 = owner[p], o1 = owner[p + 1], o2 = owner[p + w], o3 = owner[p + w + 1];
+                const int o = max(max(o0, o1), max(o2, o3));          // all non-negative owners in a quad agree
+                if (o >= 0) {
+                    const int cnt = (o0 == o) + (o1 == o) + (o2 == o) + (o3 == o);
+                    val = cnt == 4 ? 2 : (cnt == 3 ? 1 : 0);
+                    key = img * root_cap + o;
+                }
+            }
         }
-        s = (s + 4) & 7;
+        wave_atomic_add_by_key(area2, key, val);
+    }
+}
+
+__global__ __launch_bounds__(256) void pp_keep_kernel(int n, int h, const int *__restrict__ nroots, const int *__restrict__ roots,
+                                                      const int *__restrict__ area2, int root_cap, float min_area,
+                                                      int *__restrict__ nkept, int *__restrict__ kept,
+                                                      int *__restrict__ stage, int *__restrict__ ymax,
+                                                      int *__restrict__ rows, int cap, float *__restrict__ vote, int n_cls)
+{
+    for (int img = blockIdx.x; img < n; img += gridDim.x) {
+        const int nr = nroots[img];
+        for (int s = threadIdx.x; s < nr; s += blockDim.x) {
+            const size_t gi = (size_t)img * root_cap + s;
+            const double area = (double)area2[gi] * 0.5;
+            int k = -1;
+            if (area > (double)min_area) {                            // utils.py:55 (strict >)
+                k = atomicAdd(&nkept[img], 1);
+                if (k < cap) {
+                    int *st = stage + ((size_t)img * cap + k) * STAGE_INTS;
+                    st[0] = roots[gi];
+                    ymax[(size_t)img * cap + k] = 0;
+                    int *r = rows + ((size_t)img * cap + k) * (size_t)(6 * h);
+                    for (int y = 0; y < h; ++y) { r[2 * y] = 0x7fffffff; r[2 * y + 1] = -1; }
+                    if (n_cls > 0) {
+                        float *v = vote + ((size_t)img * cap + k) * (n_cls + 1);
+                        for (int c = 0; c <= n_cls; ++c) v[c] = 0.f;
+                    }
+                } else {
+                    k = -1;                                           // overflow: reported through counts[] > cap
+                }
+            }
+            kept[gi] = k;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ extents
+__global__ __launch_bounds__(256) void pp_extents_kernel(const int *__restrict__ owner, const int *__restrict__ kept, long npix,
+                                                         int h, int w, int root_cap, int cap, int *__restrict__ rows,
+                                                         int *__restrict__ ymax)
+{
+    const int hw = h * w;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int o = owner[p];
+        if (o < 0) continue;
+        const int img = (int)(p / hw), loc = (int)(p % hw);
+        const int y = loc / w, x = loc % w;
+        const bool left_end = (x == 0) || owner[p - 1] != o;
+        const bool right_end = (x == w - 1) || owner[p + 1] != o;
+        const bool bottom = (y == h - 1) || owner[p + w] != o;
+        if (!(left_end || right_end || bottom)) continue;
+        const int k = kept[(size_t)img * root_cap + o];
+        if (k < 0) continue;
+        int *r = rows + ((size_t)img * cap + k) * (size_t)(6 * h);
+        if (left_end) atomicMin(&r[2 * y], x);
+        if (right_end) atomicMax(&r[2 * y + 1], x);
+        if (bottom) atomicMax(&ymax[(size_t)img * cap + k], y);
     }
 }
 
@@ -412,99 +525,56 @@ __device__ int hull_from_rows(int *rows, int nrows, int y0, ipt *scratch_pts)
     return n;
 }
 
-__global__ __launch_bounds__(256) void trace_boxes_kernel(const unsigned char *__restrict__ fg, int n, int h, int w,
-                                                          const int *__restrict__ nroots, const int *__restrict__ roots,
-                                                          int root_cap, int *__restrict__ nkept, int *__restrict__ stage,
-                                                          int *__restrict__ rows_ws, int cap, int scale, float min_area)
+
+// one lane per kept object: hull from row extents -> minAreaRect -> boxPoints -> rounded quad
+__global__ __launch_bounds__(64) void pp_boxes_kernel(int n, int h, int w, const int *__restrict__ nkept, int *__restrict__ stage,
+                                                      const int *__restrict__ ymax, int *__restrict__ rows_ws, int cap, int scale)
 {
-    // one block per image (grid-stride over images); lanes take external roots
-    for (int img = blockIdx.x; img < n; img += gridDim.x) {
-        const unsigned char *m = fg + (size_t)img * h * w;
-        const int nr = min(nroots[img], root_cap);
-        for (int ri = threadIdx.x; ri < nr; ri += blockDim.x) {
-            const int loc = roots[(size_t)img * root_cap + ri];
-            const int y0 = loc / w, x0 = loc % w;
-            trace_result tr;
-            trace_border(m, h, w, x0, y0, tr, nullptr);
-            const long long a2 = tr.a2 < 0 ? -tr.a2 : tr.a2;
-            const double area = (double)a2 * 0.5;
-            if (!(area > (double)min_area)) continue;               // utils.py:55 (strict >)
-            const int slot = atomicAdd(&nkept[img], 1);
-            if (slot >= cap) continue;                              // reported through counts[] > cap
-            const int nrows = tr.ymax - y0 + 1;
-            // rows scratch of this slot: 2*h ints for extents + the hull is built in a second area
-            int *rows = rows_ws + ((size_t)img * cap + slot) * (size_t)(6 * h);
-            for (int r = 0; r < nrows; ++r) { rows[2 * r] = 0x7fffffff; rows[2 * r + 1] = -0x7fffffff; }
-            trace_result tr2;
-            trace_border(m, h, w, x0, y0, tr2, rows);
-            ipt *pts = (ipt *)(rows + 2 * h);                       // 4h ints = room for 2h points
-            const int nh = hull_from_rows(rows, nrows, y0, pts);
-            float box[8];
-            min_area_box(pts, nh, box);
-            int *st = stage + ((size_t)img * cap + slot) * STAGE_INTS;
-            st[0] = loc;
+    const long total = (long)n * cap;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int img = (int)(t / cap), k = (int)(t % cap);
+        if (k >= min(nkept[img], cap)) continue;
+        int *st = stage + ((size_t)img * cap + k) * STAGE_INTS;
+        const int y0 = st[0] / w;
+        const int nrows = ymax[(size_t)img * cap + k] - y0 + 1;
+        int *rows = rows_ws + ((size_t)img * cap + k) * (size_t)(6 * h);
+        ipt *pts = (ipt *)(rows + 2 * h);                             // 4h ints = room for 2h points
+        const int nh = hull_from_rows(rows + 2 * y0, nrows, y0, pts);
+        float box[8];
+        min_area_box(pts, nh, box);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
-            st[9] = 0;
-        }
+        for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
+        st[9] = 0;
     }
 }
 
-// ------------------------------------------------------------------------------------ 5
-// Class vote (segmap_manager.py:59-67): mean over the filled contour of softmax(class logits),
-// argmax.  The filled contour of an external component = every pixel it encloses; the owner of a
-// pixel is found by walking the nesting chain: fg component -> background region north of its
-// raster-first pixel -> fg component north of that region's raster-first pixel -> ... until a
-// component whose enclosing background is the outside (root 0).
-__device__ int owner_root(const unsigned char *m, const int *lab, int w, int loc)
+// ------------------------------------------------------------------------------------ vote
+// Class vote (segmap_manager.py:59-67): mean over the filled contour of softmax(class logits).
+__global__ __launch_bounds__(256) void pp_vote_kernel(const float *__restrict__ logits, int k_out, const int *__restrict__ owner,
+                                                      const int *__restrict__ kept, long npix, int hw, int root_cap, int cap,
+                                                      float *__restrict__ vote)
 {
-    int node = lab[loc + 1];
-    for (int guard = 0; guard < 64; ++guard) {
-        if (node == 0) return -1;                 // outside background: no owner
-        const int p = node - 1;                   // raster-first pixel of this region
-        if (p < w) {                              // first row: nothing above
-            return m[p] ? p : -1;
-        }
-        const int up = lab[p - w + 1];            // region north of the raster-first pixel
-        if (m[p] && up == 0) return p;            // external foreground component
-        node = up;
-    }
-    return -1;
-}
-
-__global__ void class_vote_kernel(const float *__restrict__ logits, int k_out, const unsigned char *__restrict__ fg,
-                                  const int *__restrict__ label, long npix, int h, int w,
-                                  const int *__restrict__ nkept, const int *__restrict__ stage, int cap,
-                                  float *__restrict__ vote)
-{
-    const int hw = h * w;
     const int n_cls = k_out - 1;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
-        const int img = (int)(p / hw), loc = (int)(p % hw);
-        const int nk = min(nkept[img], cap);
-        if (nk == 0) continue;
-        const int own = owner_root(fg + (size_t)img * hw, label + (size_t)img * (hw + 1), w, loc);
-        if (own < 0) continue;
-        // find the slot of this owner (few kept objects per image)
-        int slot = -1;
-        const int *st = stage + (size_t)img * cap * STAGE_INTS;
-        for (int s = 0; s < nk; ++s)
-            if (st[s * STAGE_INTS] == own) { slot = s; break; }
-        if (slot < 0) continue;                   // owner was filtered out by the area test
+        const int o = owner[p];
+        if (o < 0) continue;
+        const int img = (int)(p / hw);
+        const int k = kept[(size_t)img * root_cap + o];
+        if (k < 0) continue;
         const float *lg = logits + p * k_out + 1;
         float mx = lg[0];
         for (int c = 1; c < n_cls; ++c) mx = fmaxf(mx, lg[c]);
         float sum = 0.f;
         for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
-        float *v = vote + ((size_t)img * cap + slot) * (n_cls + 1);
+        float *v = vote + ((size_t)img * cap + k) * (n_cls + 1);
         for (int c = 0; c < n_cls; ++c) atomicAdd(&v[c], expf(lg[c] - mx) / sum);
     }
 }
 
-// ------------------------------------------------------------------------------------ 6
-__global__ void emit_kernel(int n, const int *__restrict__ nkept, const int *__restrict__ stage,
-                            const float *__restrict__ vote, int n_cls, int cap, int *__restrict__ quads,
-                            int *__restrict__ classes, int *__restrict__ counts)
+// ------------------------------------------------------------------------------------ emit
+__global__ __launch_bounds__(256) void pp_emit_kernel(int n, const int *__restrict__ nkept, const int *__restrict__ stage,
+                                                      const float *__restrict__ vote, int n_cls, int cap, int *__restrict__ quads,
+                                                      int *__restrict__ classes, int *__restrict__ counts)
 {
     for (int img = blockIdx.x; img < n; img += gridDim.x) {
         const int total = nkept[img];
@@ -540,35 +610,44 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
 {
     UBD_REQUIRE(hd && logits && quads && counts && workspace, "ubd_postprocess: null argument");
     UBD_REQUIRE(n > 0 && map_h > 0 && map_w > 0 && cap > 0, "ubd_postprocess: bad sizes n=%d h=%d w=%d cap=%d", n, map_h, map_w, cap);
-    UBD_REQUIRE((long)map_h * map_w < (1L << 30), "ubd_postprocess: map too large");
+    UBD_REQUIRE((long)map_h * map_w < (1L << 30) && (long)n * map_h * map_w < (1L << 31), "ubd_postprocess: map too large");
     const int n_cls = hd->cfg.n_classes;
     UBD_REQUIRE(n_cls == 0 || classes, "ubd_postprocess: classes buffer required when n_classes > 0");
     pp_layout L;
     pp_layout_compute(n, map_h, map_w, cap, n_cls, &L);
-    UBD_REQUIRE(workspace_bytes >= ubd_postprocess_workspace_bytes(hd, n, map_h, map_w, cap), "ubd_postprocess: workspace too small");
+    UBD_REQUIRE(workspace_bytes >= L.total, "ubd_postprocess: workspace too small (%zu < %zu)", workspace_bytes, L.total);
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
+    int *nroots = (int *)(ws + L.off_nroots), *nkept = (int *)(ws + L.off_nkept);
     int *label = (int *)(ws + L.off_label);
     unsigned char *fg = (unsigned char *)(ws + L.off_fg);
-    int *nroots = (int *)(ws + L.off_nroots), *nkept = (int *)(ws + L.off_nkept);
-    int *roots = (int *)(ws + L.off_roots), *stage = (int *)(ws + L.off_stage), *rows = (int *)(ws + L.off_rows);
+    int *owner = (int *)(ws + L.off_owner), *rootslot = (int *)(ws + L.off_rootslot);
+    int *roots = (int *)(ws + L.off_roots), *area2 = (int *)(ws + L.off_area2), *kept = (int *)(ws + L.off_kept);
+    int *stage = (int *)(ws + L.off_stage), *ymax = (int *)(ws + L.off_ymax), *rows = (int *)(ws + L.off_rows);
     float *vote = (float *)(ws + L.off_vote);
     const int hw = map_h * map_w;
     const long npix = (long)n * hw;
-    // counters are contiguous at the start of the workspace: one memset node
-    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));
-    if (n_cls > 0) UBD_CHECK_HIP(hipMemsetAsync(vote, 0, sizeof(float) * (size_t)n * cap * (n_cls + 1), st));
+    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));          // the two per-image counters
     int grid = (int)((npix + 255) / 256);
     const int gmax = hd->num_cus * 8;
     if (grid > gmax) grid = gmax;
-    hipLaunchKernelGGL(threshold_init_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, logit_threshold, npix, hw, fg, label, binary_map);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid), dim3(256), 0, st, fg, label, npix, map_h, map_w);
-    hipLaunchKernelGGL(ccl_flatten_img_kernel, dim3(grid), dim3(256), 0, st, label, n, hw);
-    hipLaunchKernelGGL(find_roots_kernel, dim3(grid), dim3(256), 0, st, fg, label, npix, map_h, map_w, nroots, roots, L.root_cap);
-    hipLaunchKernelGGL(trace_boxes_kernel, dim3(n), dim3(256), 0, st, fg, n, map_h, map_w, nroots, roots, L.root_cap, nkept, stage, rows, cap, scale, min_area);
+    hipLaunchKernelGGL(pp_init_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, logit_threshold, npix, hw, map_w, fg, label, binary_map);
+    hipLaunchKernelGGL(pp_merge_kernel, dim3(grid), dim3(256), 0, st, fg, label, npix, map_h, map_w);
+    hipLaunchKernelGGL(pp_flatten_kernel, dim3(grid), dim3(256), 0, st, label, n, hw);
+    hipLaunchKernelGGL(pp_roots_kernel, dim3(grid), dim3(256), 0, st, fg, label, npix, map_h, map_w, nroots, roots, rootslot, area2, L.root_cap);
+    hipLaunchKernelGGL(pp_owner_kernel, dim3(grid), dim3(256), 0, st, fg, label, rootslot, npix, map_h, map_w, owner);
+    hipLaunchKernelGGL(pp_area_kernel, dim3(grid), dim3(256), 0, st, owner, npix, map_h, map_w, area2, L.root_cap);
+    hipLaunchKernelGGL(pp_keep_kernel, dim3(n), dim3(256), 0, st, n, map_h, nroots, roots, area2, L.root_cap, min_area, nkept, kept, stage, ymax, rows, cap, vote, n_cls);
+    hipLaunchKernelGGL(pp_extents_kernel, dim3(grid), dim3(256), 0, st, owner, kept, npix, map_h, map_w, L.root_cap, cap, rows, ymax);
+    {
+        const long total = (long)n * cap;
+        int bgrid = (int)((total + 63) / 64);
+        if (bgrid > gmax) bgrid = gmax;
+        hipLaunchKernelGGL(pp_boxes_kernel, dim3(bgrid), dim3(64), 0, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+    }
     if (n_cls > 0)
-        hipLaunchKernelGGL(class_vote_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, fg, label, npix, map_h, map_w, nkept, stage, cap, vote);
-    hipLaunchKernelGGL(emit_kernel, dim3(n), dim3(256), 0, st, n, nkept, stage, vote, n_cls, cap, quads, classes, counts);
+        hipLaunchKernelGGL(pp_vote_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, owner, kept, npix, hw, L.root_cap, cap, vote);
+    hipLaunchKernelGGL(pp_emit_kernel, dim3(n), dim3(256), 0, st, n, nkept, stage, vote, n_cls, cap, quads, classes, counts);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -31,12 +31,6 @@ extern "C" int ubd_adam_step(float *params, const float *grads, float *m, float 
 
 extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *, int, int, int) { return 0; }
 
-extern "C" int ubd_loss(ubd_handle *, const float *, const int32_t *, int, int, int, float *, float *, void *, size_t, void *)
-{
-    ubd_set_error("ubd_loss: not implemented in this build");
-    return 3;
-}
-
 extern "C" int ubd_train_step(ubd_handle *, const float *, const void *, int, int, const int32_t *, int, int, int,
                               float *, float *, void *, size_t, void *)
 {

@@ -54,7 +54,7 @@ def loss_and_grad(y_true, y_pred, want_grad=True):
     hd = _handle(k - 1, device)
     loss = torch.zeros(4, dtype=torch.float32, device=device)
     grad = torch.empty_like(yp) if want_grad else None
-    ws = torch.empty(int(lib.ubd_train_workspace_bytes(hd, 1, 4, 4)) + 64 * n * h * w + (1 << 20), dtype=torch.uint8, device=device)
+    ws = torch.empty(int(lib.ubd_loss_workspace_bytes(hd, n, h, w)), dtype=torch.uint8, device=device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _lib.check(lib.ubd_loss(hd, yp.data_ptr(), yt.data_ptr(), n, h, w, loss.data_ptr(),
                             grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(), stream), "ubd_loss")
