@@ -134,7 +134,7 @@ def loss_and_grads(x, y_true, weights, classification_mode, fml_compatible=True,
     logits.retain_grad()
     loss = total_loss(yt, logits, classification_mode)
     loss.backward()
-    return (float(loss), logits.detach().numpy(), logits.grad.numpy().copy(), from_torch_grads(tw))
+    return (float(loss.detach()), logits.detach().numpy(), logits.grad.numpy().copy(), from_torch_grads(tw))
 
 
 def adam_step(params, grads, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):

@@ -22,7 +22,7 @@ def test_matches_torch_autograd():
         loss = otorch.total_loss(torch.tensor(yt, dtype=torch.float64), t, n_cls > 0)
         loss.backward()
         l2, g2 = oloss.total_loss(yt, yp, n_cls > 0)
-        assert abs(float(loss) - l2) < 1e-10
+        assert abs(float(loss.detach()) - l2) < 1e-10
         assert np.abs(t.grad.numpy() - g2).max() < 1e-12
 
 

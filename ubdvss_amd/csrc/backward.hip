@@ -1,0 +1,581 @@
+// Backward pass + train-step orchestration of the ubdvss hot path on gfx950 (fp32 path).
+//
+// The reference gets its gradients from TensorFlow autodiff of the Keras graph
+// (model.compile / fit_generator, train.py:110-112, :176-188); here every gradient kernel is
+// written out.  Notation: layer output Y = relu(Z); G = dL/dZ ("masked" gradient); the kernels pass
+// G tensors from layer to layer:
+//   head_dx      G9 = (dlogits . hk^T) * (A9 > 0)
+//   head_wgrad   dhk = A9^T dlogits, dhb = sum dlogits                       (MFMA, K-dim = pixels)
+//   dil_wgrad    dW[t][ci][co] = sum_p X[p+off_t][ci] G[p][co], db = sum_p G (MFMA, K-dim = pixels,
+//                M = 216 (+1 row of ones for the bias), N = 24)
+//   dilconv<1>   G_below = conv(G, flipped/transposed W, same dilation) * (X > 0)   (forward kernel)
+//   sep_bwd      separable layer: recomputes the depthwise output, dpw/db (MFMA), dDW = G pw^T (MFMA,
+//                lands directly in the depthwise lane layout), ddw (VALU), writes dDW
+//   sep_dx       G_below = depthwise-transpose(dDW) * (X > 0)
+// Weight gradients are accumulated with fp32 atomics into the zeroed flat gradient vector
+// (Keras get_weights() order, same as the parameters).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define UBD_BWD_DGRAD_FLOATS (UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
+#define UBD_BWD_SEP_FLOATS (6 * 2 * 64)
+#define UBD_BWD_FRAG_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
+
+// ------------------------------------------------------------------------------------
+// Backward weight fragments:
+//   dgrad[L][t'][j][nt][lane] = W_L[8-t'][co' ][ci']   with ci' = input channel of the dgrad conv
+//        (= forward output channel) from (j, q) as in the forward packing, co' = (lane&15)+16nt
+//   seppwT[s][step][tile][lane]: A operand of the dDW product, A[rho = lane&15][k = q]
+//        = pw[ch(rho, tile)][co = 6q + step];   CIN==24: ch = 6*(rho>>2) + (rho&3) + 4*tile (tile 1: rho&3 < 2)
+//                                               CIN< 24: tile 0 only, ch = rho>>2 if (rho&3)==0 and ch < CIN
+// ------------------------------------------------------------------------------------
+struct pack_bwd_args {
+    size_t off_sep_pw[3];
+    size_t off_dil_k[UBD_NUM_DIL];
+    int c_in;
+};
+
+__global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restrict__ out, pack_bwd_args a)
+{
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < UBD_BWD_FRAG_FLOATS; idx += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (idx < UBD_BWD_DGRAD_FLOATS) {
+            int L = idx / UBD_DIL_FRAG_FLOATS, r = idx % UBD_DIL_FRAG_FLOATS;
+            int lane = r & 63, nt = (r >> 6) & 1, tj = r >> 7, j = tj % 6, t = tj / 6;
+            int q = lane >> 4, cop = (lane & 15) + 16 * nt;
+            int cip = j < 4 ? 4 * q + j : 16 + 2 * q + (j - 4);
+            if (cop < UBD_C) v = params[a.off_dil_k[L] + ((size_t)(8 - t) * UBD_C + cop) * UBD_C + cip];
+        } else {
+            int r = idx - UBD_BWD_DGRAD_FLOATS;
+            int s = r / UBD_BWD_SEP_FLOATS;
+            r %= UBD_BWD_SEP_FLOATS;
+            int cin = s == 0 ? a.c_in : UBD_C;
+            int lane = r & 63, tile = (r >> 6) & 1, step = r >> 7;
+            int rho = lane & 15, q = lane >> 4;
+            int ch = -1;
+            if (cin == UBD_C) {
+                int sub = (rho & 3) + 4 * tile;
+                if (sub < 6) ch = 6 * (rho >> 2) + sub;
+            } else if (tile == 0 && (rho & 3) == 0 && (rho >> 2) < cin) {
+                ch = rho >> 2;
+            }
+            if (ch >= 0) v = params[a.off_sep_pw[s] + (size_t)ch * UBD_C + 6 * q + step];
+        }
+        out[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ head
+__global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dlogits, const float *__restrict__ a9,
+                                                      const float *__restrict__ hk, float *__restrict__ g, long npix, int k_out)
+{
+    __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
+    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        float dl[UBD_MAX_CLASSES + 1];
+        for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
+        const f32x4 *pa = (const f32x4 *)(a9 + p * UBD_C);
+        f32x4 *pg = (f32x4 *)(g + p * UBD_C);
+#pragma unroll
+        for (int c4 = 0; c4 < 6; ++c4) {
+            const f32x4 av = pa[c4];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+                for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[(c4 * 4 + e) * k_out + k], acc);
+                o[e] = av[e] > 0.f ? acc : 0.f;
+            }
+            pg[c4] = o;
+        }
+    }
+}
+
+// dhk[c][k] = sum_p a9[p][c] dl[p][k]; dhb[k] = sum_p dl[p][k]  (row 24 of the A operand is all ones)
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict__ a9, const float *__restrict__ dlogits,
+                                                         float *__restrict__ g_hk, float *__restrict__ g_hb, long npix, int k_out)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
+    f32x4 acc[2][2] = {};
+    const long nsteps = (npix + 3) >> 2;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long per = (nsteps + nwaves - 1) / nwaves;
+    const long s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
+    for (long s = s0; s < s1; ++s) {
+        const long p = s * 4 + k;
+        const bool ok = p < npix;
+        const float a0 = ok ? a9[p * UBD_C + m] : 0.f;
+        const float a1 = ok ? (m < 8 ? a9[p * UBD_C + 16 + m] : (m == 8 ? 1.f : 0.f)) : 0.f;
+        const float b0 = (ok && m < k_out) ? dlogits[p * k_out + m] : 0.f;
+        const float b1 = (ok && 16 + m < k_out) ? dlogits[p * k_out + 16 + m] : 0.f;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        if (k_out > 16) {
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D: col = lane&15 (k index), row = 4*(lane>>4) + r (channel index / ones row)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * k + r, col = m + 16 * nt;
+                const float v = acc[mt][nt][r];
+                if (col < k_out && v != 0.f) {
+                    if (row < UBD_C) atomicAdd(&g_hk[row * k_out + col], v);
+                    else if (row == UBD_C) atomicAdd(&g_hb[col], v);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------ dilated wgrad
+__global__ __launch_bounds__(256, 1) void dil_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gz,
+                                                           float *__restrict__ g_k, float *__restrict__ g_b, int n, int h,
+                                                           int w, int d, unsigned bytes)
+{
+    __shared__ float red[224 * 32];
+    const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4, wid = threadIdx.x >> 6;
+    // per-lane row description of the 14 M-tiles
+    int roff[14];      // element offset of (tap, ci) relative to the pixel, or marker
+    int rdy[14], rdx[14];
+#pragma unroll
+    for (int mt = 0; mt < 14; ++mt) {
+        const int rho = 16 * mt + m;
+        const int t = rho / UBD_C, ci = rho % UBD_C;
+        rdy[mt] = (t / 3 - 1) * d;
+        rdx[mt] = (t % 3 - 1) * d;
+        roff[mt] = (rdy[mt] * w + rdx[mt]) * UBD_C + ci;
+    }
+    // rows 0..207 (tiles 0..12) are always real (tap, ci) rows; tile 13 holds rows 208..215 (m < 8),
+    // the all-ones row 216 (m == 8, gives the bias gradient) and 7 padding rows.
+    const bool row13_real = m < 8, row13_ones = m == 8;
+    f32x4 acc[14][2] = {};
+    const int w4 = (w + 3) >> 2;
+    const long nsteps = (long)n * h * w4;
+    const long nwaves = (long)gridDim.x * 4;
+    const long wave = (long)blockIdx.x * 4 + wid;
+    const long per = (nsteps + nwaves - 1) / nwaves;
+    const long s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gz, 0, (int)bytes, 0x00020000);
+    const unsigned oob = bytes;
+
+    auto load = [&](long s, float (&a)[14], float &b0, float &b1) {
+        const long row = s / w4;                 // = img*h + y
+        const int xs = (int)(s % w4) * 4;
+        const int y = (int)(row % h);
+        const int px = xs + k;
+        const bool pok = px < w;
+        const unsigned pbase = (unsigned)(((size_t)row * w + px) * UBD_C);     // element index of the pixel
+        b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(pok ? (pbase + m) * 4u : oob), 0, 0));
+        b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((pok && m < 8) ? (pbase + 16 + m) * 4u : oob), 0, 0));
+#pragma unroll
+        for (int mt = 0; mt < 14; ++mt) {
+            const int iy = y + rdy[mt], ix = px + rdx[mt];
+            const bool real = (mt < 13) || row13_real;
+            const bool ok = real && pok && iy >= 0 && iy < h && ix >= 0 && ix < w;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(ok ? (unsigned)((int)pbase + roff[mt]) * 4u : oob), 0, 0));
+            a[mt] = (mt == 13 && row13_ones) ? 1.f : v;
+        }
+    };
+    auto fma_all = [&](const float (&a)[14], float b0, float b1) {
+#pragma unroll
+        for (int mt = 0; mt < 14; ++mt) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+        }
+    };
+    if (s0 < s1) {
+        float A0[14], A1[14], p0, p1, q0, q1;
+        load(s0, A0, p0, p1);
+        long s = s0;
+        for (;;) {
+            if (s + 1 < s1) load(s + 1, A1, q0, q1);
+            fma_all(A0, p0, p1);
+            if (++s >= s1) break;
+            if (s + 1 < s1) load(s + 1, A0, p0, p1);
+            fma_all(A1, q0, q1);
+            if (++s >= s1) break;
+        }
+    }
+    // block reduction through LDS, then one atomic per output per block
+    for (int t = threadIdx.x; t < 224 * 32; t += blockDim.x) red[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 14; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mt + 4 * k + r) * 32 + m + 16 * nt], acc[mt][nt][r]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 217 * UBD_C; t += blockDim.x) {
+        const int rho = t / UBD_C, co = t % UBD_C;
+        const float v = red[rho * 32 + co];
+        if (v != 0.f) {
+            if (rho < 216) atomicAdd(&g_k[rho * UBD_C + co], v);
+            else atomicAdd(&g_b[co], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ separable backward
+template <int CIN, int STRIDE, int IN_U8>
+__global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
+                                                      float *__restrict__ dDW, const float *__restrict__ fwdfrag,
+                                                      const float *__restrict__ bwdfrag, float *__restrict__ g_dw,
+                                                      float *__restrict__ g_pw, float *__restrict__ g_b, int n, int H, int W,
+                                                      int OH, int OW, int pad_lo, float pre_sub, float pre_div)
+{
+    constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
+    constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;           // tiles of the dDW product
+    constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;          // M tiles of the dpw product (CIN rows + ones row)
+    __shared__ float s_dw[4][16][UBD_C];
+    __shared__ float s_g[4][16][UBD_C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
+
+    float dwk[9][CPL];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+    float apw[6][NT_A];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int tl = 0; tl < NT_A; ++tl) apw[s][tl] = bwdfrag[(s * 2 + tl) * 64 + lane];
+    const bool ch_ok = (CIN == UBD_C) || (q < CIN);
+    const int cb = (CIN == UBD_C) ? 6 * q : q;
+
+    float ddw[9][CPL];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) ddw[t][s] = 0.f;
+    f32x4 accpw[MT_PW][2] = {};
+
+    const int tiles_x = (OW + 15) >> 4;
+    const long total = (long)n * OH * tiles_x;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + wid; tile < total; tile += nwaves) {
+        const int xt = (int)(tile % tiles_x);
+        const long rowid = tile / tiles_x;
+        const int oy = (int)(rowid % OH);
+        const long img = rowid / OH;
+        const int x0 = xt * 16;
+        const int ox = x0 + i;
+        const bool pvalid = ox < OW;
+
+        // ---- 1. input taps, depthwise output
+        float xv[9][CPL];
+        float dwv[CPL];
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * STRIDE + ky - pad_lo;
+            const bool rok = (iy >= 0) && (iy < H);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int t = ky * 3 + kx;
+                const int ix = ox * STRIDE + kx - pad_lo;
+                const bool ok = rok && ch_ok && (ix >= 0) && (ix < W) && pvalid;
+                const size_t e = (((size_t)img * H + (size_t)(rok ? iy : 0)) * W + (size_t)(ok ? ix : 0)) * CIN + cb;
+                if constexpr (CIN == UBD_C) {
+                    const f32x2 *p = (const f32x2 *)((const float *)xin + e);
+                    f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
+                    if (ok) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+                    xv[t][0] = v0[0]; xv[t][1] = v0[1]; xv[t][2] = v1[0]; xv[t][3] = v1[1]; xv[t][4] = v2[0]; xv[t][5] = v2[1];
+                } else {
+                    float v = 0.f;
+                    if (ok) {
+                        if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[e] - pre_sub) / pre_div;
+                        else v = (((const float *)xin)[e] - pre_sub) / pre_div;
+                    }
+                    xv[t][0] = v;
+                }
+#pragma unroll
+                for (int s = 0; s < CPL; ++s) dwv[s] = fmaf(xv[t][s], dwk[t][s], dwv[s]);
+            }
+        }
+        // ---- 2. G of this pixel, channels 6q..6q+5 (zero outside the tile)
+        float g6[6];
+        {
+            const f32x2 *pg = (const f32x2 *)(G + (((size_t)img * OH + oy) * OW + (size_t)(pvalid ? ox : 0)) * UBD_C + 6 * q);
+            f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
+            if (pvalid) { v0 = pg[0]; v1 = pg[1]; v2 = pg[2]; }
+            g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
+        }
+        // ---- 3. dDW[i][ch] = sum_co G[i][co] pw[ch][co]  (rows = channels in lane layout, cols = pixels)
+        f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
+            if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
+        }
+        float ddwv[CPL];
+        if constexpr (CIN == UBD_C) {
+            ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
+        } else {
+            ddwv[0] = dA[0];
+        }
+        // ---- 4. depthwise kernel gradient
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) ddw[t][s] = fmaf(xv[t][s], ddwv[s], ddw[t][s]);
+        // ---- 5. pointwise kernel / bias gradient: transpose DW and G through this wave's LDS tile
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) s_dw[wid][i][cb + s] = ch_ok ? dwv[s] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) s_g[wid][i][6 * q + s] = g6[s];
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int pr = 4 * g4 + q;               // lane (m = i, k = q): pixel row pr of the tile
+            const float b0 = s_g[wid][pr][i];
+            const float b1 = i < 8 ? s_g[wid][pr][16 + i] : 0.f;
+            float a0, a1 = 0.f;
+            if constexpr (CIN == UBD_C) {
+                a0 = s_dw[wid][pr][i];
+                a1 = i < 8 ? s_dw[wid][pr][16 + i] : (i == 8 ? 1.f : 0.f);
+            } else {
+                a0 = i < CIN ? s_dw[wid][pr][i] : (i == CIN ? 1.f : 0.f);
+            }
+            accpw[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accpw[0][0], 0, 0, 0);
+            accpw[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accpw[0][1], 0, 0, 0);
+            if constexpr (MT_PW == 2) {
+                accpw[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accpw[1][0], 0, 0, 0);
+                accpw[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accpw[1][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 6. dDW for the data-gradient kernel
+        if (dDW != nullptr && pvalid && ch_ok) {
+            float *pd = dDW + (((size_t)img * OH + oy) * OW + ox) * CIN + cb;
+            if constexpr (CIN == UBD_C) {
+                f32x2 *p2 = (f32x2 *)pd;
+                p2[0] = (f32x2){ddwv[0], ddwv[1]}; p2[1] = (f32x2){ddwv[2], ddwv[3]}; p2[2] = (f32x2){ddwv[4], ddwv[5]};
+            } else {
+                pd[0] = ddwv[0];
+            }
+        }
+    }
+    // ---- flush: depthwise kernel gradient (reduce over the 16 pixel lanes of each q group)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            float v = ddw[t][s];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (i == 0 && ch_ok && v != 0.f) atomicAdd(&g_dw[t * CIN + cb + s], v);
+        }
+    // pointwise kernel / bias gradient: D col = i (co), row = 4q + r (+16 mt) (ci or the ones row)
+#pragma unroll
+    for (int mt = 0; mt < MT_PW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * q + r, col = i + 16 * nt;
+                const float v = accpw[mt][nt][r];
+                if (col < UBD_C && v != 0.f) {
+                    if (row < CIN) atomicAdd(&g_pw[row * UBD_C + col], v);
+                    else if (row == CIN) atomicAdd(&g_b[col], v);
+                }
+            }
+}
+
+// G_below[q][c] = (sum_t dDW[(q + pad - t)/s][c] dw[t][c]) * (X[q][c] > 0)   (24-channel layers only)
+template <int STRIDE>
+__global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ dDW, const float *__restrict__ xmask,
+                                                     float *__restrict__ gout, const float *__restrict__ fwdfrag, int n, int H,
+                                                     int W, int OH, int OW, int pad_lo)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
+    float dwk[9][6];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+    const int tiles_x = (W + 15) >> 4;
+    const long total = (long)n * H * tiles_x;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
+        const int xt = (int)(tile % tiles_x);
+        const long rowid = tile / tiles_x;
+        const int iy = (int)(rowid % H);
+        const long img = rowid / H;
+        const int ix = xt * 16 + i;
+        if (ix >= W) continue;
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy - ky + pad_lo;
+            const bool yok = ty >= 0 && (STRIDE == 1 || (ty & 1) == 0) && (ty / STRIDE) < OH;
+            const int oy = ty / STRIDE;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix - kx + pad_lo;
+                const bool ok = yok && tx >= 0 && (STRIDE == 1 || (tx & 1) == 0) && (tx / STRIDE) < OW;
+                if (ok) {
+                    const int ox = tx / STRIDE;
+                    const f32x2 *p = (const f32x2 *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C + 6 * q);
+                    const f32x2 v0 = p[0], v1 = p[1], v2 = p[2];
+                    const int t = ky * 3 + kx;
+                    acc[0] = fmaf(v0[0], dwk[t][0], acc[0]); acc[1] = fmaf(v0[1], dwk[t][1], acc[1]);
+                    acc[2] = fmaf(v1[0], dwk[t][2], acc[2]); acc[3] = fmaf(v1[1], dwk[t][3], acc[3]);
+                    acc[4] = fmaf(v2[0], dwk[t][4], acc[4]); acc[5] = fmaf(v2[1], dwk[t][5], acc[5]);
+                }
+            }
+        }
+        const size_t e = (((size_t)img * H + iy) * W + ix) * UBD_C + 6 * q;
+        const f32x2 *pm = (const f32x2 *)(xmask + e);
+        const f32x2 m0 = pm[0], m1 = pm[1], m2 = pm[2];
+        f32x2 *po = (f32x2 *)(gout + e);
+        po[0] = (f32x2){m0[0] > 0.f ? acc[0] : 0.f, m0[1] > 0.f ? acc[1] : 0.f};
+        po[1] = (f32x2){m1[0] > 0.f ? acc[2] : 0.f, m1[1] > 0.f ? acc[3] : 0.f};
+        po[2] = (f32x2){m2[0] > 0.f ? acc[4] : 0.f, m2[1] > 0.f ? acc[5] : 0.f};
+    }
+}
+
+// ------------------------------------------------------------------------------------ host
+struct train_layout {
+    ubd_fwd_layout fwd;
+    size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, total;
+};
+
+static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train_layout *T)
+{
+    ubd_fwd_layout_compute(h, n, H, W, 1, &T->fwd);
+    size_t off = T->fwd.total;
+    const size_t small = ubd_align_up((size_t)n * (H / 4) * (W / 4) * UBD_C * sizeof(float), 256);
+    const size_t big = ubd_align_up((size_t)n * (H / 2) * (W / 2) * UBD_C * sizeof(float), 256);
+    const size_t lg = ubd_align_up((size_t)n * (H / 4) * (W / 4) * h->k_out * sizeof(float), 256);
+    T->off_bfrag = off;   off += ubd_align_up(UBD_BWD_FRAG_FLOATS * sizeof(float), 256);
+    T->off_logits = off;  off += lg;
+    T->off_dlogits = off; off += lg;
+    T->off_gq[0] = off;   off += small;
+    T->off_gq[1] = off;   off += small;
+    T->off_ddw3 = off;    off += small;
+    T->off_gb[0] = off;   off += big;
+    T->off_gb[1] = off;   off += big;
+    T->off_loss = off;    off += ubd_loss_workspace_bytes(h, n, H / 4, W / 4);
+    T->total = off;
+}
+
+extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int height, int width)
+{
+    if (!h) return 0;
+    train_layout T;
+    train_layout_compute(h, n, height, width, &T);
+    return T.total;
+}
+
+template <int CIN, int STRIDE>
+static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
+                           const float *bfrag, float *g_dw, float *g_pw, float *g_b, int n, int H, int W, int OH, int OW,
+                           int pad_lo, float sub, float div, hipStream_t st)
+{
+    const long tiles = (long)n * OH * ((OW + 15) / 16);
+    const int grid = ubd_grid_for(tiles, h->num_cus, 4, 2);
+    if (in_u8)
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, g_dw, g_pw, g_b, n, H, W, OH, OW, pad_lo, sub, div);
+    else
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, g_dw, g_pw, g_b, n, H, W, OH, OW, pad_lo, sub, div);
+}
+
+extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                              const int32_t *y_true, int n, int height, int width, float *grads, float *loss,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    UBD_REQUIRE(h && params && images && y_true && grads && loss && workspace, "ubd_train_step: null argument");
+    UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_train_step: only UBD_F32 in this build");
+    train_layout T;
+    train_layout_compute(h, n, height, width, &T);
+    UBD_REQUIRE(workspace_bytes >= T.total, "ubd_train_step: workspace too small (%zu < %zu)", workspace_bytes, T.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    float *logits = (float *)(ws + T.off_logits), *dlogits = (float *)(ws + T.off_dlogits);
+    float *bfrag = (float *)(ws + T.off_bfrag);
+    const float *wfrag = (const float *)(ws + T.fwd.off_wfrag);
+    const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
+
+    // forward (activations kept), loss + dlogits
+    int rc = ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, T.fwd, st);
+    if (rc) return rc;
+    const long npix = (long)n * H4 * W4;
+    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
+    if (rc) return rc;
+
+    UBD_CHECK_HIP(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), st));
+    pack_bwd_args pa;
+    for (int s = 0; s < 3; ++s) pa.off_sep_pw[s] = h->off_sep_pw[s];
+    for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
+    pa.c_in = h->cfg.c_in;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
+
+    const float *a1 = (const float *)(ws + T.fwd.off_a1), *a2 = (const float *)(ws + T.fwd.off_a2);
+    const float *acts[7];
+    for (int k = 0; k < 7; ++k) acts[k] = (const float *)(ws + T.fwd.off_acts[k]);     // L3, L4..L9 outputs
+    float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
+    float *ddw3 = (float *)(ws + T.off_ddw3);
+    float *gb[2] = {(float *)(ws + T.off_gb[0]), (float *)(ws + T.off_gb[1])};
+
+    int grid = (int)((npix + 255) / 256);
+    if (grid > h->num_cus * 8) grid = h->num_cus * 8;
+    // head
+    hipLaunchKernelGGL(head_dx_kernel, dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
+    {
+        const long nsteps = (npix + 3) / 4;
+        int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
+        hipLaunchKernelGGL(head_wgrad_kernel, dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
+    }
+    // dilated layers, top to bottom
+    const unsigned bytes = (unsigned)((size_t)npix * UBD_C * 4);
+    int cur = 0;
+    for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
+        const float *X = acts[k];                               // input of dilated layer k (= output of the layer below)
+        const long nsteps = (long)n * H4 * ((W4 + 3) / 4);
+        int gw = ubd_grid_for((nsteps + 31) / 32, h->num_cus, 4, 1);
+        hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], bytes);
+        ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
+        cur ^= 1;
+    }
+    // separable layers
+    const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;
+    const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
+    const float *bs0 = bfrag + UBD_BWD_DGRAD_FLOATS, *bs1 = bs0 + UBD_BWD_SEP_FLOATS, *bs2 = bs1 + UBD_BWD_SEP_FLOATS;
+    // L3: input a2 (H2 x W2), output H4 x W4, G = gq[cur]
+    launch_sep_bwd<UBD_C, 2>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    {
+        const long tiles = (long)n * H2 * ((W2 + 15) / 16);
+        const int g3 = ubd_grid_for(tiles, h->num_cus, 4, 8);
+        hipLaunchKernelGGL(sep_dx_kernel<2>, dim3(g3), dim3(256), 0, st, ddw3, a2, gb[0], sf2, n, H2, W2, H4, W4, pad_s2);
+        // L2: input a1, output H2 x W2, G = gb[0]
+        launch_sep_bwd<UBD_C, 1>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+        hipLaunchKernelGGL(sep_dx_kernel<1>, dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
+    }
+    // L1: input = images, no data gradient
+    float sub = 0.f, div = 1.f;
+    if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
+    const int u8 = in_dtype == UBD_IN_U8;
+    if (h->cfg.c_in == 1)
+        launch_sep_bwd<1, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+    else
+        launch_sep_bwd<3, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}

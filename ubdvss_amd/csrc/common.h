@@ -57,3 +57,14 @@ struct ubd_fwd_layout {
     size_t off_acts[7];      // training: L3..L9 outputs kept
     size_t total;
 };
+
+// ---- cross-file internals ------------------------------------------------------------------
+void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L);
+int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st);
+void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
+                        const float *in, float *out, int n, int H4, int W4, hipStream_t st);
+int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu);
+int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
+                  char *ws, hipStream_t st);
+extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);

@@ -91,6 +91,22 @@ __device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t ro
     }
 }
 
+// Backward epilogue: no bias; multiply by the ReLU mask of the layer below (its saved output > 0).
+__device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const float *__restrict__ mask_src,
+                                                  size_t row_base_elems, int x0, int ow, int lane, f32x4 acc0, f32x4 acc1)
+{
+    const int co = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int px = x0 + 4 * q + r;
+        if (px < ow) {
+            const size_t e = (row_base_elems + (size_t)px) * UBD_C;
+            y[e + co] = mask_src[e + co] > 0.f ? acc0[r] : 0.f;
+            if (co < 8) y[e + 16 + co] = mask_src[e + 16 + co] > 0.f ? acc1[r] : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Separable 3x3 conv (+bias+ReLU).  One wave = one tile of 16 consecutive output pixels.
 // lane = (i = lane&15 : pixel, q = lane>>4 : channel group).
@@ -212,6 +228,10 @@ __device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc
     }
 }
 
+// EPI 0: y = relu(conv + bias) (forward).  EPI 1: y = conv * (mask_src > 0) (data gradient: `wfrag`
+// then holds the spatially flipped, channel-transposed kernel and `bias` is the saved activation
+// whose ReLU mask applies).
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                              const float *__restrict__ wfrag,
                                                              const float *__restrict__ bias, int n, int h, int w,
@@ -227,7 +247,8 @@ __global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__rest
             wr[t][j][0] = wfrag[((t * 6 + j) * 2 + 0) * 64 + lane];
             wr[t][j][1] = wfrag[((t * 6 + j) * 2 + 1) * 64 + lane];
         }
-    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    float b0 = 0.f, b1 = 0.f;
+    if constexpr (EPI == 0) { b0 = bias[i]; b1 = (i < 8) ? bias[16 + i] : 0.f; }
 
     const int tiles_x = (w + 15) >> 4;
     const long total = (long)n * h * tiles_x;
@@ -262,7 +283,8 @@ __global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__rest
         }
         const int xt = (int)(tl % tiles_x);
         const long rowid = tl / tiles_x;     // = img*h + y
-        store_tile_relu(y, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1, b0, b1);
+        if constexpr (EPI == 0) store_tile_relu(y, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1, b0, b1);
+        else store_tile_masked(y, bias, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1);
     };
 
     a_frags A0, A1;
@@ -342,7 +364,7 @@ extern "C" size_t ubd_forward_workspace_bytes(const ubd_handle *h, int n, int he
     return L.total;
 }
 
-static int grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu)
+int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu)
 {
     long blocks = (waves_needed + waves_per_block - 1) / waves_per_block;
     long cap = (long)num_cus * blocks_per_cu;
@@ -356,7 +378,7 @@ static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, 
                        int n, int H, int W, int OH, int OW, int pad_lo, float sc, float sh, hipStream_t st)
 {
     long tiles = (long)n * OH * ((OW + 15) / 16);
-    int grid = grid_for(tiles, h->num_cus, 4, 8);
+    int grid = ubd_grid_for(tiles, h->num_cus, 4, 8);
     if (in_u8)
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
     else
@@ -372,17 +394,26 @@ static void launch_pack(const ubd_handle *h, const float *params, float *wfrag, 
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, st, params, wfrag, pa);
 }
 
+// frag: this layer's 6912 packed floats; aux: bias (epi 0) or mask source activation (epi 1)
+void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
+                        const float *in, float *out, int n, int H4, int W4, hipStream_t st)
+{
+    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
+    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
+    int grid = ubd_grid_for(tiles, h->num_cus, 4, 1);
+    grid = (grid + 7) / 8 * 8;
+    if (epi == 0)
+        hipLaunchKernelGGL(dilconv_f32_kernel<0>, dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, dilation, in_bytes);
+    else
+        hipLaunchKernelGGL(dilconv_f32_kernel<1>, dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, dilation, in_bytes);
+}
+
 static void launch_dil(const ubd_handle *h, const float *params, const float *wfrag, int k, const float *in, float *out,
                        int n, int H4, int W4, hipStream_t st)
 {
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *dfrag = wfrag + 3 * per_sep;
-    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
-    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
-    int grid = grid_for(tiles, h->num_cus, 4, 1);
-    grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL(dilconv_f32_kernel, dim3(grid), dim3(256), 0, st, in, out, dfrag + (size_t)k * UBD_DIL_FRAG_FLOATS,
-                       params + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], in_bytes);
+    ubd_launch_dilconv(h, 0, dfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, params + h->off_dil_b[k], UBD_DILATIONS[k], in, out, n, H4, W4, st);
 }
 
 extern "C" int ubd_pack_weights(ubd_handle *h, const float *params, void *workspace, size_t workspace_bytes, void *stream)

@@ -1,5 +1,5 @@
 // Training path of the ubdvss hot path on gfx950: fused loss, backward, Adam.
-// (work in progress: ubd_adam_step is implemented; loss/backward land next)
+// Adam update (loss: loss.hip; backward + train step: backward.hip).
 #include "common.h"
 
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
@@ -29,11 +29,3 @@ extern "C" int ubd_adam_step(float *params, const float *grads, float *m, float 
     return 0;
 }
 
-extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *, int, int, int) { return 0; }
-
-extern "C" int ubd_train_step(ubd_handle *, const float *, const void *, int, int, const int32_t *, int, int, int,
-                              float *, float *, void *, size_t, void *)
-{
-    ubd_set_error("ubd_train_step: not implemented in this build");
-    return 3;
-}

@@ -1,0 +1,67 @@
+"""Data-parallel plumbing (the reference is single-device).
+
+One process per GPU.  Inference shards images by rank with no collective (replicas).  Training has
+ONE exchange step per iteration: a sum all-reduce of the flat fp32 gradient vector (33 028 floats for
+the RGB detection model) over RCCL/xGMI (``backend="nccl"`` on ROCm) -- or gloo on CPU in the tests;
+the 1/world scaling is folded into the Adam kernel.  The loss is evaluated per replica.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, world, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kwargs["device_id"] = torch.device(f"cuda:{local}")
+        dist.init_process_group(backend, **kwargs)
+    return rk, world, local
+
+
+def shard_range(n_items, rk, world):
+    """Contiguous [lo, hi) slice of n_items owned by rank rk (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rk * base + min(rk, rem)
+    return lo, lo + base + (1 if rk < rem else 0)
+
+
+def allreduce_gradients(flat_grads, group=None):
+    """In-place SUM all-reduce of the flat gradient vector; returns the scale (1/world) the optimiser
+    must apply to obtain the data-parallel mean."""
+    w = world_size(group)
+    if w > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / w
+
+
+def broadcast_parameters(flat_params, src=0, group=None):
+    if world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)
+
+
+def max_over_ranks(value, device=None, group=None):
+    """max of a python float over all ranks (bench timing contract)."""
+    if world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

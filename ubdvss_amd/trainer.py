@@ -11,9 +11,8 @@ import ctypes
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
-from . import _lib
+from . import _lib, distributed
 from .net import PreprocessingType
 
 
@@ -39,12 +38,8 @@ class Trainer:
         self._ws = None
         self._pg = process_group
 
-    def _world(self):
-        return dist.get_world_size(self._pg) if dist.is_available() and dist.is_initialized() else 1
-
     def broadcast_weights(self, src=0):
-        if self._world() > 1:
-            dist.broadcast(self.model.params, src=src, group=self._pg)
+        distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
 
     def backward_on_device(self, images, targets):
         """images: device tensor (N,H,W,C) float32 or uint8; targets: device int32 (N,H/4,W/4[,1]).
@@ -68,15 +63,13 @@ class Trainer:
                                                 mdl._stream()), "ubd_train_step")
 
     def apply_gradients(self):
-        world = self._world()
-        if world > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self._pg)
+        grad_scale = distributed.allreduce_gradients(self.grads, group=self._pg)
         self.iterations += 1
         o = self.opt
         with torch.cuda.device(self.model.device):
             _lib.check(self._lib.ubd_adam_step(self.model.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                                self.v.data_ptr(), self.grads.numel(), self.iterations, o.lr, o.beta_1,
-                                               o.beta_2, o.epsilon, 1.0 / world, self.model._stream()), "ubd_adam_step")
+                                               o.beta_2, o.epsilon, grad_scale, self.model._stream()), "ubd_adam_step")
 
     def train_step_on_device(self, images, targets):
         self.backward_on_device(images, targets)
