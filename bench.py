@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-train", action="store_true", help="skip the extra train-step measurement")
+    ap.add_argument("--train-batch", type=int, default=64)
     return ap.parse_args()
 
 
@@ -103,7 +105,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device(f"cuda:{torch.cuda.current_device()}")
 
-    from ubdvss_amd import NetConfig, Model, ModelRunner, synthetic, _lib
+    from ubdvss_amd import NetConfig, Model, ModelRunner, Trainer, Adam, synthetic, _lib
     cfg = NetConfig(grey=False)
     model = Model(cfg, seed=1)                               # glorot-uniform random init, zero biases
     runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
@@ -135,6 +137,37 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH * args.steps / elapsed
+
+    # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), fp32, batch/GPU = --train-batch
+    train = None
+    if not args.no_train:
+        tb = args.train_batch
+        tlabels = synthetic.rectangle_maps(30 + rank, tb, SIDE // 4, SIDE // 4)
+        tx = torch.from_numpy(synthetic.textured_images(31 + rank, tlabels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
+        ty = torch.from_numpy(tlabels).to(dev)
+        tmodel = Model(cfg, seed=1)
+        trainer = Trainer(tmodel, Adam(lr=1e-3))
+        trainer.broadcast_weights()
+        for _ in range(max(1, args.warmup)):
+            trainer.train_step_on_device(tx, ty)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step_on_device(tx, ty)
+        sync_all()
+        tel = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([tel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tel = float(t.item())
+        train_bytes_per_image = (3 * 12599296 - SIDE * SIDE * C_IN) * 4.0       # E_train elements, fp32
+        train = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
+                 "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb, "dtype": "f32",
+                 "parallelism": f"dp{world}: per-replica loss, one flat-gradient all-reduce (RCCL) per step" if world > 1 else "single GPU",
+                 "loss_last": round(float(trainer.loss[0]), 5),
+                 "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
+        del trainer, tmodel, tx, ty
+        torch.cuda.empty_cache()
 
     line = None
     if rank == 0:
@@ -192,7 +225,7 @@ def main():
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},

@@ -106,34 +106,50 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
     const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long per = (nsteps + nwaves - 1) / nwaves;
     const long s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
-    for (long s = s0; s < s1; ++s) {
-        const long p = s * 4 + k;
-        const bool ok = p < npix;
-        const float a0 = ok ? a9[p * UBD_C + m] : 0.f;
-        const float a1 = ok ? (m < 8 ? a9[p * UBD_C + 16 + m] : (m == 8 ? 1.f : 0.f)) : 0.f;
-        const float b0 = (ok && m < k_out) ? dlogits[p * k_out + m] : 0.f;
-        const float b1 = (ok && 16 + m < k_out) ? dlogits[p * k_out + 16 + m] : 0.f;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        if (k_out > 16) {
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (long sb = s0; sb < s1; sb += 8) {
+        float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                          // 8 k-steps of loads in flight
+            const long p = (sb + u) * 4 + k;
+            const bool ok = (sb + u < s1) && p < npix;
+            a0[u] = ok ? a9[p * UBD_C + m] : 0.f;
+            a1[u] = ok ? (m < 8 ? a9[p * UBD_C + 16 + m] : (m == 8 ? 1.f : 0.f)) : 0.f;
+            b0[u] = (ok && m < k_out) ? dlogits[p * k_out + m] : 0.f;
+            b1[u] = (ok && 16 + m < k_out) ? dlogits[p * k_out + 16 + m] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            if (k_out > 16) {
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
         }
     }
-    // D: col = lane&15 (k index), row = 4*(lane>>4) + r (channel index / ones row)
+    // D: col = lane&15 (k index), row = 4*(lane>>4) + r (channel index / ones row).
+    // Block reduction in LDS first: with k_out == 1 every wave targets the same 25 addresses.
+    __shared__ float red[32 * 32];
+    for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) red[t] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mt + 4 * k + r, col = m + 16 * nt;
                 const float v = acc[mt][nt][r];
-                if (col < k_out && v != 0.f) {
-                    if (row < UBD_C) atomicAdd(&g_hk[row * k_out + col], v);
-                    else if (row == UBD_C) atomicAdd(&g_hb[col], v);
-                }
+                if (v != 0.f) atomicAdd(&red[(16 * mt + 4 * k + r) * 32 + m + 16 * nt], v);
             }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 25 * 32; t += blockDim.x) {
+        const int row = t >> 5, col = t & 31;
+        const float v = red[t];
+        if (col < k_out && v != 0.f) {
+            if (row < UBD_C) atomicAdd(&g_hk[row * k_out + col], v);
+            else atomicAdd(&g_hb[col], v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ dilated wgrad
@@ -159,22 +175,22 @@ __global__ __launch_bounds__(256, 1) void dil_wgrad_kernel(const float *__restri
     const bool row13_real = m < 8, row13_ones = m == 8;
     f32x4 acc[14][2] = {};
     const int w4 = (w + 3) >> 2;
-    const long nsteps = (long)n * h * w4;
-    const long nwaves = (long)gridDim.x * 4;
-    const long wave = (long)blockIdx.x * 4 + wid;
-    const long per = (nsteps + nwaves - 1) / nwaves;
-    const long s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
+    const int nsteps = n * h * w4;
+    const int nwaves = gridDim.x * 4;
+    const int wave = blockIdx.x * 4 + wid;
+    const int per = (nsteps + nwaves - 1) / nwaves;
+    const int s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gz, 0, (int)bytes, 0x00020000);
     const unsigned oob = bytes;
 
-    auto load = [&](long s, float (&a)[14], float &b0, float &b1) {
-        const long row = s / w4;                 // = img*h + y
-        const int xs = (int)(s % w4) * 4;
-        const int y = (int)(row % h);
+    auto load = [&](int s, float (&a)[14], float &b0, float &b1) {
+        const int row = (int)((unsigned)s / (unsigned)w4);                 // = img*h + y
+        const int xs = (int)((unsigned)s % (unsigned)w4) * 4;
+        const int y = (int)((unsigned)row % (unsigned)h);
         const int px = xs + k;
         const bool pok = px < w;
-        const unsigned pbase = (unsigned)(((size_t)row * w + px) * UBD_C);     // element index of the pixel
+        const unsigned pbase = (unsigned)(row * w + px) * (unsigned)UBD_C;     // element index of the pixel
         b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(pok ? (pbase + m) * 4u : oob), 0, 0));
         b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((pok && m < 8) ? (pbase + 16 + m) * 4u : oob), 0, 0));
 #pragma unroll
@@ -194,15 +210,21 @@ __global__ __launch_bounds__(256, 1) void dil_wgrad_kernel(const float *__restri
         }
     };
     if (s0 < s1) {
-        float A0[14], A1[14], p0, p1, q0, q1;
+        // unconditional (clamped) prefetch, two steps ahead: see the note in forward.hip dilconv
+        float A0[14], A1[14], A2[14], p0, p1, q0, q1, r0, r1;
+        const int sl = s1 - 1;
         load(s0, A0, p0, p1);
-        long s = s0;
+        load(s0 + 1 < sl ? s0 + 1 : sl, A1, q0, q1);
+        int s = s0;
         for (;;) {
-            if (s + 1 < s1) load(s + 1, A1, q0, q1);
+            load(s + 2 < sl ? s + 2 : sl, A2, r0, r1);
             fma_all(A0, p0, p1);
             if (++s >= s1) break;
-            if (s + 1 < s1) load(s + 1, A0, p0, p1);
+            load(s + 2 < sl ? s + 2 : sl, A0, p0, p1);
             fma_all(A1, q0, q1);
+            if (++s >= s1) break;
+            load(s + 2 < sl ? s + 2 : sl, A1, q0, q1);
+            fma_all(A2, r0, r1);
             if (++s >= s1) break;
         }
     }
@@ -264,13 +286,13 @@ __global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ x
     f32x4 accpw[MT_PW][2] = {};
 
     const int tiles_x = (OW + 15) >> 4;
-    const long total = (long)n * OH * tiles_x;
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + wid; tile < total; tile += nwaves) {
-        const int xt = (int)(tile % tiles_x);
-        const long rowid = tile / tiles_x;
-        const int oy = (int)(rowid % OH);
-        const long img = rowid / OH;
+    const int total = n * OH * tiles_x;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int tile = blockIdx.x * (blockDim.x >> 6) + wid; tile < total; tile += nwaves) {
+        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int oy = (int)((unsigned)rowid % (unsigned)OH);
+        const int img = (int)((unsigned)rowid / (unsigned)OH);
         const int x0 = xt * 16;
         const int ox = x0 + i;
         const bool pvalid = ox < OW;
@@ -410,13 +432,13 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
 #pragma unroll
         for (int s = 0; s < 6; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
     const int tiles_x = (W + 15) >> 4;
-    const long total = (long)n * H * tiles_x;
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
-        const int xt = (int)(tile % tiles_x);
-        const long rowid = tile / tiles_x;
-        const int iy = (int)(rowid % H);
-        const long img = rowid / H;
+    const int total = n * H * tiles_x;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
+        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int iy = (int)((unsigned)rowid % (unsigned)H);
+        const int img = (int)((unsigned)rowid / (unsigned)H);
         const int ix = xt * 16 + i;
         if (ix >= W) continue;
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -549,7 +571,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
         const float *X = acts[k];                               // input of dilated layer k (= output of the layer below)
         const long nsteps = (long)n * H4 * ((W4 + 3) / 4);
-        int gw = ubd_grid_for((nsteps + 31) / 32, h->num_cus, 4, 1);
+        int gw = ubd_grid_for((nsteps + 31) / 32, h->num_cus, 4, 2);
         hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], bytes);
         ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         cur ^= 1;

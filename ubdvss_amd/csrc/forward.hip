@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t ro
 }
 
 // Backward epilogue: no bias; multiply by the ReLU mask of the layer below (its saved output > 0).
-__device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const float *__restrict__ mask_src,
+__device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const float (&mk)[8],
                                                   size_t row_base_elems, int x0, int ow, int lane, f32x4 acc0, f32x4 acc1)
 {
     const int co = lane & 15, q = lane >> 4;
@@ -101,8 +101,8 @@ __device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const f
         int px = x0 + 4 * q + r;
         if (px < ow) {
             const size_t e = (row_base_elems + (size_t)px) * UBD_C;
-            y[e + co] = mask_src[e + co] > 0.f ? acc0[r] : 0.f;
-            if (co < 8) y[e + 16 + co] = mask_src[e + 16 + co] > 0.f ? acc1[r] : 0.f;
+            y[e + co] = mk[r] > 0.f ? acc0[r] : 0.f;
+            if (co < 8) y[e + 16 + co] = mk[4 + r] > 0.f ? acc1[r] : 0.f;
         }
     }
 }
@@ -139,13 +139,13 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
     const int cb = (CIN == UBD_C) ? 6 * q : q;
 
     const int tiles_x = (OW + 15) >> 4;
-    const long total = (long)n * OH * tiles_x;
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    for (long tile = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
-        const int xt = (int)(tile % tiles_x);
-        const long rowid = tile / tiles_x;
-        const int oy = (int)(rowid % OH);
-        const long img = rowid / OH;
+    const int total = n * OH * tiles_x;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
+        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int oy = (int)((unsigned)rowid % (unsigned)OH);
+        const int img = (int)((unsigned)rowid / (unsigned)OH);
         const int x0 = xt * 16;
         const int ox = x0 + i;
 
@@ -200,14 +200,13 @@ struct a_frags {
     f32x2 v2[9];
 };
 
-__device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, long tile,
+__device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc, unsigned oob, int tile,
                                          int tiles_x, int h, int w, int d, int lane)
 {
     const int i = lane & 15, q = lane >> 4;
-    const int xt = (int)(tile % tiles_x);
-    const long rowid = tile / tiles_x;
-    const int yy = (int)(rowid % h);
-    const long img = rowid / h;
+    const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
+    const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);       // = img*h + y
+    const int yy = (int)((unsigned)rowid % (unsigned)h);
     const int px = xt * 16 + i;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -217,7 +216,7 @@ __device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = px + (kx - 1) * d;
             const bool ok = rok && (ix >= 0) && (ix < w);
-            const unsigned byte_off = (unsigned)((((size_t)img * h + (size_t)iy) * w + (size_t)ix) * (UBD_C * 4));
+            const unsigned byte_off = (unsigned)((rowid + (ky - 1) * d) * w + ix) * (unsigned)(UBD_C * 4);
             const unsigned o4 = ok ? byte_off + 16u * q : oob;
             const unsigned o2 = ok ? byte_off + 64u + 8u * q : oob;
             u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o4, 0, 0);
@@ -232,7 +231,7 @@ __device__ __forceinline__ void dil_load(a_frags &a, __amdgpu_buffer_rsrc_t rsrc
 // then holds the spatially flipped, channel-transposed kernel and `bias` is the saved activation
 // whose ReLU mask applies).
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+__global__ __launch_bounds__(256, 2) void dilconv_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                              const float *__restrict__ wfrag,
                                                              const float *__restrict__ bias, int n, int h, int w,
                                                              int d, unsigned in_bytes)
@@ -251,23 +250,36 @@ __global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__rest
     if constexpr (EPI == 0) { b0 = bias[i]; b1 = (i < 8) ? bias[16 + i] : 0.f; }
 
     const int tiles_x = (w + 15) >> 4;
-    const long total = (long)n * h * tiles_x;
+    const int total = n * h * tiles_x;
     // XCD-aware split: blocks b and b+8 share an XCD (and its L2); give each XCD group one
     // contiguous eighth of the tile range so that halo rows are re-read from the same L2.
     const int xcd = blockIdx.x & 7;
     const int nblk_x = (gridDim.x + 7 - xcd) >> 3;        // blocks in this XCD group
-    const long chunk = (total + 7) >> 3;
-    const long t_begin = (long)xcd * chunk;
-    const long t_end = (t_begin + chunk < total) ? t_begin + chunk : total;
-    const long stride = (long)nblk_x * 4;
-    long tile = t_begin + (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int chunk = (total + 7) >> 3;
+    const int t_begin = xcd * chunk;
+    const int t_end = (t_begin + chunk < total) ? t_begin + chunk : total;
+    const int stride = nblk_x * 4;
+    int tile = t_begin + (int)(blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);
     if (tile >= t_end) return;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
     const unsigned oob = in_bytes;   // offset >= num_records -> hardware returns 0
 
-    auto compute_store = [&](const a_frags &a, long tl) {
+    auto compute_store = [&](const a_frags &a, int tl) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        float mk[8];
+        if constexpr (EPI == 1) {      // ReLU-mask source of this tile's outputs: issued now, consumed after the MFMAs
+            const int co = lane & 15, q = lane >> 4;
+            const int xt0 = (int)((unsigned)tl % (unsigned)tiles_x);
+            const int rid = (int)((unsigned)tl / (unsigned)tiles_x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int opx = xt0 * 16 + 4 * q + r;
+                const size_t e = ((size_t)rid * w + (size_t)(opx < w ? opx : 0)) * UBD_C;
+                mk[r] = bias[e + co];
+                mk[4 + r] = bias[e + 16 + (co & 7)];
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
@@ -281,22 +293,26 @@ __global__ __launch_bounds__(256, 1) void dilconv_f32_kernel(const float *__rest
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v2[t][j], wr[t][4 + j][1], acc1, 0, 0, 0);
             }
         }
-        const int xt = (int)(tl % tiles_x);
-        const long rowid = tl / tiles_x;     // = img*h + y
+        const int xt = (int)((unsigned)tl % (unsigned)tiles_x);
+        const int rowid = (int)((unsigned)tl / (unsigned)tiles_x);     // = img*h + y
         if constexpr (EPI == 0) store_tile_relu(y, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1, b0, b1);
-        else store_tile_masked(y, bias, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1);
+        else store_tile_masked(y, mk, (size_t)rowid * w, xt * 16, w, lane, acc0, acc1);
     };
 
+    // Register double buffering.  The prefetch is UNCONDITIONAL (the tile index is clamped on the last
+    // iteration): a conditional prefetch makes hipcc's s_waitcnt insertion assume the worst-case number of
+    // outstanding loads at the join and wait for the NEXT tile's loads before this tile's MFMAs.
     a_frags A0, A1;
+    const int t_last = t_end - 1;
     dil_load(A0, rsrc, oob, tile, tiles_x, h, w, d, lane);
     for (;;) {
-        long nxt = tile + stride;
-        if (nxt < t_end) dil_load(A1, rsrc, oob, nxt, tiles_x, h, w, d, lane);
+        int nxt = tile + stride;
+        dil_load(A1, rsrc, oob, nxt < t_last ? nxt : t_last, tiles_x, h, w, d, lane);
         compute_store(A0, tile);
         tile = nxt;
         if (tile >= t_end) break;
         nxt = tile + stride;
-        if (nxt < t_end) dil_load(A0, rsrc, oob, nxt, tiles_x, h, w, d, lane);
+        dil_load(A0, rsrc, oob, nxt < t_last ? nxt : t_last, tiles_x, h, w, d, lane);
         compute_store(A1, tile);
         tile = nxt;
         if (tile >= t_end) break;
@@ -400,7 +416,7 @@ void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const f
 {
     const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
     const long tiles = (long)n * H4 * ((W4 + 15) / 16);
-    int grid = ubd_grid_for(tiles, h->num_cus, 4, 1);
+    int grid = ubd_grid_for(tiles, h->num_cus, 4, 2);     // 250 VGPRs -> two waves per SIMD hide each other's waits
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
         hipLaunchKernelGGL(dilconv_f32_kernel<0>, dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, dilation, in_bytes);

@@ -187,13 +187,22 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *
     if (threadIdx.x == 0) blockties[blockIdx.x] = (unsigned)r;
 }
 
-__global__ void loss_tiescan_kernel(unsigned *blockties, int nblocks)
+__global__ __launch_bounds__(1024) void loss_tiescan_kernel(unsigned *blockties, int nblocks)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned acc = 0;
-        for (int b = 0; b < nblocks; ++b) { const unsigned c = blockties[b]; blockties[b] = acc; acc += c; }
-        blockties[nblocks] = acc;
+    // exclusive scan of <= LOSS_MAX_BLOCKS (1024) counts by one 1024-thread block
+    __shared__ unsigned s[1024];
+    const int t = threadIdx.x;
+    const unsigned mine = t < nblocks ? blockties[t] : 0u;
+    s[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? s[t - o] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
     }
+    if (t < nblocks) blockties[t] = s[t] - mine;
+    if (t == nblocks - 1) blockties[nblocks] = s[t];
 }
 
 // ---- gradient + hard-negative / classification sums --------------------------------------------
@@ -310,7 +319,7 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 4096, 2);
     hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist + 4096, 2, npix);
     hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, blockties);
-    hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(64), 0, st, blockties, cgrid);
+    hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix, k_out - 1, loss);
     UBD_CHECK_HIP(hipGetLastError());

@@ -548,6 +548,119 @@ __global__ __launch_bounds__(64) void pp_boxes_kernel(int n, int h, int w, const
     }
 }
 
+// Wave-cooperative variant (default): one wave per kept object, row extents and hull in LDS.
+// A row point (x_i, y0+i) is a vertex of the left (min-x) chain iff the largest incoming slope
+// dx/dy over all earlier rows is strictly smaller than the smallest outgoing slope over all later
+// rows (exact integer cross-multiplication); mirrored for the right chain.  Every lane tests its own
+// rows against all others (O(rows^2) cheap integer work, LDS broadcast reads), vertices are
+// compacted with ballots; lane 0 then orders the polygon like cv::convexHull and runs the calipers.
+__device__ __forceinline__ void hull_finish(ipt *P, int nl, int nr, int &n_out)
+{
+    // P = lc[0..nl-1] (top -> bottom) followed by rc[0..nr-1] (top -> bottom): reverse rc
+    ipt *rc = P + nl;
+    for (int a = 0, b = nr - 1; a < b; ++a, --b) { ipt t = rc[a]; rc[a] = rc[b]; rc[b] = t; }
+    int n = nl + nr;
+    if (nr > 0 && P[nl - 1].x == P[nl].x && P[nl - 1].y == P[nl].y) {           // bottom junction
+        for (int k = nl; k < n - 1; ++k) P[k] = P[k + 1];
+        --n;
+    }
+    if (n > 1 && P[n - 1].x == P[0].x && P[n - 1].y == P[0].y) --n;            // top junction
+    bool changed = true;
+    while (changed && n > 2) {
+        changed = false;
+        for (int k = 0; k < n && n > 2; ++k) {
+            const ipt a = P[(k + n - 1) % n], b = P[k], c = P[(k + 1) % n];
+            if (cross3(a, b, c) == 0) {
+                for (int m = k; m < n - 1; ++m) P[m] = P[m + 1];
+                --n; --k; changed = true;
+            }
+        }
+    }
+    if (n == 2) {
+        const bool swap = (P[1].x < P[0].x) || (P[1].x == P[0].x && P[1].y < P[0].y);
+        if (swap) { ipt t = P[0]; P[0] = P[1]; P[1] = t; }
+    } else if (n > 2) {
+        int s = 0;
+        for (int k = 1; k < n; ++k)
+            if (P[k].x < P[s].x || (P[k].x == P[s].x && P[k].y < P[s].y)) s = k;
+        if (s != 0) {
+            auto rev = [&](int a, int b) { for (; a < b; ++a, --b) { ipt t = P[a]; P[a] = P[b]; P[b] = t; } };
+            rev(0, s - 1); rev(s, n - 1); rev(0, n - 1);
+        }
+    }
+    n_out = n;
+}
+
+__global__ __launch_bounds__(256) void pp_boxes_wave_kernel(int n, int h, int w, const int *__restrict__ nkept,
+                                                            int *__restrict__ stage, const int *__restrict__ ymax,
+                                                            const int *__restrict__ rows_ws, int cap, int scale)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int *rws = smem + wid * (6 * h + 4);
+    ipt *pts = (ipt *)(rws + 2 * h);
+    for (int img = blockIdx.x; img < n; img += gridDim.x) {
+        const int nk = min(nkept[img], cap);
+        for (int k = wid; k < nk; k += nw) {
+            int *st = stage + ((size_t)img * cap + k) * STAGE_INTS;
+            const int y0 = st[0] / w;
+            const int nrows = ymax[(size_t)img * cap + k] - y0 + 1;
+            const int *g = rows_ws + ((size_t)img * cap + k) * (size_t)(6 * h) + 2 * y0;
+            for (int r = lane; r < 2 * nrows; r += 64) rws[r] = g[r];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            int cnt[2] = {0, 0};
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {            // 0: left chain (min x), 1: right chain (max x)
+                ipt *out = pts + (side ? cnt[0] : 0);
+                int nout = 0;
+                for (int base = 0; base < nrows; base += 64) {
+                    const int i = base + lane;
+                    bool isv = false;
+                    int xi = 0;
+                    if (i < nrows) {
+                        xi = rws[2 * i + side];
+                        if (i == 0 || i == nrows - 1) {
+                            isv = true;
+                        } else {
+                            // extreme incoming slope (xi - xa)/(i - a), a < i ; extreme outgoing (xb - xi)/(b - i), b > i
+                            int in_n = xi - rws[2 * (i - 1) + side], in_d = 1;        // |n| < 2^15, d < 2^15: products fit int32
+                            for (int a = i - 2; a >= 0; --a) {
+                                const int nn = xi - rws[2 * a + side], dd = i - a;
+                                const bool better = side ? (nn * in_d < in_n * dd) : (nn * in_d > in_n * dd);
+                                if (better) { in_n = nn; in_d = dd; }
+                            }
+                            int out_n = rws[2 * (i + 1) + side] - xi, out_d = 1;
+                            for (int b = i + 2; b < nrows; ++b) {
+                                const int nn = rws[2 * b + side] - xi, dd = b - i;
+                                const bool better = side ? (nn * out_d > out_n * dd) : (nn * out_d < out_n * dd);
+                                if (better) { out_n = nn; out_d = dd; }
+                            }
+                            isv = side ? (in_n * out_d > out_n * in_d) : (in_n * out_d < out_n * in_d);
+                        }
+                    }
+                    const unsigned long long bal = __ballot(isv);
+                    if (isv) out[nout + __popcll(bal & ((1ull << lane) - 1ull))] = (ipt){xi, y0 + i};
+                    nout += __popcll(bal);
+                }
+                cnt[side] = nout;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                int nh = 0;
+                hull_finish(pts, cnt[0], cnt[1], nh);
+                float box[8];
+                min_area_box(pts, nh, box);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
+                st[9] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ vote
 // Class vote (segmap_manager.py:59-67): mean over the filled contour of softmax(class logits).
 __global__ __launch_bounds__(256) void pp_vote_kernel(const float *__restrict__ logits, int k_out, const int *__restrict__ owner,
@@ -610,7 +723,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
 {
     UBD_REQUIRE(hd && logits && quads && counts && workspace, "ubd_postprocess: null argument");
     UBD_REQUIRE(n > 0 && map_h > 0 && map_w > 0 && cap > 0, "ubd_postprocess: bad sizes n=%d h=%d w=%d cap=%d", n, map_h, map_w, cap);
-    UBD_REQUIRE((long)map_h * map_w < (1L << 30) && (long)n * map_h * map_w < (1L << 31), "ubd_postprocess: map too large");
+    UBD_REQUIRE(map_h < 32768 && map_w < 32768 && (long)n * map_h * map_w < (1L << 31), "ubd_postprocess: map too large");
     const int n_cls = hd->cfg.n_classes;
     UBD_REQUIRE(n_cls == 0 || classes, "ubd_postprocess: classes buffer required when n_classes > 0");
     pp_layout L;
@@ -640,10 +753,15 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     hipLaunchKernelGGL(pp_keep_kernel, dim3(n), dim3(256), 0, st, n, map_h, nroots, roots, area2, L.root_cap, min_area, nkept, kept, stage, ymax, rows, cap, vote, n_cls);
     hipLaunchKernelGGL(pp_extents_kernel, dim3(grid), dim3(256), 0, st, owner, kept, npix, map_h, map_w, L.root_cap, cap, rows, ymax);
     {
-        const long total = (long)n * cap;
-        int bgrid = (int)((total + 63) / 64);
-        if (bgrid > gmax) bgrid = gmax;
-        hipLaunchKernelGGL(pp_boxes_kernel, dim3(bgrid), dim3(64), 0, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+        const size_t lds = (size_t)4 * (6 * map_h + 4) * sizeof(int);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(256), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+        } else {                                       // very tall maps: serial per-object fallback in global memory
+            const long total = (long)n * cap;
+            int bgrid = (int)((total + 63) / 64);
+            if (bgrid > gmax) bgrid = gmax;
+            hipLaunchKernelGGL(pp_boxes_kernel, dim3(bgrid), dim3(64), 0, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+        }
     }
     if (n_cls > 0)
         hipLaunchKernelGGL(pp_vote_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, owner, kept, npix, hw, L.root_cap, cap, vote);
