@@ -108,21 +108,105 @@ __device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const f
 }
 
 // ------------------------------------------------------------------------------------
-// Separable 3x3 conv (+bias+ReLU).  One wave = one tile of 16 consecutive output pixels.
-// lane = (i = lane&15 : pixel, q = lane>>4 : channel group).
+// Separable 3x3 conv (+bias+ReLU), LDS-staged.
+// Block = 4 waves = one output tile of 16 columns x TH rows.  The input patch
+// ((TH-1)*S+3) x (15*S+3) pixels is copied ONCE from global memory into LDS (zero padding and the
+// fused uint8 / mobilenet preprocessing applied on the way), so every input byte crosses L2->CU once
+// per tile instead of once per tap.  Each wave then produces TH/4 row tiles of 16 pixels:
+// lane = (i = lane&15 : pixel, q = lane>>4 : channel group); depthwise 3x3 on the VALU directly in
+// the MFMA A-operand layout, pointwise 1x1 as v_mfma_f32_16x16x4_f32.
+// LDS pixel stride: 26 dwords for 24 channels (104 B keeps 8-byte alignment and makes the
+// ds_read_b64 of 16 neighbouring pixels conflict-free), CIN dwords for 1/3 channels.
 // ------------------------------------------------------------------------------------
+template <int CIN, int STRIDE> struct sep_cfg {
+    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int PH = (TH - 1) * STRIDE + 3;
+    static constexpr int PW = 15 * STRIDE + 3;
+    static constexpr int PS = CIN;                                   // LDS pixel stride in dwords
+    static constexpr int CHUNKS = (CIN == UBD_C) ? PH * PW * 6 : 0;  // 16-byte chunks of the 24-channel patch
+    static constexpr int LDS_FLOATS = (CIN == UBD_C) ? (CHUNKS + 255) / 256 * 256 * 4 : PH * PW * CIN;
+};
+
 template <int CIN, int STRIDE, int IN_U8>
 __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                       const float *__restrict__ frag,  // pwfrag then dwlane
                                                       const float *__restrict__ bias, int n, int H, int W, int OH,
                                                       int OW, int pad_lo, float pre_sub, float pre_div)
 {
+    using C = sep_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;   // channels per lane
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float patch[C::LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const float *pwfrag = frag;
     const float *dwlane = frag + UBD_SEP_FRAG_FLOATS;
 
+    // tile coordinates
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int ox0 = tx * 16, oy0 = ty * C::TH;
+    const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+
+    // ---- stage the input patch
+    if constexpr (CIN == UBD_C) {
+        // LDS-DMA (global_load_lds_dwordx4): each wave instruction drops 64 x 16 B linearly into LDS, no
+        // VGPR round trip, all of a wave's pieces in flight at once.  LDS slot c = pix*6 + sp holds chunk
+        // part = (sp + 3*f) % 6 of patch pixel pix, f = (patch column >> 3) & 1: rotating every other
+        // octet of columns by half a pixel (12 dwords) makes the ds_read_b64 of 16 neighbouring pixels
+        // bank-conflict free at stride 1 (2-way at stride 2).  Out-of-image pixels are fetched from a
+        // clamped address and zeroed afterwards (border tiles only).
+        const char *src = (const char *)xin;
+        constexpr int ROUNDS = (C::CHUNKS + 255) / 256;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int cbase = rd * 256 + wid * 64;                   // wave-uniform first chunk of this piece
+            int c = cbase + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const int pix = c / 6, sp = c - pix * 6;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            int part = sp + 3 * ((pc >> 3) & 1);
+            part = part >= 6 ? part - 6 : part;
+            int gy = iy0 + pr, gx = ix0 + pc;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const char *g = src + ((((size_t)img * H + gy) * W + gx) * UBD_C + part * 4) * sizeof(float);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(patch + cbase * 4), 16, 0, 0);
+        }
+        __syncthreads();                                             // includes the vmcnt(0) drain of the DMA
+        const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
+        if (border) {                                                // block-uniform
+            for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                const int gy = iy0 + pr, gx = ix0 + pc;
+                if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                    f32x4 *z = (f32x4 *)(patch + pix * UBD_C);
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) z[k] = zero;
+                }
+            }
+        }
+    } else {
+        constexpr int ELEMS = C::PH * C::PW * CIN;
+        for (int e = threadIdx.x; e < ELEMS; e += 256) {
+            const int pix = e / CIN, ch = e - pix * CIN;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            const int gy = iy0 + pr, gx = ix0 + pc;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
+                if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
+                else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
+            }
+            patch[e] = v;
+        }
+    }
+
+    // ---- per-lane weights (overlaps with the staging loads)
     float dwk[9][CPL];
     float pwf[CPL][2];
 #pragma unroll
@@ -135,37 +219,28 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
         pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane];
     }
     const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
     const bool ch_ok = (CIN == UBD_C) || (q < CIN);
-    const int cb = (CIN == UBD_C) ? 6 * q : q;
+    __syncthreads();
 
-    const int tiles_x = (OW + 15) >> 4;
-    const int total = n * OH * tiles_x;
-    const int nwaves = gridDim.x * (blockDim.x >> 6);
-    for (int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < total; tile += nwaves) {
-        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int oy = (int)((unsigned)rowid % (unsigned)OH);
-        const int img = (int)((unsigned)rowid / (unsigned)OH);
-        const int x0 = xt * 16;
-        const int ox = x0 + i;
-
+    // ---- compute: wave `wid` owns rows wid, wid+4, ...
+    for (int r = wid; r < C::TH; r += 4) {
+        const int oy = oy0 + r;
+        if (oy >= OH) break;
         float dwv[CPL];
 #pragma unroll
         for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * STRIDE + ky - pad_lo;
-            const bool rok = (iy >= 0) && (iy < H);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * STRIDE + kx - pad_lo;
-                const bool ok = rok && ch_ok && (ix >= 0) && (ix < W) && (ox < OW);
-                const size_t e = (((size_t)img * H + (size_t)(rok ? iy : 0)) * W + (size_t)(ok ? ix : 0)) * CIN + cb;
+                const int pcol = i * STRIDE + kx;
+                int coff = cb;
+                if constexpr (CIN == UBD_C) { coff = cb + 12 * ((pcol >> 3) & 1); coff = coff >= UBD_C ? coff - UBD_C : coff; }
+                const float *p = patch + ((r * STRIDE + ky) * C::PW + pcol) * C::PS + coff;
+                const int t = ky * 3 + kx;
                 if constexpr (CIN == UBD_C) {
-                    const f32x2 *p = (const f32x2 *)((const float *)xin + e);
-                    f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
-                    if (ok) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-                    const int t = ky * 3 + kx;
+                    const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
                     dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]);
                     dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
                     dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]);
@@ -173,22 +248,18 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
                     dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]);
                     dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
                 } else {
-                    float v = 0.f;
-                    if (ok) {
-                        if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[e] - pre_sub) / pre_div;
-                        else v = (((const float *)xin)[e] - pre_sub) / pre_div;
-                    }
-                    dwv[0] = fmaf(v, dwk[ky * 3 + kx][0], dwv[0]);
+                    dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);          // dwk is zero for lanes without a channel
                 }
             }
         }
+        (void)ch_ok;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
         }
-        store_tile_relu(y, ((size_t)img * OH + oy) * OW, x0, OW, lane, acc0, acc1, b0, b1);
+        store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, OW, lane, acc0, acc1, b0, b1);
     }
 }
 
@@ -393,8 +464,9 @@ template <int CIN, int STRIDE>
 static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, const float *frag, const float *bias,
                        int n, int H, int W, int OH, int OW, int pad_lo, float sc, float sh, hipStream_t st)
 {
-    long tiles = (long)n * OH * ((OW + 15) / 16);
-    int grid = ubd_grid_for(tiles, h->num_cus, 4, 8);
+    (void)h;
+    const int th = sep_cfg<CIN, STRIDE>::TH;
+    const int grid = n * ((OH + th - 1) / th) * ((OW + 15) / 16);
     if (in_u8)
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
     else
