@@ -36,6 +36,10 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     h->cfg = *cfg;
     h->k_out = 1 + cfg->n_classes;
     h->num_cus = prop.multiProcessorCount;
+    {
+        const char *e = getenv("UBD_DILCONV");
+        h->use_wino = !(e && strcmp(e, "direct") == 0);
+    }
     // Keras model.get_weights() order
     size_t off = 0;
     int cin = cfg->c_in;

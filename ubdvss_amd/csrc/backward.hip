@@ -22,7 +22,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define UBD_BWD_DGRAD_FLOATS (UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
 #define UBD_BWD_SEP_FLOATS (6 * 2 * 64)
-#define UBD_BWD_FRAG_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
+#define UBD_BWD_DIRECT_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
+#define UBD_BWD_FRAG_FLOATS (UBD_BWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)
 
 // ------------------------------------------------------------------------------------
 // Backward weight fragments:
@@ -40,7 +41,7 @@ struct pack_bwd_args {
 
 __global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restrict__ out, pack_bwd_args a)
 {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < UBD_BWD_FRAG_FLOATS; idx += gridDim.x * blockDim.x) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < UBD_BWD_DIRECT_FLOATS; idx += gridDim.x * blockDim.x) {
         float v = 0.f;
         if (idx < UBD_BWD_DGRAD_FLOATS) {
             int L = idx / UBD_DIL_FRAG_FLOATS, r = idx % UBD_DIL_FRAG_FLOATS;
@@ -548,6 +549,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
     pa.c_in = h->cfg.c_in;
     hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
+    if (h->use_wino) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
 
     const float *a1 = (const float *)(ws + T.fwd.off_a1), *a2 = (const float *)(ws + T.fwd.off_a2);
     const float *acts[7];
@@ -573,7 +575,10 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
         const long nsteps = (long)n * H4 * ((W4 + 3) / 4);
         int gw = ubd_grid_for((nsteps + 31) / 32, h->num_cus, 4, 2);
         hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], bytes);
-        ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
+        if (h->use_wino)
+            ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
+        else
+            ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         cur ^= 1;
     }
     // separable layers

@@ -18,6 +18,7 @@ struct ubd_handle {
     size_t off_head_k, off_head_b;
     size_t n_params;
     int num_cus;
+    int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
 };
 
 static const int UBD_DILATIONS[UBD_NUM_DIL] = {1, 2, 4, 8, 16, 1};
@@ -49,6 +50,9 @@ static inline size_t ubd_align_up(size_t v, size_t a) { return (v + a - 1) / a *
 #define UBD_DIL_FRAG_FLOATS (9 * 6 * 2 * 64)     // per dilated layer
 #define UBD_SEP_FRAG_FLOATS (6 * 2 * 64)         // pointwise fragments per separable layer
 #define UBD_SEP_DW_FLOATS (9 * 6 * 64)           // per-lane depthwise taps per separable layer
+#define UBD_WINO_FRAG_FLOATS (16 * 6 * 64 * 2)   // Winograd-domain weights per dilated layer (wino.hip)
+#define UBD_FWD_DIRECT_FLOATS (3 * (UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS) + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
+#define UBD_FWD_FRAG_FLOATS (UBD_FWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)
 
 struct ubd_fwd_layout {
     size_t off_wfrag;     // packed weights
@@ -68,3 +72,6 @@ int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
                   char *ws, hipStream_t st);
 extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
+void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
+void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
+                             const float *in, float *out, int n, int H4, int W4, hipStream_t st);

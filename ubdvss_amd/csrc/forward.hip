@@ -426,7 +426,7 @@ static size_t act_bytes(const ubd_handle *, long n, long hh, long ww) { return (
 
 void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L)
 {
-    const size_t wf = (3 * (UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS) + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS) * sizeof(float);
+    const size_t wf = (size_t)UBD_FWD_FRAG_FLOATS * sizeof(float);
     size_t off = 0;
     L->off_wfrag = off; off += ubd_align_up(wf, 256);
     const size_t a = ubd_align_up(act_bytes(h, n, H / 2, W / 2), 256);
@@ -480,6 +480,7 @@ static void launch_pack(const ubd_handle *h, const float *params, float *wfrag, 
     for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
     pa.c_in = h->cfg.c_in;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, st, params, wfrag, pa);
+    if (h->use_wino) ubd_launch_pack_wino(h, params, wfrag + UBD_FWD_DIRECT_FLOATS, 0, st);
 }
 
 // frag: this layer's 6912 packed floats; aux: bias (epi 0) or mask source activation (epi 1)
@@ -499,6 +500,11 @@ void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const f
 static void launch_dil(const ubd_handle *h, const float *params, const float *wfrag, int k, const float *in, float *out,
                        int n, int H4, int W4, hipStream_t st)
 {
+    if (h->use_wino) {
+        ubd_launch_dilconv_wino(h, 0, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k],
+                                UBD_DILATIONS[k], in, out, n, H4, W4, st);
+        return;
+    }
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *dfrag = wfrag + 3 * per_sep;
     ubd_launch_dilconv(h, 0, dfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, params + h->off_dil_b[k], UBD_DILATIONS[k], in, out, n, H4, W4, st);
