@@ -108,7 +108,7 @@ def main():
     from ubdvss_amd import NetConfig, Model, ModelRunner, Trainer, Adam, synthetic, _lib
     cfg = NetConfig(grey=False)
     model = Model(cfg, seed=1)                               # glorot-uniform random init, zero biases
-    runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
+    runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024, pipelined=True)
 
     # synthetic batch resident in HBM: stripe-textured rectangles on noise
     labels = synthetic.rectangle_maps(3 + rank, BATCH, SIDE // 4, SIDE // 4)

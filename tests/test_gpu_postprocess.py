@@ -154,3 +154,27 @@ def test_large_map_1024_input_shape():
     _compare(model, lg, 0)
     a = _run(model, lg)[1]; b = _run(model, lg)[1]
     assert all(np.array_equal(x[0], y[0]) for x, y in zip(a, b))
+
+
+def test_pipelined_runner_matches_serial():
+    """Two-stream pipeline (postprocess of batch k overlapping forward of batch k+1) gives the same
+    results as the serial path, batch after batch."""
+    cfg = NetConfig(grey=False)
+    model = Model(cfg, seed=5)
+    w = onet.init_weights(41, 3, 0, bias_scale=0.3)
+    model.set_weights(w)
+    serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
+    batches = []
+    for k in range(5):
+        labels = synthetic.rectangle_maps(70 + k, 4, 32, 32)
+        batches.append(torch.from_numpy(synthetic.textured_images(80 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda())
+    ref = [[t.clone() for t in serial.predict_on_device(model, b) if t is not None] for b in batches]
+    got = []
+    for b in batches:
+        out = piped.predict_on_device(model, b)
+        got.append(out)
+    torch.cuda.synchronize()
+    # slots are double-buffered: only the last two batches are still resident
+    for k in (3, 4):
+        for a, r in zip([t for t in got[k] if t is not None], ref[k]):
+            assert torch.equal(a, r)

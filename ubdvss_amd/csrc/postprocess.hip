@@ -549,11 +549,8 @@ __global__ __launch_bounds__(64) void pp_boxes_kernel(int n, int h, int w, const
 }
 
 // Wave-cooperative variant (default): one wave per kept object, row extents and hull in LDS.
-// A row point (x_i, y0+i) is a vertex of the left (min-x) chain iff the largest incoming slope
-// dx/dy over all earlier rows is strictly smaller than the smallest outgoing slope over all later
-// rows (exact integer cross-multiplication); mirrored for the right chain.  Every lane tests its own
-// rows against all others (O(rows^2) cheap integer work, LDS broadcast reads), vertices are
-// compacted with ballots; lane 0 then orders the polygon like cv::convexHull and runs the calipers.
+// The left / right hull chains are found by wave-parallel gift wrapping over the row extents (exact
+// integer slope comparisons); lane 0 then orders the polygon like cv::convexHull and runs the calipers.
 __device__ __forceinline__ void hull_finish(ipt *P, int nl, int nr, int &n_out)
 {
     // P = lc[0..nl-1] (top -> bottom) followed by rc[0..nr-1] (top -> bottom): reverse rc
@@ -612,36 +609,40 @@ __global__ __launch_bounds__(256) void pp_boxes_wave_kernel(int n, int h, int w,
             int cnt[2] = {0, 0};
 #pragma unroll
             for (int side = 0; side < 2; ++side) {            // 0: left chain (min x), 1: right chain (max x)
+                // Gift wrapping down the chain: from vertex row c the next vertex is the later row with the
+                // extreme slope dx/dy (min for the left chain, max for the right one; farthest on ties, which
+                // drops collinear points).  Candidates are spread over the 64 lanes, fractions compared
+                // exactly by int32 cross-multiplication (|dx|, dy < 2^15), then a xor-butterfly reduction.
                 ipt *out = pts + (side ? cnt[0] : 0);
-                int nout = 0;
-                for (int base = 0; base < nrows; base += 64) {
-                    const int i = base + lane;
-                    bool isv = false;
-                    int xi = 0;
-                    if (i < nrows) {
-                        xi = rws[2 * i + side];
-                        if (i == 0 || i == nrows - 1) {
-                            isv = true;
-                        } else {
-                            // extreme incoming slope (xi - xa)/(i - a), a < i ; extreme outgoing (xb - xi)/(b - i), b > i
-                            int in_n = xi - rws[2 * (i - 1) + side], in_d = 1;        // |n| < 2^15, d < 2^15: products fit int32
-                            for (int a = i - 2; a >= 0; --a) {
-                                const int nn = xi - rws[2 * a + side], dd = i - a;
-                                const bool better = side ? (nn * in_d < in_n * dd) : (nn * in_d > in_n * dd);
-                                if (better) { in_n = nn; in_d = dd; }
-                            }
-                            int out_n = rws[2 * (i + 1) + side] - xi, out_d = 1;
-                            for (int b = i + 2; b < nrows; ++b) {
-                                const int nn = rws[2 * b + side] - xi, dd = b - i;
-                                const bool better = side ? (nn * out_d > out_n * dd) : (nn * out_d < out_n * dd);
-                                if (better) { out_n = nn; out_d = dd; }
-                            }
-                            isv = side ? (in_n * out_d > out_n * in_d) : (in_n * out_d < out_n * in_d);
+                int nout = 0, c = 0;
+                for (;;) {
+                    const int xc = rws[2 * c + side];
+                    if (lane == 0) out[nout] = (ipt){xc, y0 + c};
+                    ++nout;
+                    if (c >= nrows - 1) break;
+                    int bn = 0, bd = 0, br = -1;
+                    for (int r = c + 1 + lane; r < nrows; r += 64) {
+                        const int nn = rws[2 * r + side] - xc, dd = r - c;
+                        bool better = true;
+                        if (bd != 0) {
+                            const int lhs = nn * bd, rhs = bn * dd;
+                            better = side ? (lhs >= rhs) : (lhs <= rhs);      // later row wins ties
                         }
+                        if (better) { bn = nn; bd = dd; br = r; }
                     }
-                    const unsigned long long bal = __ballot(isv);
-                    if (isv) out[nout + __popcll(bal & ((1ull << lane) - 1ull))] = (ipt){xi, y0 + i};
-                    nout += __popcll(bal);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const int on = __shfl_xor(bn, o, 64), od = __shfl_xor(bd, o, 64), orr = __shfl_xor(br, o, 64);
+                        bool take;
+                        if (od == 0) take = false;
+                        else if (bd == 0) take = true;
+                        else {
+                            const int lhs = on * bd, rhs = bn * od;
+                            take = lhs == rhs ? (orr > br) : (side ? (lhs > rhs) : (lhs < rhs));
+                        }
+                        if (take) { bn = on; bd = od; br = orr; }
+                    }
+                    c = br;
                 }
                 cnt[side] = nout;
             }

@@ -13,12 +13,24 @@ from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 
 class ModelRunner:
-    def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256):
-        """model_runner.py:31-38: pixel_probability > pixel_threshold is positive."""
+    def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256, pipelined=False):
+        """model_runner.py:31-38: pixel_probability > pixel_threshold is positive.
+        pipelined=True: the postprocess of batch k runs on a second HIP stream and overlaps the forward pass
+        of batch k+1 (double-buffered logits / results); results of a call are complete once
+        ``self.last_event`` has been waited for (``synchronize()``)."""
         self._net_config = net_config
         eps = 1e-9
         self._logit_threshold = - np.log(1 / np.clip(pixel_threshold, eps, 1 - eps) - 1)
         self._cap = max_objects_per_image
+        self._pipelined = pipelined
+        self._side = None
+        self._slots = {}
+        self._step = 0
+        self.last_event = None
+
+    def synchronize(self):
+        if self.last_event is not None:
+            self.last_event.synchronize()
 
     @property
     def logit_threshold(self):
@@ -27,10 +39,36 @@ class ModelRunner:
     def predict_on_device(self, model, images):
         """images: device tensor (N,H,W,C).  Returns device tensors
         (logits, binary_map (N,h,w) int32, quads (N,cap,8), classes or None, counts (N))."""
-        logits = model.predict_on_device(images)
-        bmap, quads, classes, counts = model.postprocess_on_device(
-            logits, self._logit_threshold, self._net_config.get_scale(),
-            self._net_config.get_min_pixels_for_detection(), cap=self._cap)
+        scale = self._net_config.get_scale()
+        min_area = self._net_config.get_min_pixels_for_detection()
+        if not self._pipelined:
+            logits = model.predict_on_device(images)
+            bmap, quads, classes, counts = model.postprocess_on_device(logits, self._logit_threshold, scale, min_area, cap=self._cap)
+            return logits, bmap, quads, classes, counts
+        # ---- two-stream pipeline: forward on the caller's stream, postprocess on the side stream
+        n, hh, ww, _ = images.shape
+        key = (self._step & 1, n, hh, ww, id(model))
+        self._step += 1
+        main = torch.cuda.current_stream(model.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=model.device)
+        slot = self._slots.get(key)
+        if slot is None:
+            slot = {"logits": torch.empty((n, hh // 4, ww // 4, model.k_out), dtype=torch.float32, device=model.device),
+                    "out": model.alloc_postprocess_outputs(n, hh // 4, ww // 4, self._cap), "done": None}
+            self._slots[key] = slot
+        if slot["done"] is not None:
+            main.wait_event(slot["done"])               # the previous postprocess of this slot still reads its logits
+        logits = model.predict_on_device(images, out=slot["logits"])
+        fwd_done = torch.cuda.Event()
+        fwd_done.record(main)
+        self._side.wait_event(fwd_done)
+        with torch.cuda.stream(self._side):
+            bmap, quads, classes, counts = model.postprocess_on_device(logits, self._logit_threshold, scale, min_area,
+                                                                       cap=self._cap, outputs=slot["out"])
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(self._side)
+        self.last_event = slot["done"]
         return logits, bmap, quads, classes, counts
 
     def predict(self, model, images, rescale=False, meta_infos=None):
@@ -44,6 +82,7 @@ class ModelRunner:
         if xt.dtype == torch.uint8:
             xt = xt.float()                 # numpy images arrive already preprocessed, as in the reference
         logits, bmap, quads, classes, counts = self.predict_on_device(model, xt)
+        self.synchronize()
         counts_h = counts.cpu().numpy()
         if (counts_h > self._cap).any():
             raise RuntimeError(f"more than max_objects_per_image={self._cap} objects in an image "

@@ -288,18 +288,26 @@ class Model:
         return self.predict_on_device(xt, preprocessing=pre).cpu().numpy()
 
     # ---------------------------------------------------------------- postprocess
-    def postprocess_on_device(self, logits, logit_threshold, scale, min_area, cap=256, want_map=True):
-        """logits: fp32 (N,h,w,K) device tensor.  Returns (binary_map int32 (N,h,w) or None,
-        quads int32 (N,cap,8), classes int32 (N,cap) or None, counts int32 (N))."""
-        logits = logits.contiguous()
-        n, mh, mw, k = logits.shape
-        if k != self.k_out:
-            raise ValueError(f"logits have {k} channels, model has {self.k_out}")
+    def alloc_postprocess_outputs(self, n, mh, mw, cap, want_map=True):
         dev = self.device
         bmap = torch.empty((n, mh, mw), dtype=torch.int32, device=dev) if want_map else None
         quads = torch.zeros((n, cap, 8), dtype=torch.int32, device=dev)
         classes = torch.zeros((n, cap), dtype=torch.int32, device=dev) if self.n_classes > 0 else None
         counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        return bmap, quads, classes, counts
+
+    def postprocess_on_device(self, logits, logit_threshold, scale, min_area, cap=256, want_map=True, outputs=None):
+        """logits: fp32 (N,h,w,K) device tensor.  Returns (binary_map int32 (N,h,w) or None,
+        quads int32 (N,cap,8), classes int32 (N,cap) or None, counts int32 (N)).  Runs on the current
+        torch stream; `outputs` may hold preallocated result tensors (alloc_postprocess_outputs)."""
+        logits = logits.contiguous()
+        n, mh, mw, k = logits.shape
+        if k != self.k_out:
+            raise ValueError(f"logits have {k} channels, model has {self.k_out}")
+        dev = self.device
+        if outputs is None:
+            outputs = self.alloc_postprocess_outputs(n, mh, mw, cap, want_map)
+        bmap, quads, classes, counts = outputs
         nbytes = self._lib.ubd_postprocess_workspace_bytes(self._h, n, mh, mw, cap)
         ws = self._workspace("_pp_ws", nbytes)
         with torch.cuda.device(dev):
