@@ -204,7 +204,7 @@ def main():
         t_layer = float(np.mean(layer_ms)) * 1e-3
         flop_layer = 2.0 * 216 * 24 * n * mh * mw
         bytes_layer = 2.0 * n * mh * mw * 24 * 4
-        roofline = {"bound": "mfma", "kernel": "dilconv_f32_kernel", "achieved": round(flop_layer / t_layer / 1e12, 3),
+        roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
                     "traffic": None, "avg_launch_us": round(t_layer * 1e6, 2),
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],

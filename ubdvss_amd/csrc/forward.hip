@@ -79,15 +79,18 @@ __global__ void pack_weights_kernel(const float *__restrict__ params, float *__r
 __device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t row_base_elems, int x0, int ow,
                                                 int lane, f32x4 acc0, f32x4 acc1, float b0, float b1)
 {
+    // Branch-free: buffer stores whose per-lane offset is pushed out of range for lanes that must not write.
     const int co = lane & 15, q = lane >> 4;
+    float *rowp = y + (row_base_elems + (size_t)x0) * UBD_C;                 // wave-uniform tile base
+    const int npx = ow - x0 < 16 ? ow - x0 : 16;                              // valid pixels in this tile
+    const unsigned bytes = (unsigned)npx * UBD_C * 4u;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, (int)bytes, 0x00020000);
+    const unsigned base = (unsigned)(4 * q) * (UBD_C * 4u) + (unsigned)co * 4u;
+    const unsigned base1 = co < 8 ? base + 64u : 0x40000000u;                // channels 16..23 only from lanes co < 8
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        int px = x0 + 4 * q + r;
-        if (px < ow) {
-            float *p = y + (row_base_elems + (size_t)px) * UBD_C;
-            p[co] = fmaxf(acc0[r] + b0, 0.f);
-            if (co < 8) p[16 + co] = fmaxf(acc1[r] + b1, 0.f);
-        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc0[r] + b0, 0.f)), rs, (int)(base + r * 96u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc1[r] + b1, 0.f)), rs, (int)(base1 + r * 96u), 0, 0);
     }
 }
 
@@ -124,9 +127,14 @@ template <int CIN, int STRIDE> struct sep_cfg {
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int PS = CIN;                                   // LDS pixel stride in dwords
     static constexpr int CHUNKS = (CIN == UBD_C) ? PH * PW * 6 : 0;  // 16-byte chunks of the 24-channel patch
-    static constexpr int LDS_FLOATS = (CIN == UBD_C) ? (CHUNKS + 255) / 256 * 256 * 4 : PH * PW * CIN;
+    static constexpr int ELEMS = PH * PW * CIN;
+    static constexpr int BUF_FLOATS = (CIN == UBD_C) ? (CHUNKS + 255) / 256 * 256 * 4 : (ELEMS + 3) / 4 * 4;
+    static constexpr int STAGE_REGS = (CIN == UBD_C) ? 1 : (ELEMS + 255) / 256;   // per-thread prefetch registers (CIN < 24)
 };
 
+// Persistent: each block walks tiles blockIdx.x, +gridDim.x, ...; the patch of tile t+1 is fetched while
+// tile t is computed (24 channels: LDS-DMA into the other half of a double buffer; 1/3 channels: loads held
+// in registers across the compute phase, written to LDS afterwards).  Per-lane weights are loaded once.
 template <int CIN, int STRIDE, int IN_U8>
 __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                       const float *__restrict__ frag,  // pwfrag then dwlane
@@ -135,31 +143,71 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
 {
     using C = sep_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;   // channels per lane
-    __shared__ __attribute__((aligned(16))) float patch[C::LDS_FLOATS];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int NBUF = (CIN == UBD_C) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float patch_mem[NBUF * C::BUF_FLOATS];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform in an SGPR
     const int i = lane & 15, q = lane >> 4;
     const float *pwfrag = frag;
     const float *dwlane = frag + UBD_SEP_FRAG_FLOATS;
 
-    // tile coordinates
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_x; bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int img = bid / tiles_y;
-    const int ox0 = tx * 16, oy0 = ty * C::TH;
-    const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+    const int total = n * tiles_y * tiles_x;
 
-    // ---- stage the input patch
+    // per-lane weights
+    float dwk[9][CPL];
+    float pwf[CPL][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) {
+        pwf[s][0] = pwfrag[(s * 2 + 0) * 64 + lane];
+        pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane];
+    }
+    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
+
+    auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
+        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int r = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)r % (unsigned)tiles_y);
+        img = (int)((unsigned)r / (unsigned)tiles_y);
+        oy0 = ty * C::TH; ox0 = tx * 16;
+    };
+    // 24 channels: LDS-DMA (global_load_lds_dwordx4): 64 x 16 B per wave instruction land linearly in LDS, no
+    // VGPR round trip.  LDS slot c = pix*6 + sp holds chunk part = (sp + 3*f) % 6 of patch pixel pix,
+    // f = (patch column >> 3) & 1: rotating every other octet of columns by half a pixel (12 dwords) makes the
+    // ds_read_b64 of 16 neighbouring pixels bank-conflict free at stride 1 (2-way at stride 2).  Out-of-image
+    // pixels are fetched from a clamped address and zeroed afterwards (border tiles only).
+    constexpr int ROUNDS = (CIN == UBD_C) ? (C::CHUNKS + 255) / 256 : 1;
+    int dma_rel[ROUNDS];           // interior tiles: byte offset of this lane's chunk relative to the patch origin
     if constexpr (CIN == UBD_C) {
-        // LDS-DMA (global_load_lds_dwordx4): each wave instruction drops 64 x 16 B linearly into LDS, no
-        // VGPR round trip, all of a wave's pieces in flight at once.  LDS slot c = pix*6 + sp holds chunk
-        // part = (sp + 3*f) % 6 of patch pixel pix, f = (patch column >> 3) & 1: rotating every other
-        // octet of columns by half a pixel (12 dwords) makes the ds_read_b64 of 16 neighbouring pixels
-        // bank-conflict free at stride 1 (2-way at stride 2).  Out-of-image pixels are fetched from a
-        // clamped address and zeroed afterwards (border tiles only).
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            int c = rd * 256 + wid * 64 + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const int pix = c / 6, sp = c - pix * 6;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            int part = sp + 3 * ((pc >> 3) & 1);
+            part = part >= 6 ? part - 6 : part;
+            dma_rel[rd] = ((pr * W + pc) * UBD_C + part * 4) * 4;
+        }
+    }
+    auto dma_tile = [&](int tile, float *buf) {
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
         const char *src = (const char *)xin;
-        constexpr int ROUNDS = (C::CHUNKS + 255) / 256;
+        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::PH <= H) && (ix0 + C::PW <= W);   // block-uniform
+        if (interior) {
+            const char *origin = src + (((size_t)img * H + iy0) * W + ix0) * (UBD_C * sizeof(float));
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(origin + dma_rel[rd]),
+                                                 (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 4), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int cbase = rd * 256 + wid * 64;                   // wave-uniform first chunk of this piece
@@ -174,92 +222,134 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
             gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
             const char *g = src + ((((size_t)img * H + gy) * W + gx) * UBD_C + part * 4) * sizeof(float);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(patch + cbase * 4), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, 0, 0);
         }
-        __syncthreads();                                             // includes the vmcnt(0) drain of the DMA
-        const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
-        if (border) {                                                // block-uniform
-            for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                const int gy = iy0 + pr, gx = ix0 + pc;
-                if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                    f32x4 *z = (f32x4 *)(patch + pix * UBD_C);
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    };
+    // 1 / 3 channels: plain loads into registers (converted / preprocessed), stored to LDS later
+    int ld_rel[C::STAGE_REGS];     // interior tiles: element offset of this thread's patch elements
+    if constexpr (CIN != UBD_C) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) z[k] = zero;
-                }
-            }
-        }
-    } else {
-        constexpr int ELEMS = C::PH * C::PW * CIN;
-        for (int e = threadIdx.x; e < ELEMS; e += 256) {
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            int e = k * 256 + threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
             const int pix = e / CIN, ch = e - pix * CIN;
             const int pr = pix / C::PW, pc = pix - pr * C::PW;
-            const int gy = iy0 + pr, gx = ix0 + pc;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
-                if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
-                else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
-            }
-            patch[e] = v;
+            ld_rel[k] = (pr * W + pc) * CIN + ch;
         }
     }
-
-    // ---- per-lane weights (overlaps with the staging loads)
-    float dwk[9][CPL];
-    float pwf[CPL][2];
+    auto load_regs = [&](int tile, float (&st)[C::STAGE_REGS]) {
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::PH <= H) && (ix0 + C::PW <= W);   // block-uniform
+        if (interior) {
+            const size_t origin = (((size_t)img * H + iy0) * W + ix0) * CIN;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+            for (int k = 0; k < C::STAGE_REGS; ++k) {
+                if constexpr (IN_U8) st[k] = ((float)((const unsigned char *)xin)[origin + ld_rel[k]] - pre_sub) / pre_div;
+                else st[k] = (((const float *)xin)[origin + ld_rel[k]] - pre_sub) / pre_div;
+            }
+            return;
+        }
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
-#pragma unroll
-    for (int s = 0; s < CPL; ++s) {
-        pwf[s][0] = pwfrag[(s * 2 + 0) * 64 + lane];
-        pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane];
-    }
-    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
-    const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
-    const bool ch_ok = (CIN == UBD_C) || (q < CIN);
-    __syncthreads();
-
-    // ---- compute: wave `wid` owns rows wid, wid+4, ...
-    for (int r = wid; r < C::TH; r += 4) {
-        const int oy = oy0 + r;
-        if (oy >= OH) break;
-        float dwv[CPL];
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int pcol = i * STRIDE + kx;
-                int coff = cb;
-                if constexpr (CIN == UBD_C) { coff = cb + 12 * ((pcol >> 3) & 1); coff = coff >= UBD_C ? coff - UBD_C : coff; }
-                const float *p = patch + ((r * STRIDE + ky) * C::PW + pcol) * C::PS + coff;
-                const int t = ky * 3 + kx;
-                if constexpr (CIN == UBD_C) {
-                    const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
-                    dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]);
-                    dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
-                    dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]);
-                    dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
-                    dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]);
-                    dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
-                } else {
-                    dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);          // dwk is zero for lanes without a channel
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            const int e = k * 256 + threadIdx.x;
+            float v = 0.f;
+            if (e < C::ELEMS) {
+                const int pix = e / CIN, ch = e - pix * CIN;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                const int gy = iy0 + pr, gx = ix0 + pc;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
+                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
+                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
                 }
             }
+            st[k] = v;
         }
-        (void)ch_ok;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    float stage[C::STAGE_REGS];
+    if constexpr (CIN == UBD_C) dma_tile(tile, patch_mem);
+    else load_regs(tile, stage);
+
+    for (int it = 0;; ++it) {
+        float *patch = patch_mem + ((CIN == UBD_C) ? (it & 1) * C::BUF_FLOATS : 0);
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int nxt = tile + gridDim.x;
+        const bool has_next = nxt < total;                           // block-uniform
+        if constexpr (CIN == UBD_C) {
+            __syncthreads();                 // DMA of this tile landed (vmcnt(0)) + everyone left the other buffer
+            if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_FLOATS);
+            const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+            const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
+            if (border) {                                            // block-uniform
+                for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
+                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                    const int gy = iy0 + pr, gx = ix0 + pc;
+                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                        f32x4 *z = (f32x4 *)(patch + pix * UBD_C);
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
+                        for (int k = 0; k < 6; ++k) z[k] = zero;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): zeros written
+                __builtin_amdgcn_s_barrier();                        // raw barrier: must not drain the DMA in flight
+            }
+        } else {
+            __syncthreads();                                         // previous tile's readers are done
+#pragma unroll
+            for (int k = 0; k < C::STAGE_REGS; ++k) {
+                const int e = k * 256 + threadIdx.x;
+                if (e < C::ELEMS) patch[e] = stage[k];
+            }
+            __syncthreads();
+            if (has_next) load_regs(nxt, stage);                     // in flight during the compute phase
         }
-        store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, OW, lane, acc0, acc1, b0, b1);
+
+        // ---- compute: wave `wid` owns rows wid, wid+4, ...
+        for (int r = wid; r < C::TH; r += 4) {
+            const int oy = oy0 + r;
+            if (oy >= OH) break;
+            float dwv[CPL];
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int pcol = i * STRIDE + kx;
+                    int coff = cb;
+                    if constexpr (CIN == UBD_C) { coff = cb + 12 * ((pcol >> 3) & 1); coff = coff >= UBD_C ? coff - UBD_C : coff; }
+                    const float *p = patch + ((r * STRIDE + ky) * C::PW + pcol) * C::PS + coff;
+                    const int t = ky * 3 + kx;
+                    if constexpr (CIN == UBD_C) {
+                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
+                        dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]);
+                        dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
+                        dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]);
+                        dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
+                        dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]);
+                        dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
+                    } else {
+                        dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);      // dwk is zero for lanes without a channel
+                    }
+                }
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
+            }
+            store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, OW, lane, acc0, acc1, b0, b1);
+        }
+        if (!has_next) break;
+        tile = nxt;
     }
 }
 
@@ -330,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void dilconv_f32_kernel(const float *__rest
     const int t_begin = xcd * chunk;
     const int t_end = (t_begin + chunk < total) ? t_begin + chunk : total;
     const int stride = nblk_x * 4;
-    int tile = t_begin + (int)(blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);
+    int tile = t_begin + (int)(blockIdx.x >> 3) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile >= t_end) return;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
@@ -464,9 +554,11 @@ template <int CIN, int STRIDE>
 static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, const float *frag, const float *bias,
                        int n, int H, int W, int OH, int OW, int pad_lo, float sc, float sh, hipStream_t st)
 {
-    (void)h;
     const int th = sep_cfg<CIN, STRIDE>::TH;
-    const int grid = n * ((OH + th - 1) / th) * ((OW + 15) / 16);
+    const int tiles = n * ((OH + th - 1) / th) * ((OW + 15) / 16);
+    const int per_cu = (CIN == UBD_C) ? ((sep_cfg<CIN, STRIDE>::BUF_FLOATS * 8 > 80 * 1024) ? 1 : 2) : 4;   // LDS-limited residency
+    int grid = h->num_cus * per_cu;
+    if (grid > tiles) grid = tiles;
     if (in_u8)
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
     else
