@@ -154,82 +154,135 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------ dilated wgrad
-__global__ __launch_bounds__(256, 1) void dil_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gz,
+// dW[t][ci][co] = sum_p X[p + off_t][ci] G[p][co],  db[co] = sum_p G[p][co].
+// GEMM view: M = 216 (+ one all-ones row -> bias gradient, padded to 14 tiles of 16), N = 24 (2 tiles), K = pixels.
+// A convolution with dilation d is dense on each of the d x d phase sub-grids, so the work is cut into items
+// (image, phase (ry, rx), 8 x 16 tile of the sub-grid): the block copies the X tile with a one-sub-pixel halo
+// (10 x 18 pixels spaced d in the image) and the G tile into LDS by LDS-DMA (per-lane gather addresses,
+// double-buffered against the MFMA phase), and all 9 taps x 24 channels of the A operand are then read from LDS
+// (ds_read_b32) instead of 14 global gathers per k-step.  Each wave owns every 4th k-step (4 consecutive
+// sub-pixels), accumulates the whole 224 x 32 result in 112 VGPRs across all its items, and the block reduces
+// through LDS to one fp32 atomic per output at the very end.
+#define WG_TH 8
+#define WG_TW 16
+#define WG_XW (WG_TW + 2)
+#define WG_XPIX ((WG_TH + 2) * WG_XW)          // 180
+#define WG_GPIX (WG_TH * WG_TW)                // 128
+#define WG_CHUNKS ((WG_XPIX + WG_GPIX) * 6)    // 1848 16-byte chunks
+#define WG_ROUNDS ((WG_CHUNKS + 255) / 256)    // 8
+#define WG_BUF_FLOATS (WG_ROUNDS * 256 * 4)    // 8192 floats = 32 KiB
+
+__global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gz,
                                                            float *__restrict__ g_k, float *__restrict__ g_b, int n, int h,
-                                                           int w, int d, unsigned bytes)
+                                                           int w, int d)
 {
-    __shared__ float red[224 * 32];
-    const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4, wid = threadIdx.x >> 6;
-    // per-lane row description of the 14 M-tiles
-    int roff[14];      // element offset of (tap, ci) relative to the pixel, or marker
-    int rdy[14], rdx[14];
+    __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF_FLOATS];     // 64 KiB: two tile buffers / final reduction
+    const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    // A-operand rows of the 14 M-tiles: dword offset of (tap, ci) relative to the X-tile pixel of the output position
+    int aoff[14];
 #pragma unroll
     for (int mt = 0; mt < 14; ++mt) {
         const int rho = 16 * mt + m;
         const int t = rho / UBD_C, ci = rho % UBD_C;
-        rdy[mt] = (t / 3 - 1) * d;
-        rdx[mt] = (t % 3 - 1) * d;
-        roff[mt] = (rdy[mt] * w + rdx[mt]) * UBD_C + ci;
+        aoff[mt] = ((t / 3) * WG_XW + (t % 3)) * UBD_C + ci;          // rows >= 216 are never read (see below)
     }
-    // rows 0..207 (tiles 0..12) are always real (tap, ci) rows; tile 13 holds rows 208..215 (m < 8),
-    // the all-ones row 216 (m == 8, gives the bias gradient) and 7 padding rows.
     const bool row13_real = m < 8, row13_ones = m == 8;
-    f32x4 acc[14][2] = {};
-    const int w4 = (w + 3) >> 2;
-    const int nsteps = n * h * w4;
-    const int nwaves = gridDim.x * 4;
-    const int wave = blockIdx.x * 4 + wid;
-    const int per = (nsteps + nwaves - 1) / nwaves;
-    const int s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gz, 0, (int)bytes, 0x00020000);
-    const unsigned oob = bytes;
 
-    auto load = [&](int s, float (&a)[14], float &b0, float &b1) {
-        const int row = (int)((unsigned)s / (unsigned)w4);                 // = img*h + y
-        const int xs = (int)((unsigned)s % (unsigned)w4) * 4;
-        const int y = (int)((unsigned)row % (unsigned)h);
-        const int px = xs + k;
-        const bool pok = px < w;
-        const unsigned pbase = (unsigned)(row * w + px) * (unsigned)UBD_C;     // element index of the pixel
-        b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(pok ? (pbase + m) * 4u : oob), 0, 0));
-        b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((pok && m < 8) ? (pbase + 16 + m) * 4u : oob), 0, 0));
+    // work items
+    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;              // largest sub-grid
+    const int tiles_y = (sh + WG_TH - 1) / WG_TH, tiles_x = (sw + WG_TW - 1) / WG_TW;
+    const int items = n * d * d * tiles_y * tiles_x;
+
+    struct item_t { int img, ry, rx, sy0, sx0; };
+    auto decode = [&](int it) {
+        item_t r;
+        const int tx = (int)((unsigned)it % (unsigned)tiles_x); it = (int)((unsigned)it / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)it % (unsigned)tiles_y); it = (int)((unsigned)it / (unsigned)tiles_y);
+        r.rx = (int)((unsigned)it % (unsigned)d); it = (int)((unsigned)it / (unsigned)d);
+        r.ry = (int)((unsigned)it % (unsigned)d);
+        r.img = (int)((unsigned)it / (unsigned)d);
+        r.sy0 = ty * WG_TH; r.sx0 = tx * WG_TW;
+        return r;
+    };
+    // chunk c of the combined tile: c < XPIX*6 -> X pixel (with halo), else G pixel; returns image coords
+    auto chunk_src = [&](const item_t &I, int c, bool &is_x, int &gy, int &gx, int &part) {
+        c = c < WG_CHUNKS ? c : WG_CHUNKS - 1;
+        const int pix = c / 6;
+        part = c - pix * 6;
+        is_x = pix < WG_XPIX;
+        int sy, sx;
+        if (is_x) { sy = pix / WG_XW - 1; sx = pix % WG_XW - 1; }
+        else { const int gp = pix - WG_XPIX; sy = gp / WG_TW; sx = gp % WG_TW; }
+        gy = I.ry + (I.sy0 + sy) * d;
+        gx = I.rx + (I.sx0 + sx) * d;
+    };
+    auto dma_item = [&](int it, float *buf) {
+        const item_t I = decode(it);
 #pragma unroll
-        for (int mt = 0; mt < 14; ++mt) {
-            const int iy = y + rdy[mt], ix = px + rdx[mt];
-            const bool real = (mt < 13) || row13_real;
-            const bool ok = real && pok && iy >= 0 && iy < h && ix >= 0 && ix < w;
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(ok ? (unsigned)((int)pbase + roff[mt]) * 4u : oob), 0, 0));
-            a[mt] = (mt == 13 && row13_ones) ? 1.f : v;
+        for (int rd = 0; rd < WG_ROUNDS; ++rd) {
+            const int cbase = rd * 256 + wid * 64;
+            bool is_x; int gy, gx, part;
+            chunk_src(I, cbase + lane, is_x, gy, gx, part);
+            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                 // clamped; out-of-image pixels are zeroed later
+            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+            const float *src = (is_x ? x : gz) + (((size_t)I.img * h + gy) * w + gx) * UBD_C + part * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, 0, 0);
         }
     };
-    auto fma_all = [&](const float (&a)[14], float b0, float b1) {
+
+    f32x4 acc[14][2] = {};
+    int it = blockIdx.x;
+    if (it < items) dma_item(it, smem);
+    for (int iter = 0; it < items; ++iter, it += gridDim.x) {
+        float *buf = smem + (iter & 1) * WG_BUF_FLOATS;
+        const item_t I = decode(it);
+        __syncthreads();                              // this item's DMA landed; everyone left the other buffer
+        if (it + (int)gridDim.x < items) dma_item(it + gridDim.x, smem + ((iter + 1) & 1) * WG_BUF_FLOATS);
+        // zero the pixels that lie outside the image (halo / ragged sub-grid edge)
+        const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
+                            (I.ry + (I.sy0 + WG_TH) * d >= h) || (I.rx + (I.sx0 + WG_TW) * d >= w);   // block-uniform
+        if (ragged) {
+            for (int pix = threadIdx.x; pix < WG_XPIX + WG_GPIX; pix += 256) {
+                bool is_x; int gy, gx, part;
+                chunk_src(I, pix * 6, is_x, gy, gx, part);
+                if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
+                    f32x4 *z = (f32x4 *)(buf + pix * UBD_C);
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 14; ++mt) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+                    for (int q6 = 0; q6 < 6; ++q6) z[q6] = zero;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();             // raw barrier: the next item's DMA stays in flight
         }
-    };
-    if (s0 < s1) {
-        // unconditional (clamped) prefetch, two steps ahead: see the note in forward.hip dilconv
-        float A0[14], A1[14], A2[14], p0, p1, q0, q1, r0, r1;
-        const int sl = s1 - 1;
-        load(s0, A0, p0, p1);
-        load(s0 + 1 < sl ? s0 + 1 : sl, A1, q0, q1);
-        int s = s0;
-        for (;;) {
-            load(s + 2 < sl ? s + 2 : sl, A2, r0, r1);
-            fma_all(A0, p0, p1);
-            if (++s >= s1) break;
-            load(s + 2 < sl ? s + 2 : sl, A0, p0, p1);
-            fma_all(A1, q0, q1);
-            if (++s >= s1) break;
-            load(s + 2 < sl ? s + 2 : sl, A1, q0, q1);
-            fma_all(A2, r0, r1);
-            if (++s >= s1) break;
+        // k-steps: (row py, group of 4 consecutive sub-pixels); this wave takes every 4th
+        const int rows_eff = min(WG_TH, sh - I.sy0), grp_eff = (min(WG_TW, sw - I.sx0) + 3) >> 2;
+        const int nsteps = rows_eff * grp_eff;
+        const float *xt = buf, *gt = buf + WG_XPIX * UBD_C;
+        for (int s = wid; s < nsteps; s += 4) {
+            const int py = (int)((unsigned)s / (unsigned)grp_eff), pg = s - py * grp_eff;
+            const int px = pg * 4 + k;                                 // this lane's sub-pixel column
+            const float *xp = xt + (py * WG_XW + px) * UBD_C;          // X-tile pixel of tap (0,0)
+            const float *gp = gt + (py * WG_TW + px) * UBD_C;
+            const float b0 = gp[m];
+            const float b1 = m < 8 ? gp[16 + m] : 0.f;
+            float a[14];
+#pragma unroll
+            for (int mt = 0; mt < 13; ++mt) a[mt] = xp[aoff[mt]];
+            a[13] = row13_real ? xp[aoff[13]] : (row13_ones ? 1.f : 0.f);
+#pragma unroll
+            for (int mt = 0; mt < 14; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+            }
         }
     }
-    // block reduction through LDS, then one atomic per output per block
+    // block reduction through LDS (the tile buffers are free now), then one atomic per output per block
+    __syncthreads();
+    float *red = smem;                                 // 224 x 32 floats = 28 KiB
     for (int t = threadIdx.x; t < 224 * 32; t += blockDim.x) red[t] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -568,13 +621,16 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
         hipLaunchKernelGGL(head_wgrad_kernel, dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
     }
     // dilated layers, top to bottom
-    const unsigned bytes = (unsigned)((size_t)npix * UBD_C * 4);
     int cur = 0;
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
         const float *X = acts[k];                               // input of dilated layer k (= output of the layer below)
-        const long nsteps = (long)n * H4 * ((W4 + 3) / 4);
-        int gw = ubd_grid_for((nsteps + 31) / 32, h->num_cus, 4, 2);
-        hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, UBD_DILATIONS[k], bytes);
+        {
+            const int dd = UBD_DILATIONS[k];
+            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + WG_TH - 1) / WG_TH) * (((W4 + dd - 1) / dd + WG_TW - 1) / WG_TW);
+            int gw = h->num_cus * 2;
+            if (gw > items) gw = (int)items;
+            hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, dd);
+        }
         if (h->use_wino)
             ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         else
