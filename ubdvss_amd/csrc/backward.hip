@@ -69,6 +69,37 @@ __global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------ partial sums
+// Weight gradients are accumulated per block and written as one row of a [blocks][count] partial-sum matrix;
+// reduce_partials_kernel adds the rows in a fixed order (deterministic, and no same-address atomics: a few
+// thousand fp32 atomics per address cost ~0.4 ms per launch on MI355X).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int nblocks, int count,
+                                                              float *__restrict__ out0, int n0, float *__restrict__ out1, int n1,
+                                                              float *__restrict__ out2)
+{
+    // block = 64 consecutive elements x 4 row groups; 8 independent loads in flight per thread
+    __shared__ float s[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < count) {
+        int b = ty;
+        for (; b + 28 < nblocks; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(b + 4 * u) * count + e];
+        }
+        for (; b < nblocks; b += 4) acc[0] += part[(size_t)b * count + e];
+    }
+    s[ty][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (ty == 0 && e < count) {
+        const float v = (s[0][tx] + s[1][tx]) + (s[2][tx] + s[3][tx]);
+        if (e < n0) out0[e] = v;
+        else if (e < n0 + n1) out1[e - n0] = v;
+        else out2[e - n0 - n1] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------ head
 __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dlogits, const float *__restrict__ a9,
                                                       const float *__restrict__ hk, float *__restrict__ g, long npix, int k_out)
@@ -173,7 +204,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
 #define WG_BUF_FLOATS (WG_ROUNDS * 256 * 4)    // 8192 floats = 32 KiB
 
 __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gz,
-                                                           float *__restrict__ g_k, float *__restrict__ g_b, int n, int h,
+                                                           float *__restrict__ partials, int n, int h,
                                                            int w, int d)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF_FLOATS];     // 64 KiB: two tile buffers / final reduction
@@ -292,32 +323,45 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mt + 4 * k + r) * 32 + m + 16 * nt], acc[mt][nt][r]);
     __syncthreads();
-    for (int t = threadIdx.x; t < 217 * UBD_C; t += blockDim.x) {
-        const int rho = t / UBD_C, co = t % UBD_C;
-        const float v = red[rho * 32 + co];
-        if (v != 0.f) {
-            if (rho < 216) atomicAdd(&g_k[rho * UBD_C + co], v);
-            else atomicAdd(&g_b[co], v);
-        }
-    }
+    // row of the partial-sum matrix: [216*24 kernel gradient | 24 bias gradient]
+    float *prow = partials + (size_t)blockIdx.x * (217 * UBD_C);
+    for (int t = threadIdx.x; t < 217 * UBD_C; t += blockDim.x) prow[t] = red[(t / UBD_C) * 32 + (t % UBD_C)];
 }
 
 // ------------------------------------------------------------------------------------ separable backward
+// Persistent blocks over output tiles of 16 columns x TH rows (as the forward sepconv_kernel): the input
+// patch and the G tile are staged in LDS (24 channels: LDS-DMA, clamped + zero-fixed at the image border;
+// 1/3 channels: converted on the way through registers), every tap and both G layouts are then read from LDS.
+template <int CIN, int STRIDE> struct sepb_cfg {
+    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int PH = (TH - 1) * STRIDE + 3;
+    static constexpr int PW = 15 * STRIDE + 3;
+    static constexpr int XPIX = PH * PW;
+    static constexpr int GPIX = TH * 16;
+    static constexpr int XFLOATS = (CIN == UBD_C) ? XPIX * UBD_C : (XPIX * CIN + 3) / 4 * 4;
+    static constexpr int CHUNKS = ((CIN == UBD_C) ? XPIX * 6 : 0) + GPIX * 6;         // DMA chunks (X if 24 ch, then G)
+    static constexpr int ROUNDS = (CHUNKS + 255) / 256;
+    static constexpr int GOFF = (CIN == UBD_C) ? 0 : XFLOATS;                          // float offset of the DMA region
+    static constexpr int LDS_FLOATS = GOFF + ROUNDS * 256 * 4;
+};
+
 template <int CIN, int STRIDE, int IN_U8>
-__global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
+__global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
-                                                      const float *__restrict__ bwdfrag, float *__restrict__ g_dw,
-                                                      float *__restrict__ g_pw, float *__restrict__ g_b, int n, int H, int W,
+                                                      const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
                                                       int OH, int OW, int pad_lo, float pre_sub, float pre_div)
 {
+    using C = sepb_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;           // tiles of the dDW product
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;          // M tiles of the dpw product (CIN rows + ones row)
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ float s_dw[4][16][UBD_C];
-    __shared__ float s_g[4][16][UBD_C];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
+    float *xpatch = lds;                                                // CIN==24: part of the DMA region
+    float *gtile = lds + C::GOFF + ((CIN == UBD_C) ? C::XPIX * UBD_C : 0);
 
     float dwk[9][CPL];
 #pragma unroll
@@ -330,7 +374,7 @@ __global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ x
 #pragma unroll
         for (int tl = 0; tl < NT_A; ++tl) apw[s][tl] = bwdfrag[(s * 2 + tl) * 64 + lane];
     const bool ch_ok = (CIN == UBD_C) || (q < CIN);
-    const int cb = (CIN == UBD_C) ? 6 * q : q;
+    const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
 
     float ddw[9][CPL];
 #pragma unroll
@@ -339,122 +383,196 @@ __global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ x
         for (int s = 0; s < CPL; ++s) ddw[t][s] = 0.f;
     f32x4 accpw[MT_PW][2] = {};
 
-    const int tiles_x = (OW + 15) >> 4;
-    const int total = n * OH * tiles_x;
-    const int nwaves = gridDim.x * (blockDim.x >> 6);
-    for (int tile = blockIdx.x * (blockDim.x >> 6) + wid; tile < total; tile += nwaves) {
-        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int oy = (int)((unsigned)rowid % (unsigned)OH);
-        const int img = (int)((unsigned)rowid / (unsigned)OH);
-        const int x0 = xt * 16;
-        const int ox = x0 + i;
-        const bool pvalid = ox < OW;
-
-        // ---- 1. input taps, depthwise output
-        float xv[9][CPL];
-        float dwv[CPL];
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * STRIDE + ky - pad_lo;
-            const bool rok = (iy >= 0) && (iy < H);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int t = ky * 3 + kx;
-                const int ix = ox * STRIDE + kx - pad_lo;
-                const bool ok = rok && ch_ok && (ix >= 0) && (ix < W) && pvalid;
-                const size_t e = (((size_t)img * H + (size_t)(rok ? iy : 0)) * W + (size_t)(ok ? ix : 0)) * CIN + cb;
-                if constexpr (CIN == UBD_C) {
-                    const f32x2 *p = (const f32x2 *)((const float *)xin + e);
-                    f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
-                    if (ok) { v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-                    xv[t][0] = v0[0]; xv[t][1] = v0[1]; xv[t][2] = v1[0]; xv[t][3] = v1[1]; xv[t][4] = v2[0]; xv[t][5] = v2[1];
-                } else {
-                    float v = 0.f;
-                    if (ok) {
-                        if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[e] - pre_sub) / pre_div;
-                        else v = (((const float *)xin)[e] - pre_sub) / pre_div;
-                    }
-                    xv[t][0] = v;
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
+    const int total = n * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
+        const int img = (int)((unsigned)rr / (unsigned)tiles_y);
+        const int oy0 = ty * C::TH, ox0 = tx * 16;
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        __syncthreads();                                               // previous tile fully consumed
+        // ---- stage X patch (24 ch) and G tile by LDS-DMA; clamped addresses, zero-fix below
+#pragma unroll 2
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int cbase = rd * 256 + wid * 64;
+            int c = cbase + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const float *src;
+            if (CIN == UBD_C && c < C::XPIX * 6) {
+                const int pix = c / 6, part = c - pix * 6;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                int gy = iy0 + pr, gx = ix0 + pc;
+                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                src = (const float *)xin + (((size_t)img * H + gy) * W + gx) * UBD_C + part * 4;
+            } else {
+                const int cg = c - ((CIN == UBD_C) ? C::XPIX * 6 : 0);
+                const int pix = cg / 6, part = cg - pix * 6;
+                int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+                gy = gy >= OH ? OH - 1 : gy;
+                gx = gx >= OW ? OW - 1 : gx;
+                src = G + (((size_t)img * OH + gy) * OW + gx) * UBD_C + part * 4;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(lds + C::GOFF + cbase * 4), 16, 0, 0);
+        }
+        if constexpr (CIN != UBD_C) {                                  // small-channel input: through registers
+            for (int e = threadIdx.x; e < C::XPIX * CIN; e += 256) {
+                const int pix = e / CIN, ch = e - pix * CIN;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                const int gy = iy0 + pr, gx = ix0 + pc;
+                float v = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
+                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
+                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
                 }
-#pragma unroll
-                for (int s = 0; s < CPL; ++s) dwv[s] = fmaf(xv[t][s], dwk[t][s], dwv[s]);
+                xpatch[e] = v;
             }
         }
-        // ---- 2. G of this pixel, channels 6q..6q+5 (zero outside the tile)
-        float g6[6];
+        __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
         {
-            const f32x2 *pg = (const f32x2 *)(G + (((size_t)img * OH + oy) * OW + (size_t)(pvalid ? ox : 0)) * UBD_C + 6 * q);
-            f32x2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f}, v2 = {0.f, 0.f};
-            if (pvalid) { v0 = pg[0]; v1 = pg[1]; v2 = pg[2]; }
-            g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
-        }
-        // ---- 3. dDW[i][ch] = sum_co G[i][co] pw[ch][co]  (rows = channels in lane layout, cols = pixels)
-        f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
+            const bool xborder = (CIN == UBD_C) && ((iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W));
+            const bool gborder = (oy0 + C::TH > OH) || (ox0 + 16 > OW);
+            if (xborder || gborder) {                                  // block-uniform
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                if (xborder)
+                    for (int pix = threadIdx.x; pix < C::XPIX; pix += 256) {
+                        const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                        const int gy = iy0 + pr, gx = ix0 + pc;
+                        if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                            f32x4 *z = (f32x4 *)(xpatch + pix * UBD_C);
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
-            if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
-        }
-        float ddwv[CPL];
-        if constexpr (CIN == UBD_C) {
-            ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
-        } else {
-            ddwv[0] = dA[0];
-        }
-        // ---- 4. depthwise kernel gradient
+                            for (int k6 = 0; k6 < 6; ++k6) z[k6] = zero;
+                        }
+                    }
+                if (gborder)
+                    for (int pix = threadIdx.x; pix < C::GPIX; pix += 256)
+                        if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
+                            f32x4 *z = (f32x4 *)(gtile + pix * UBD_C);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int s = 0; s < CPL; ++s) ddw[t][s] = fmaf(xv[t][s], ddwv[s], ddw[t][s]);
-        // ---- 5. pointwise kernel / bias gradient: transpose DW and G through this wave's LDS tile
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) s_dw[wid][i][cb + s] = ch_ok ? dwv[s] : 0.f;
-#pragma unroll
-        for (int s = 0; s < 6; ++s) s_g[wid][i][6 * q + s] = g6[s];
-        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int pr = 4 * g4 + q;               // lane (m = i, k = q): pixel row pr of the tile
-            const float b0 = s_g[wid][pr][i];
-            const float b1 = i < 8 ? s_g[wid][pr][16 + i] : 0.f;
-            float a0, a1 = 0.f;
-            if constexpr (CIN == UBD_C) {
-                a0 = s_dw[wid][pr][i];
-                a1 = i < 8 ? s_dw[wid][pr][16 + i] : (i == 8 ? 1.f : 0.f);
-            } else {
-                a0 = i < CIN ? s_dw[wid][pr][i] : (i == CIN ? 1.f : 0.f);
-            }
-            accpw[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accpw[0][0], 0, 0, 0);
-            accpw[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accpw[0][1], 0, 0, 0);
-            if constexpr (MT_PW == 2) {
-                accpw[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accpw[1][0], 0, 0, 0);
-                accpw[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accpw[1][1], 0, 0, 0);
+                            for (int k6 = 0; k6 < 6; ++k6) z[k6] = zero;
+                        }
+                __syncthreads();
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- 6. dDW for the data-gradient kernel
-        if (dDW != nullptr && pvalid && ch_ok) {
-            float *pd = dDW + (((size_t)img * OH + oy) * OW + ox) * CIN + cb;
+
+#pragma unroll 1
+        for (int r = wid; r < C::TH; r += 4) {
+            const int oy = oy0 + r;
+            if (oy >= OH) break;
+            const int ox = ox0 + i;
+            const bool pvalid = ox < OW;
+            // ---- 1. depthwise output (taps are re-read from LDS in step 4 instead of being kept in 54 VGPRs)
+            float dwv[CPL];
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int t = ky * 3 + kx;
+                    const float *p = xpatch + ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    if constexpr (CIN == UBD_C) {
+                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
+                        dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]); dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
+                        dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]); dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
+                        dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]); dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
+                    } else {
+                        dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);        // dwk is zero for lanes without a channel
+                    }
+                }
+            // ---- 2. G of this pixel, channels 6q..6q+5 (zero outside the map: zero-fixed tile)
+            float g6[6];
+            {
+                const f32x2 *pg = (const f32x2 *)(gtile + (r * 16 + i) * UBD_C + 6 * q);
+                const f32x2 v0 = pg[0], v1 = pg[1], v2 = pg[2];
+                g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
+            }
+            // ---- 3. dDW[i][ch] = sum_co G[i][co] pw[ch][co]  (rows = channels in lane layout, cols = pixels)
+            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
+                if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
+            }
+            float ddwv[CPL];
             if constexpr (CIN == UBD_C) {
-                f32x2 *p2 = (f32x2 *)pd;
-                p2[0] = (f32x2){ddwv[0], ddwv[1]}; p2[1] = (f32x2){ddwv[2], ddwv[3]}; p2[2] = (f32x2){ddwv[4], ddwv[5]};
+                ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
             } else {
-                pd[0] = ddwv[0];
+                ddwv[0] = dA[0];
+            }
+            // ---- 4. depthwise kernel gradient
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int t = ky * 3 + kx;
+                    const float *p = xpatch + ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    if constexpr (CIN == UBD_C) {
+                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
+                        ddw[t][0] = fmaf(v0[0], ddwv[0], ddw[t][0]); ddw[t][1] = fmaf(v0[1], ddwv[1], ddw[t][1]);
+                        ddw[t][2] = fmaf(v1[0], ddwv[2], ddw[t][2]); ddw[t][3] = fmaf(v1[1], ddwv[3], ddw[t][3]);
+                        ddw[t][4] = fmaf(v2[0], ddwv[4], ddw[t][4]); ddw[t][5] = fmaf(v2[1], ddwv[5], ddw[t][5]);
+                    } else {
+                        ddw[t][0] = fmaf(ch_ok ? p[0] : 0.f, ddwv[0], ddw[t][0]);
+                    }
+                }
+            // ---- 5. pointwise kernel / bias gradient: DW transposed through this wave's LDS tile, G read in place
+#pragma unroll
+            for (int s = 0; s < CPL; ++s)
+                if (ch_ok) s_dw[wid][i][cb + s] = dwv[s];
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int pr = 4 * g4 + q;               // lane (m = i, k = q): pixel pr of this row tile
+                const float *gp = gtile + (r * 16 + pr) * UBD_C;
+                const float b0 = gp[i];
+                const float b1 = i < 8 ? gp[16 + i] : 0.f;
+                float a0, a1 = 0.f;
+                if constexpr (CIN == UBD_C) {
+                    a0 = s_dw[wid][pr][i];
+                    a1 = i < 8 ? s_dw[wid][pr][16 + i] : (i == 8 ? 1.f : 0.f);
+                } else {
+                    a0 = i < CIN ? s_dw[wid][pr][i] : (i == CIN ? 1.f : 0.f);
+                }
+                accpw[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accpw[0][0], 0, 0, 0);
+                accpw[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accpw[0][1], 0, 0, 0);
+                if constexpr (MT_PW == 2) {
+                    accpw[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accpw[1][0], 0, 0, 0);
+                    accpw[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accpw[1][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- 6. dDW for the data-gradient kernel
+            if (dDW != nullptr && pvalid && ch_ok) {
+                float *pd = dDW + (((size_t)img * OH + oy) * OW + ox) * CIN + cb;
+                if constexpr (CIN == UBD_C) {
+                    f32x2 *p2 = (f32x2 *)pd;
+                    p2[0] = (f32x2){ddwv[0], ddwv[1]}; p2[1] = (f32x2){ddwv[2], ddwv[3]}; p2[2] = (f32x2){ddwv[4], ddwv[5]};
+                } else {
+                    pd[0] = ddwv[0];
+                }
             }
         }
     }
-    // ---- flush: depthwise kernel gradient (reduce over the 16 pixel lanes of each q group)
+    // ---- flush: block-level reduction in LDS, then this block's row of the partial-sum matrix
+    //      row layout: [9*CIN depthwise | CIN*24 pointwise | 24 bias]
+    constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
+    __syncthreads();
+    float *red = lds;                                   // tile buffers are free now
+    for (int t = threadIdx.x; t < PART; t += blockDim.x) red[t] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             float v = ddw[t][s];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (i == 0 && ch_ok && v != 0.f) atomicAdd(&g_dw[t * CIN + cb + s], v);
+            if (i == 0 && ch_ok) atomicAdd(&red[t * CIN + cb + s], v);
         }
     // pointwise kernel / bias gradient: D col = i (co), row = 4q + r (+16 mt) (ci or the ones row)
 #pragma unroll
@@ -464,12 +582,11 @@ __global__ __launch_bounds__(256) void sep_bwd_kernel(const void *__restrict__ x
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mt + 4 * q + r, col = i + 16 * nt;
-                const float v = accpw[mt][nt][r];
-                if (col < UBD_C && v != 0.f) {
-                    if (row < CIN) atomicAdd(&g_pw[row * UBD_C + col], v);
-                    else if (row == CIN) atomicAdd(&g_b[col], v);
-                }
+                if (col < UBD_C && row <= CIN) atomicAdd(&red[9 * CIN + row * UBD_C + col], accpw[mt][nt][r]);   // row CIN = bias
             }
+    __syncthreads();
+    float *prow = partials + (size_t)blockIdx.x * PART;
+    for (int t = threadIdx.x; t < PART; t += blockDim.x) prow[t] = red[t];
 }
 
 // G_below[q][c] = (sum_t dDW[(q + pad - t)/s][c] dw[t][c]) * (X[q][c] > 0)   (24-channel layers only)
@@ -529,7 +646,7 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
 // ------------------------------------------------------------------------------------ host
 struct train_layout {
     ubd_fwd_layout fwd;
-    size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, total;
+    size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, off_partials, total;
 };
 
 static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train_layout *T)
@@ -547,7 +664,8 @@ static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train
     T->off_ddw3 = off;    off += small;
     T->off_gb[0] = off;   off += big;
     T->off_gb[1] = off;   off += big;
-    T->off_loss = off;    off += ubd_loss_workspace_bytes(h, n, H / 4, W / 4);
+    T->off_loss = off;    off += ubd_align_up(ubd_loss_workspace_bytes(h, n, H / 4, W / 4), 256);
+    T->off_partials = off; off += ubd_align_up((size_t)2 * h->num_cus * (217 * UBD_C) * sizeof(float), 256);
     T->total = off;
 }
 
@@ -561,15 +679,20 @@ extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int heig
 
 template <int CIN, int STRIDE>
 static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
-                           const float *bfrag, float *g_dw, float *g_pw, float *g_b, int n, int H, int W, int OH, int OW,
-                           int pad_lo, float sub, float div, hipStream_t st)
+                           const float *bfrag, float *g_dw, float *g_pw, float *g_b, float *partials, int n, int H, int W,
+                           int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
 {
-    const long tiles = (long)n * OH * ((OW + 15) / 16);
-    const int grid = ubd_grid_for(tiles, h->num_cus, 4, 2);
+    const int th = sepb_cfg<CIN, STRIDE>::TH;
+    const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
+    const size_t lds_bytes = sepb_cfg<CIN, STRIDE>::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float);
+    int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
+    if (grid > tiles) grid = (int)tiles;
     if (in_u8)
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, g_dw, g_pw, g_b, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     else
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, g_dw, g_pw, g_b, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+    const int part = 9 * CIN + CIN * UBD_C + UBD_C;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + 63) / 64), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
 extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
@@ -610,6 +733,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
     float *ddw3 = (float *)(ws + T.off_ddw3);
     float *gb[2] = {(float *)(ws + T.off_gb[0]), (float *)(ws + T.off_gb[1])};
+    float *partials = (float *)(ws + T.off_partials);
 
     int grid = (int)((npix + 255) / 256);
     if (grid > h->num_cus * 8) grid = h->num_cus * 8;
@@ -629,7 +753,9 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
             const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + WG_TH - 1) / WG_TH) * (((W4 + dd - 1) / dd + WG_TW - 1) / WG_TW);
             int gw = h->num_cus * 2;
             if (gw > items) gw = (int)items;
-            hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], grads + h->off_dil_k[k], grads + h->off_dil_b[k], n, H4, W4, dd);
+            hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + 63) / 64), dim3(256), 0, st, partials, gw, 217 * UBD_C,
+                               grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
         }
         if (h->use_wino)
             ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
@@ -642,13 +768,13 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
     const float *bs0 = bfrag + UBD_BWD_DGRAD_FLOATS, *bs1 = bs0 + UBD_BWD_SEP_FLOATS, *bs2 = bs1 + UBD_BWD_SEP_FLOATS;
     // L3: input a2 (H2 x W2), output H4 x W4, G = gq[cur]
-    launch_sep_bwd<UBD_C, 2>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    launch_sep_bwd<UBD_C, 2>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
     {
         const long tiles = (long)n * H2 * ((W2 + 15) / 16);
         const int g3 = ubd_grid_for(tiles, h->num_cus, 4, 8);
         hipLaunchKernelGGL(sep_dx_kernel<2>, dim3(g3), dim3(256), 0, st, ddw3, a2, gb[0], sf2, n, H2, W2, H4, W4, pad_s2);
         // L2: input a1, output H2 x W2, G = gb[0]
-        launch_sep_bwd<UBD_C, 1>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+        launch_sep_bwd<UBD_C, 1>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
         hipLaunchKernelGGL(sep_dx_kernel<1>, dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
     }
     // L1: input = images, no data gradient
@@ -656,9 +782,9 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
     if (h->cfg.c_in == 1)
-        launch_sep_bwd<1, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<1, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     else
-        launch_sep_bwd<3, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<3, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }
