@@ -132,19 +132,37 @@ def dilated_conv(x, k, b, dilation, relu=True):
     return np.maximum(y, 0) if relu else y
 
 
-def forward(x, weights, fml_compatible=True, dtype=np.float64, return_all=False):
+def round_to(a, act_dtype):
+    """Round an fp64/fp32 array to bfloat16 (round-to-nearest-even on the fp32 bit pattern) or float16 and
+    return it widened again -- models 16-bit activation storage (BASELINE.json configs[2..4])."""
+    if act_dtype is None:
+        return a
+    a32 = np.asarray(a, dtype=np.float32)
+    if act_dtype == "float16":
+        return a32.astype(np.float16).astype(a.dtype)
+    if act_dtype == "bfloat16":
+        u = a32.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32).astype(a.dtype)
+    raise ValueError(act_dtype)
+
+
+def forward(x, weights, fml_compatible=True, dtype=np.float64, return_all=False, act_dtype=None):
     """x: (N,H,W,C_in) already preprocessed.  Returns logits (N,H/4,W/4,1+n_cls);
-    with return_all also the list of the 9 hidden activations."""
+    with return_all also the list of the 9 hidden activations.
+    act_dtype "bfloat16"/"float16": every hidden activation is rounded to that type when it is stored and the
+    dense dilated kernels are used in that type too (the 16-bit configs of BASELINE.json); accumulation stays
+    in `dtype`, logits are not rounded."""
     x = np.asarray(x, dtype=dtype)
     w = [np.asarray(a, dtype=dtype) for a in weights]
     acts = []
     i = 0
     for stride in (2, 1, 2):
-        x = separable_conv(x, w[i], w[i + 1], w[i + 2], stride, fml_compatible)
+        x = round_to(separable_conv(x, w[i], w[i + 1], w[i + 2], stride, fml_compatible), act_dtype)
         acts.append(x)
         i += 3
     for d in DILATIONS:
-        x = dilated_conv(x, w[i], w[i + 1], d)
+        x = round_to(dilated_conv(x, round_to(w[i], act_dtype), w[i + 1], d), act_dtype)
         acts.append(x)
         i += 2
     logits = x @ w[i][0, 0] + w[i + 1]

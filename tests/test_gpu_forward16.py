@@ -1,0 +1,70 @@
+"""GPU parity of the 16-bit activation forward paths (bf16 / fp16 storage + 16-bit MFMA in the dilated layers,
+fp32 accumulation, fp32 logits) -- BASELINE.json configs[2] (bf16) and configs[4] (fp16, 1024x1024).
+Two gates per case:
+  * vs the oracle run with the SAME storage rounding (activations and dilated kernels rounded to the 16-bit
+    type after every layer): max |diff| <= 4e-3 (fp16) / 2e-2 (bf16: one storage ulp is 2^-8 = 0.4 %, and a
+    rounding tie that flips because fp32 and fp64 accumulate in different orders propagates through the
+    remaining layers) * max|logit| + 1e-5,
+  * vs the plain fp64 oracle: <= 2e-2 * max|logit| for fp16 and <= 8e-2 * max|logit| for bf16 (proposal of SURVEY.md
+    section 8(d) scaled to the 10-layer depth; reported, loose by design)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_numpy as onet
+from ubdvss_amd import NetConfig, Model, ModelRunner, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dtype, cin, ncls, fml, n, hh, ww, seed):
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml)
+    w = onet.init_weights(seed, cin, ncls, bias_scale=0.2)
+    m = Model(cfg, dtype=dtype)
+    m.set_weights(w)
+    x = synthetic.noise_images(seed + 1, n, hh, ww, cin)
+    lg = m.predict(x)
+    ref16 = onet.forward(x.astype(np.float64), w, fml, act_dtype=dtype)
+    ref = onet.forward(x.astype(np.float64), w, fml)
+    scale = np.abs(ref).max()
+    e16 = np.abs(lg - ref16).max()
+    e64 = np.abs(lg - ref).max()
+    assert lg.dtype == np.float32 and lg.shape == ref.shape
+    assert e16 <= (2e-2 if dtype == "bfloat16" else 4e-3) * scale + 1e-5, (e16, scale)
+    assert e64 <= (8e-2 if dtype == "bfloat16" else 2e-2) * scale, (e64, scale)
+    return e16 / scale, e64 / scale
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("cin,ncls,fml,n,hh,ww", [(3, 0, True, 2, 128, 128), (1, 3, True, 1, 64, 192), (3, 2, False, 2, 72, 100)])
+def test_forward16_vs_oracle(dtype, cin, ncls, fml, n, hh, ww):
+    _run(dtype, cin, ncls, fml, n, hh, ww, 50 + cin + ncls)
+
+
+def test_cfg5_shape_fp16_1024():
+    """configs[4]: 1024x1024 fp16 forward with dilation rates 1,2,4,8,16(,1); batch reduced to 2 for the oracle."""
+    _run("float16", 3, 0, True, 2, 1024, 1024, 77)
+
+
+def test_bf16_full_batch_property_and_postprocess():
+    """configs[2] forward shape (64 x 512 x 512 x 3, bf16): image independence of the batch (bit-exact: same
+    kernels, same per-image data) and the device postprocess running on the bf16 model's fp32 logits."""
+    cfg = NetConfig(grey=False)
+    m = Model(cfg, dtype="bfloat16", seed=1)
+    x = torch.from_numpy(synthetic.noise_images(3, 64, 512, 512, 3)).cuda()
+    a = m.predict_on_device(x).clone()
+    b = m.predict_on_device(x[9:10].contiguous())
+    assert torch.equal(a[9], b[0])
+    out = ModelRunner(cfg).predict_on_device(m, x[:4].contiguous())
+    assert out[4].shape == (4,)
+
+
+def test_training_refuses_16bit_for_now():
+    from ubdvss_amd import Trainer
+    cfg = NetConfig(grey=False)
+    m = Model(cfg, dtype="bfloat16", seed=1)
+    tr = Trainer(m)
+    x = torch.zeros((1, 64, 64, 3), device="cuda")
+    y = torch.zeros((1, 16, 16), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):
+        tr.backward_on_device(x, y)

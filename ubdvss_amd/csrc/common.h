@@ -75,3 +75,7 @@ extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
                              const float *in, float *out, int n, int H4, int W4, hipStream_t st);
+void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st);
+size_t ubd_forward16_workspace_bytes(int n, int H, int W);
+int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
+                  float *logits, char *ws, size_t ws_bytes, hipStream_t st);

@@ -536,6 +536,7 @@ void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int traini
 
 extern "C" size_t ubd_forward_workspace_bytes(const ubd_handle *h, int n, int height, int width)
 {
+    if (h && h->cfg.dtype != UBD_F32) return ubd_forward16_workspace_bytes(n, height, width);
     ubd_fwd_layout L;
     ubd_fwd_layout_compute(h, n, height, width, 0, &L);
     return L.total;
@@ -563,6 +564,15 @@ static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, 
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
     else
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
+}
+
+void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st)
+{
+    pack_args pa;
+    for (int s = 0; s < 3; ++s) { pa.off_sep_dw[s] = h->off_sep_dw[s]; pa.off_sep_pw[s] = h->off_sep_pw[s]; }
+    for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
+    pa.c_in = h->cfg.c_in;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, st, params, wfrag, pa);
 }
 
 static void launch_pack(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st)
@@ -673,6 +683,11 @@ extern "C" int ubd_forward(ubd_handle *h, const float *params, const void *image
                            void *stream)
 {
     UBD_REQUIRE(h && params && images && logits && workspace, "ubd_forward: null argument");
+    if (h->cfg.dtype != UBD_F32) {
+        UBD_REQUIRE(n > 0 && height > 0 && width > 0 && (height % 4) == 0 && (width % 4) == 0, "ubd_forward: height and width must be positive multiples of 4 (got %d x %d)", height, width);
+        UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
+        return ubd_forward16(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, workspace_bytes, (hipStream_t)stream);
+    }
     ubd_fwd_layout L;
     ubd_fwd_layout_compute(h, n, height, width, 0, &L);
     UBD_REQUIRE(workspace_bytes >= L.total, "ubd_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
