@@ -1,19 +1,30 @@
 #!/bin/bash
-# PMC counters for the dilated-conv kernel (separate passes, kernel-trace only as gpurun requires)
-mkdir -p gpurun_out
+# PMC counters for one kernel (name pattern $1) of the fp32 forward pass (separate passes, kernel-trace only)
+PAT=${1:-dilconv_wino}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_${PAT}.txt
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out; rm -f $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/tools/bench_layer.py --reps 20 > $GRAFT_REPO_ROOT/gpurun_out/layer_bench.log 2>&1
+cat > /tmp/fwd_once.py <<'PY'
+import sys, os, torch
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from ubdvss_amd import NetConfig, Model, synthetic
+torch.cuda.set_device(0)
+m = Model(NetConfig(grey=False), seed=1)
+x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
+for _ in range(3): m.predict_on_device(x)
+torch.cuda.synchronize()
+PY
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmc$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -- python3 $GRAFT_REPO_ROOT/tools/bench_layer.py --reps 3 --layers 2 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -- python3 /tmp/fwd_once.py > /dev/null 2>&1
   f=$(find /tmp/pmc$i -name "*counter_collection.csv" | head -1)
-  python3 - "$f" <<'PY' >> $GRAFT_REPO_ROOT/gpurun_out/pmc_dilconv.txt
+  python3 - "$f" "$PAT" <<'PY' >> $OUT
 import csv, sys, collections
 acc = collections.defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if "dilconv" in r["Kernel_Name"]:
+        if sys.argv[2] in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 except Exception as e:
     print("ERR", e)
@@ -22,5 +33,4 @@ for k, v in acc.items():
 PY
   i=$((i+1))
 done
-cd $GRAFT_REPO_ROOT
-cat gpurun_out/layer_bench.log; cat gpurun_out/pmc_dilconv.txt
+cat $OUT
