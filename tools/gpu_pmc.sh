@@ -1,8 +1,9 @@
 #!/bin/bash
 # PMC counters for one kernel (name pattern $1) of the fp32 forward pass (separate passes, kernel-trace only)
 PAT=${1:-dilconv_wino}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_${PAT}.txt
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out; rm -f $OUT
+TAG=$(echo "$PAT" | tr -c "A-Za-z0-9_\n" "_")
+OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}.txt"
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out; rm -f "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/fwd_once.py <<'PY'
 import sys, os, torch
@@ -19,7 +20,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
   rm -rf /tmp/pmc$i
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -- python3 /tmp/fwd_once.py > /dev/null 2>&1
   f=$(find /tmp/pmc$i -name "*counter_collection.csv" | head -1)
-  python3 - "$f" "$PAT" <<'PY' >> $OUT
+  python3 - "$f" "$PAT" <<'PY' >> "$OUT"
 import csv, sys, collections
 acc = collections.defaultdict(list)
 try:
@@ -33,4 +34,4 @@ for k, v in acc.items():
 PY
   i=$((i+1))
 done
-cat $OUT
+cat "$OUT"

@@ -81,9 +81,15 @@ __device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t ro
 {
     // Branch-free: buffer stores whose per-lane offset is pushed out of range for lanes that must not write.
     const int co = lane & 15, q = lane >> 4;
-    float *rowp = y + (row_base_elems + (size_t)x0) * UBD_C;                 // wave-uniform tile base
-    const int npx = ow - x0 < 16 ? ow - x0 : 16;                              // valid pixels in this tile
-    const unsigned bytes = (unsigned)npx * UBD_C * 4u;
+    // wave-uniform tile base; readfirstlane makes the uniformity provable, otherwise hipcc wraps every buffer
+    // store in a waterfall loop (cdna_hip_programming.md T20)
+    const unsigned long long rp = (unsigned long long)(y + (row_base_elems + (size_t)x0) * UBD_C);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
+    float *rowp = (float *)(((unsigned long long)rhi << 32) | rlo);
+    int npx = ow - x0 < 16 ? ow - x0 : 16;                                    // valid pixels in this tile
+    npx = npx < 0 ? 0 : npx;
+    const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 4);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, (int)bytes, 0x00020000);
     const unsigned base = (unsigned)(4 * q) * (UBD_C * 4u) + (unsigned)co * 4u;
     const unsigned base1 = co < 8 ? base + 64u : 0x40000000u;                // channels 16..23 only from lanes co < 8
@@ -282,7 +288,14 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
         const int nxt = tile + gridDim.x;
         const bool has_next = nxt < total;                           // block-uniform
         if constexpr (CIN == UBD_C) {
-            __syncthreads();                 // DMA of this tile landed (vmcnt(0)) + everyone left the other buffer
+            // This tile's DMA must have landed.  vmcnt counts stores too (CDNA4) and __syncthreads() would drain
+            // them all (~2 us of store latency per tile): every wave issues exactly NSTORE buffer stores per tile
+            // AFTER the next tile's DMA, so "all but the NSTORE youngest" retires the DMA and nothing else.
+            constexpr int NSTORE = (C::TH / 4) * 8;
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NSTORE == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();    // + everyone left the other buffer
             if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_FLOATS);
             const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
             const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
@@ -301,20 +314,20 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
                 __builtin_amdgcn_s_barrier();                        // raw barrier: must not drain the DMA in flight
             }
         } else {
-            __syncthreads();                                         // previous tile's readers are done
+            __builtin_amdgcn_s_barrier();                            // previous tile's readers are done (no memory drain)
 #pragma unroll
             for (int k = 0; k < C::STAGE_REGS; ++k) {
                 const int e = k * 256 + threadIdx.x;
                 if (e < C::ELEMS) patch[e] = stage[k];
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): LDS writes done
+            __builtin_amdgcn_s_barrier();
             if (has_next) load_regs(nxt, stage);                     // in flight during the compute phase
         }
 
         // ---- compute: wave `wid` owns rows wid, wid+4, ...
-        for (int r = wid; r < C::TH; r += 4) {
+        for (int r = wid; r < C::TH; r += 4) {                       // fixed trip count: rows past the image only mask their stores
             const int oy = oy0 + r;
-            if (oy >= OH) break;
             float dwv[CPL];
 #pragma unroll
             for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
             }
-            store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, OW, lane, acc0, acc1, b0, b1);
+            store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, oy < OH ? OW : 0, lane, acc0, acc1, b0, b1);
         }
         if (!has_next) break;
         tile = nxt;
