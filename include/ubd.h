@@ -39,6 +39,7 @@ typedef struct ubd_config {
 } ubd_config;
 
 #define UBD_MAX_CLASSES 31
+#define UBD_LOSS_FLOATS 16
 #define UBD_N_FILTERS 24
 
 typedef struct ubd_handle ubd_handle;
@@ -102,7 +103,10 @@ int ubd_postprocess(ubd_handle *h, const float *logits, int n, int map_h, int ma
 /* Replaces the loss callable losses.get_loss(classification_mode)(y_true, y_pred)
  * (losses.py:20-24, :33-126) together with its autodiff gradient.
  *   y_true : int32 (n, map_h, map_w) labels 0..n_classes (0 = background)
- *   loss   : fp32 [4] = {total, detection, classification, n_hard_k}
+ *   loss   : fp32 [UBD_LOSS_FLOATS] = {total, detection, classification, n_hard_k,
+ *            positive_loss, negative_loss, hard_negative_loss (losses.py:138-191), n_pos,
+ *            tp, tn, fp, fn of the detection map logit0 > 0 vs y_true > 0, number of positive pixels whose
+ *            class argmax equals the label (keras_metrics.py:110-172), n_pixels, 0, 0}
  *   dlogits: fp32 like logits (may be NULL for loss only)
  * Batch-global reductions and top-k run over the n images given (per-replica semantics). */
 int ubd_loss(ubd_handle *h, const float *logits, const int32_t *y_true, int n, int map_h, int map_w,
@@ -111,7 +115,7 @@ int ubd_loss(ubd_handle *h, const float *logits, const int32_t *y_true, int n, i
 /* One pass fwd -> loss -> backward (replaces the body of Keras train_on_batch driven by
  * fit_generator, train.py:176-188, up to but excluding the optimiser update).
  *   grads : fp32 [param_count], same flat order as params (overwritten)
- *   loss  : fp32 [4] as in ubd_loss
+ *   loss  : fp32 [UBD_LOSS_FLOATS] as in ubd_loss
  * The caller may all-reduce `grads` across ranks before ubd_adam_step. */
 int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
                    const int32_t *y_true, int n, int height, int width,

@@ -101,3 +101,21 @@ def total_loss(y_true, y_pred, classification_mode, lo=LOGIT_LO_F32, hi=LOGIT_HI
     cls, gcls = classification_loss(y_true, y_pred)
     g[..., 1:] = L_CLS * gcls
     return L_DET * det + L_CLS * cls, g
+
+
+def batch_metrics(y_true, y_pred, classification_mode):
+    """keras_metrics.py:110-172 on one batch (numpy restatement): detection pixel accuracy / precision / recall /
+    f1 with pred = logit0 > 0, classification accuracy over positive pixels."""
+    yt = np.asarray(y_true)[..., 0]
+    t = (yt > 0).astype(np.int64)
+    p = (np.asarray(y_pred)[..., 0] > 0).astype(np.int64)
+    tp = float(((t == p) & (t == 1)).sum()); tn = float(((t == p) & (t == 0)).sum())
+    fp = float(((t != p) & (p == 1)).sum()); fn = float(((t != p) & (p == 0)).sum())
+    prec = tp / max(1.0, tp + fp); rec = tp / max(1.0, tp + fn)
+    out = {"detection_pixel_acc": (tp + tn) / max(1.0, t.size), "detection_pixel_precision": prec,
+           "detection_pixel_recall": rec, "detection_pixel_f1": 2 * prec * rec / (prec + rec) if prec + rec != 0 else 0.0}
+    if classification_mode:
+        labels = (yt - 1) * t
+        pred_cls = np.argmax(np.asarray(y_pred)[..., 1:], axis=-1)
+        out["classification_pixel_acc"] = float(((labels == pred_cls) * t).sum()) / max(1.0, float(t.sum()))
+    return out

@@ -76,3 +76,24 @@ def test_get_loss_callable_api():
     assert abs(float(f(yt, yp)) - oloss.total_loss(yt, yp, True)[0]) < 1e-3
     f = losses.get_loss(classification_mode=False)
     assert abs(float(f(yt, yp)) - oloss.total_loss(yt, yp[..., :1], False)[0]) < 1e-3
+
+
+def test_batch_metrics_and_loss_components():
+    """f2: the per-batch pixel metrics Keras reports with every step (keras_metrics.py:110-172) and the loss
+    components (losses.py:138-191) come out of the same fused kernel."""
+    from ubdvss_amd import keras_metrics
+    rng = np.random.default_rng(9)
+    yt = synthetic.rectangle_maps(90, 3, 48, 64, n_classes=4)
+    yp = rng.normal(0, 2.0, (3, 48, 64, 5)).astype(np.float32)
+    yp[..., 0] += np.where(yt > 0, 1.0, -1.0)
+    l16, _ = losses.loss_and_grad(yt, yp)
+    got = keras_metrics.metrics_from_loss_vector(l16.cpu().numpy(), classification_mode=True)
+    ref = oloss.batch_metrics(yt[..., None], yp, True)
+    for k, v in ref.items():
+        assert abs(got[k] - v) < 1e-6, (k, got[k], v)
+    _, _, parts = oloss.detection_loss(yt[..., None], yp, return_parts=True)
+    assert abs(got["positive_loss"] - parts["pos"]) < 1e-4 * parts["pos"]
+    assert abs(got["negative_loss"] - parts["neg"]) < 1e-4 * parts["neg"]
+    assert abs(got["hard_negative_loss"] - parts["hard"]) < 1e-4 * parts["hard"]
+    assert keras_metrics.get_all_metrics(True)[:5] == ["detection_pixel_acc", "detection_pixel_precision",
+                                                       "detection_pixel_recall", "detection_pixel_f1", "classification_pixel_acc"]

@@ -25,7 +25,10 @@ struct loss_hdr {
     unsigned k_rem;                               // rank still to resolve inside the prefix bin
     unsigned T;                                   // final threshold bits (k-th largest value)
     unsigned need_eq;                             // how many elements == T are selected
-    unsigned pad[2];
+    // per-batch pixel metrics (keras_metrics.py:110-172): detection confusion matrix with pred = logit0 > 0,
+    // and the number of positive pixels whose class argmax equals the label
+    int tp, tn, fp, fn, cls_correct;
+    unsigned pad[1];
 };
 #define LOSS_HDR_BYTES 256
 
@@ -84,10 +87,12 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stats_kernel(const float *__r
     for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
     double sp = 0, sn = 0;
-    int np = 0;
+    int np = 0, c_tp = 0, c_tn = 0, c_fp = 0;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         const float x = logits[p * k_out];
         const float z = y_true[p] > 0 ? 1.f : 0.f;
+        const bool pred = x > 0.f;                            // keras_metrics.py:112
+        c_tp += (pred && z > 0.f); c_tn += (!pred && z == 0.f); c_fp += (pred && z == 0.f);
         float xc;
         const float ce = bce_from_logit(x, z, xc);
         const float cn = ce * (1.f - z);
@@ -106,6 +111,12 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stats_kernel(const float *__r
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_neg, r);
     r = block_reduce_sum((double)np, s_red);
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->n_pos, (int)r);
+    r = block_reduce_sum((double)c_tp, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->tp, (int)r);
+    r = block_reduce_sum((double)c_tn, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->tn, (int)r);
+    r = block_reduce_sum((double)c_fp, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->fp, (int)r);
 }
 
 // ---- radix-select scan: pick the bin that holds the k_rem-th largest element -----------------
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_grad_kernel(const float *__re
     unsigned tie_base = blockties[blockIdx.x];          // ties before this iteration of this block
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double s_hard = 0, s_cls = 0;
+    int c_correct = 0;
     for (long base = lo; base < hi; base += blockDim.x) {
         const long p = base + threadIdx.x;
         const bool active = p < hi;
@@ -261,11 +273,14 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_grad_kernel(const float *__re
             const float *lg = logits + p * k_out + 1;
             if (yt > 0) {
                 float mx = lg[0];
-                for (int c = 1; c < n_cls; ++c) mx = fmaxf(mx, lg[c]);
+                int amax = 0;
+                for (int c = 1; c < n_cls; ++c)
+                    if (lg[c] > mx) { mx = lg[c]; amax = c; }         // first maximum, like tf.argmax
                 float sum = 0.f;
                 for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
                 const float lse = mx + logf(sum);
                 const int lab = yt - 1 < n_cls ? yt - 1 : n_cls - 1;
+                c_correct += (amax == lab);
                 s_cls += (double)(lse - lg[lab]);
                 if (dlogits)
                     for (int c = 0; c < n_cls; ++c)
@@ -279,6 +294,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_grad_kernel(const float *__re
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_hard, r);
     r = block_reduce_sum(s_cls, s_red);
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_cls, r);
+    r = block_reduce_sum((double)c_correct, s_red);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->cls_correct, (int)r);
 }
 
 __global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, float *loss4)
@@ -295,6 +312,20 @@ __global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, 
     loss4[1] = (float)det;
     loss4[2] = (float)cls;
     loss4[3] = (float)hdr->k;
+    // monitoring values of the Keras train step (losses.py:138-191, keras_metrics.py:110-172): loss components
+    // and the raw counters of the per-batch pixel metrics
+    loss4[4] = (float)(hdr->sum_pos / n_pos);
+    loss4[5] = (float)(hdr->sum_neg / n_neg);
+    loss4[6] = (float)hard;
+    loss4[7] = (float)hdr->n_pos;
+    loss4[8] = (float)hdr->tp;
+    loss4[9] = (float)hdr->tn;
+    loss4[10] = (float)hdr->fp;
+    loss4[11] = (float)(hdr->n_pos - hdr->tp);       // fn
+    loss4[12] = (float)hdr->cls_correct;
+    loss4[13] = (float)npix;
+    loss4[14] = 0.f;
+    loss4[15] = 0.f;
 }
 
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,

@@ -52,7 +52,7 @@ def loss_and_grad(y_true, y_pred, want_grad=True):
     n, h, w, k = yp.shape
     yt = _as_device(y_true, torch.int32, device).reshape(n, h, w)
     hd = _handle(k - 1, device)
-    loss = torch.zeros(4, dtype=torch.float32, device=device)
+    loss = torch.zeros(16, dtype=torch.float32, device=device)
     grad = torch.empty_like(yp) if want_grad else None
     ws = torch.empty(int(lib.ubd_loss_workspace_bytes(hd, n, h, w)), dtype=torch.uint8, device=device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

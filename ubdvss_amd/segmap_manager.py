@@ -4,9 +4,11 @@ Same static-method signature as the reference; the work (external components, co
 filter, minAreaRect, boxPoints, class vote) runs in libubd_hip.so on the MI355X.
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
+from PIL import Image, ImageDraw
 
 from . import _lib
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
@@ -63,3 +65,34 @@ class SegmapManager:
             return [ObjectMarkup(bbox) for bbox in q]
         c = classes.cpu().numpy()[0, :n]
         return [ClassifiedObjectMarkup(bbox, class_id) for bbox, class_id in zip(q, c)]
+
+    @staticmethod
+    def build_segmentation_map(image, markup, scale=1, for_drawing=False):
+        """Label map for training -- mirror of segmap_manager.py:81-104 (host side, PIL like the reference):
+        quads / scale, rounded outward by ``_proper_round``, filled with class+1 (or 1 / 255)."""
+        w, h = image.size
+        assert w % scale == 0 and h % scale == 0
+        image_segmap = Image.new(mode='L', size=(w // scale, h // scale), color=0)
+        draw = ImageDraw.Draw(image_segmap)
+        for object_markup in markup:
+            drawn_bbox = SegmapManager._proper_round(np.asarray(object_markup.bbox) / scale)
+            if for_drawing:
+                fill_color = 255
+            else:
+                fill_color = object_markup.object_type + 1 if isinstance(object_markup, ClassifiedObjectMarkup) else 1
+                assert fill_color <= 255, "No more than 255 classes are supported"
+            draw.polygon(drawn_bbox.tolist(), fill=fill_color)
+        return image_segmap
+
+    @staticmethod
+    def _proper_round(markup_bbox):
+        """segmap_manager.py:106-133: floor a coordinate when at least two others are larger, else ceil."""
+        if len(markup_bbox) != 8:
+            return np.array(markup_bbox).astype(np.int32)
+        xs = markup_bbox[::2]
+        ys = markup_bbox[1::2]
+        xs_greater = [sum(1 for _x in xs if _x > x) for x in xs]
+        ys_greater = [sum(1 for _y in ys if _y > y) for y in ys]
+        xs = [math.floor(x) if n_greater > 1 else math.ceil(x) for (x, n_greater) in zip(xs, xs_greater)]
+        ys = [math.floor(y) if n_greater > 1 else math.ceil(y) for (y, n_greater) in zip(ys, ys_greater)]
+        return np.ravel(list(zip(xs, ys))).astype(np.int32)

@@ -33,7 +33,7 @@ class Trainer:
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.loss = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(16, dtype=torch.float32, device=dev)
         self.iterations = 0
         self._ws = None
         self._pg = process_group
