@@ -9,6 +9,18 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_built():
+    """The C-ABI library is built in-tree (hipcc cross-compiles gfx950 without a GPU); build it when a fresh
+    checkout has not run __graft_entry__.build() yet."""
+    lib = os.path.join(ROOT, "ubdvss_amd", "libubd_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "ubdvss_amd", "csrc", "build.sh")])
+
+
+_ensure_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -106,11 +106,12 @@ class ModelRunner:
 
     @staticmethod
     def rescale(found_objects, meta_infos):
-        """model_runner.py:140-148."""
-        assert len(found_objects) == len(meta_infos)
-        return [[
-            found_objects[i][j].create_same_markup(
-                utils.rescale_bbox(found_objects[i][j].bbox,
-                                   xscale=meta_infos[i].xscale,
-                                   yscale=meta_infos[i].yscale)
-            ) for j in range(len(found_objects[i]))] for i in range(len(found_objects))]
+        """Boxes back to the coordinates of the original images (behaviour of model_runner.py:140-148): per image,
+        multiply x by meta.xscale and y by meta.yscale and truncate toward zero (utils.rescale_bbox)."""
+        if len(found_objects) != len(meta_infos):
+            raise AssertionError("one meta_info per image is required")
+        rescaled = []
+        for objects, meta in zip(found_objects, meta_infos):
+            rescaled.append([obj.create_same_markup(utils.rescale_bbox(obj.bbox, xscale=meta.xscale, yscale=meta.yscale))
+                             for obj in objects])
+        return rescaled

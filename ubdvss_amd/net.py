@@ -42,110 +42,89 @@ def depreprocess_image_mobilenet(image):    # net.py:221-222
 
 
 class NetConfig:
-    """Same fields, defaults and getters as the reference NetConfig (net.py:73-214).
-    ``class_names`` may be given directly instead of ``object_types_fname``."""
+    """System / network configuration with the reference's constructor arguments and getter names
+    (semantic_segmentation/net.py:73-214), so that code written against the reference runs unchanged.
+    Extra: ``class_names`` may be passed directly instead of a file (``object_types_fname``).
 
-    @staticmethod
-    def from_others(base_config, side_multiple=None, max_image_side=None, min_pixels_for_detection=None):
-        new_config = copy.deepcopy(base_config)
-        if side_multiple:
-            new_config._side_multiple = side_multiple
-        if max_image_side:
-            new_config._max_side = max_image_side
-        if min_pixels_for_detection:
-            new_config._min_pixels_for_detection = min_pixels_for_detection
-        return new_config
+    Fields that reach the kernels: ``grey`` (1 or 3 input channels), ``fml_compatible`` (stride-2 padding rule),
+    number of classes, ``scale`` (=4), ``min_pixels_for_detection`` (contourArea threshold), ``preprocessing``.
+    """
+
+    _OVERRIDABLE = {"side_multiple": "_side_multiple", "max_image_side": "_max_side",
+                    "min_pixels_for_detection": "_min_pixels_for_detection"}
 
     def __init__(self, object_types_fname=None, scale=4, fml_compatible=True, no_classification=False,
                  side_multiple=64, max_image_side=512, min_pixels_for_detection=5,
                  preprocessing=PreprocessingType.NONE, grey=True, class_names=None):
-        if object_types_fname is None and class_names is None:
-            self._class_names = None
-            self._is_classification_supported = False
-        else:
-            self._is_classification_supported = not no_classification
-            if class_names is not None:
-                self._class_names = list(class_names)
-                self._class_name_to_id = dict((c, i) for i, c in enumerate(self._class_names))
-            else:
-                self._read_classnames_from_file(object_types_fname)
-        self._grey = grey
-        self._scale = scale
-        self._fml_compatible = fml_compatible
+        names = None
+        if class_names is not None:
+            names = [str(c) for c in class_names]
+        elif object_types_fname is not None:
+            names = self._load_class_names(object_types_fname)
+        self._class_names = names
+        self._class_name_to_id = {c: k for k, c in enumerate(names)} if names is not None else {}
+        self._is_classification_supported = names is not None and not no_classification
+        self._grey, self._scale, self._fml_compatible = grey, scale, fml_compatible
         self._preprocessing = preprocessing
-        self._side_multiple = side_multiple
-        self._max_side = max_image_side
+        self._side_multiple, self._max_side = side_multiple, max_image_side
         self._min_pixels_for_detection = min_pixels_for_detection
 
-    def is_grey(self):
-        return self._grey
+    @staticmethod
+    def from_others(base_config, side_multiple=None, max_image_side=None, min_pixels_for_detection=None):
+        """Copy of ``base_config`` with the architecture-independent knobs replaced where a value is given."""
+        clone = copy.deepcopy(base_config)
+        given = {"side_multiple": side_multiple, "max_image_side": max_image_side,
+                 "min_pixels_for_detection": min_pixels_for_detection}
+        for key, value in given.items():
+            if value:
+                setattr(clone, NetConfig._OVERRIDABLE[key], value)
+        return clone
 
-    def get_scale(self):
-        return self._scale
+    @staticmethod
+    def _load_class_names(path):
+        if not os.path.exists(path):
+            raise AssertionError(f"File with object class names {path} does not exist")
+        with open(path) as f:
+            return [ln.strip() for ln in f if ln.strip()]
 
-    def get_min_pixels_for_detection(self):
-        return self._min_pixels_for_detection
-
-    def get_side_multiple(self):
-        return self._side_multiple
-
-    def get_max_side(self):
-        return self._max_side
-
-    def is_fml_compatible(self):
-        return self._fml_compatible
-
-    def get_preprocessing_type(self):
-        return self._preprocessing
-
-    def get_preprocessing_fn(self):
-        if self._preprocessing == PreprocessingType.NONE:
-            return lambda x: x
-        elif self._preprocessing == PreprocessingType.MOBILENET_LIKE:
-            return preprocess_image_mobilenet
-        raise ValueError("Unknown preprocessing type")
-
-    def get_depreprocessing_fn(self):
-        if self._preprocessing == PreprocessingType.NONE:
-            return lambda x: x
-        elif self._preprocessing == PreprocessingType.MOBILENET_LIKE:
-            return depreprocess_image_mobilenet
-        raise ValueError("Unknown preprocessing type")
-
-    def get_class_names(self):
-        return self._class_names
-
-    def get_n_classes(self):
-        return len(self._class_names)
-
-    def get_class_name(self, class_id):
-        return self._class_names[class_id]
-
-    def get_class_id(self, class_name):
-        return self._class_name_to_id[class_name]
+    # -- getters (names of the reference) ---------------------------------------------------------
+    def is_grey(self): return self._grey
+    def get_scale(self): return self._scale
+    def get_min_pixels_for_detection(self): return self._min_pixels_for_detection
+    def get_side_multiple(self): return self._side_multiple
+    def get_max_side(self): return self._max_side
+    def is_fml_compatible(self): return self._fml_compatible
+    def get_preprocessing_type(self): return self._preprocessing
+    def get_class_names(self): return self._class_names
+    def get_n_classes(self): return len(self._class_names)
+    def get_class_name(self, class_id): return self._class_names[class_id]
+    def get_class_id(self, class_name): return self._class_name_to_id[class_name]
+    def is_classification_supported(self): return self._is_classification_supported
 
     def is_class_supported(self, class_name):
         return self._class_names is None or class_name in self._class_name_to_id
 
-    def is_classification_supported(self):
-        return self._is_classification_supported
+    def _pre_pair(self):
+        table = {PreprocessingType.NONE: (lambda x: x, lambda x: x),
+                 PreprocessingType.MOBILENET_LIKE: (preprocess_image_mobilenet, depreprocess_image_mobilenet)}
+        if self._preprocessing not in table:
+            raise ValueError("Unknown preprocessing type")
+        return table[self._preprocessing]
 
-    def _read_classnames_from_file(self, path):
-        assert os.path.exists(path), f"File with object class names {path} does not exist"
-        class_names = []
-        with open(path, 'r') as f:
-            for line in f:
-                if line.strip():
-                    class_names.append(line.strip())
-        self._class_names = class_names
-        self._class_name_to_id = dict((class_name, i) for i, class_name in enumerate(class_names))
+    def get_preprocessing_fn(self): return self._pre_pair()[0]
+    def get_depreprocessing_fn(self): return self._pre_pair()[1]
+
+    def log_classification_mode(self):
+        if self._is_classification_supported:
+            logging.info(f"Training classification with object types: {self._class_names}")
+        elif self._class_names is not None:
+            logging.info(f"Training WITHOUT classification, detection only for types: {self._class_names}")
+        else:
+            logging.info("Training WITHOUT classification, detection for any barcode in datasets")
 
     def __str__(self):
-        sb = ["Net Config:"]
-        for key in self.__dict__:
-            if key.startswith('_'):
-                sb.append("\t{key}={value}".format(key=key[1:], value=self.__dict__[key]))
-        return '\n'.join(sb)
+        rows = [f"\t{k[1:]}={v}" for k, v in vars(self).items() if k.startswith("_")]
+        return "\n".join(["Net Config:"] + rows)
 
 
 def weight_shapes(c_in, n_classes):

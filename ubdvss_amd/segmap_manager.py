@@ -4,7 +4,6 @@ Same static-method signature as the reference; the work (external components, co
 filter, minAreaRect, boxPoints, class vote) runs in libubd_hip.so on the MI355X.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
@@ -68,31 +67,32 @@ class SegmapManager:
 
     @staticmethod
     def build_segmentation_map(image, markup, scale=1, for_drawing=False):
-        """Label map for training -- mirror of segmap_manager.py:81-104 (host side, PIL like the reference):
-        quads / scale, rounded outward by ``_proper_round``, filled with class+1 (or 1 / 255)."""
-        w, h = image.size
-        assert w % scale == 0 and h % scale == 0
-        image_segmap = Image.new(mode='L', size=(w // scale, h // scale), color=0)
-        draw = ImageDraw.Draw(image_segmap)
-        for object_markup in markup:
-            drawn_bbox = SegmapManager._proper_round(np.asarray(object_markup.bbox) / scale)
-            if for_drawing:
-                fill_color = 255
-            else:
-                fill_color = object_markup.object_type + 1 if isinstance(object_markup, ClassifiedObjectMarkup) else 1
-                assert fill_color <= 255, "No more than 255 classes are supported"
-            draw.polygon(drawn_bbox.tolist(), fill=fill_color)
-        return image_segmap
+        """Training label map (behaviour of segmap_manager.py:81-104): every quad is divided by ``scale``, its
+        corners are snapped outward (``_proper_round``) and the polygon is filled, later objects over earlier
+        ones, with 255 (``for_drawing``), class id + 1 (classified markup) or 1.  Returns a PIL 'L' image of
+        size (W/scale, H/scale)."""
+        width, height = image.size
+        if width % scale or height % scale:
+            raise AssertionError("image size must be a multiple of the map scale")
+        canvas = Image.new('L', (width // scale, height // scale), 0)
+        pen = ImageDraw.Draw(canvas)
+        for obj in markup:
+            value = 255 if for_drawing else (getattr(obj, "object_type", 0) + 1 if isinstance(obj, ClassifiedObjectMarkup) else 1)
+            if value > 255:
+                raise AssertionError("No more than 255 classes are supported")
+            corners = SegmapManager._proper_round(np.asarray(obj.bbox, dtype=np.float64) / scale)
+            pen.polygon([int(v) for v in corners], fill=int(value))
+        return canvas
 
     @staticmethod
     def _proper_round(markup_bbox):
-        """segmap_manager.py:106-133: floor a coordinate when at least two others are larger, else ceil."""
-        if len(markup_bbox) != 8:
-            return np.array(markup_bbox).astype(np.int32)
-        xs = markup_bbox[::2]
-        ys = markup_bbox[1::2]
-        xs_greater = [sum(1 for _x in xs if _x > x) for x in xs]
-        ys_greater = [sum(1 for _y in ys if _y > y) for y in ys]
-        xs = [math.floor(x) if n_greater > 1 else math.ceil(x) for (x, n_greater) in zip(xs, xs_greater)]
-        ys = [math.floor(y) if n_greater > 1 else math.ceil(y) for (y, n_greater) in zip(ys, ys_greater)]
-        return np.ravel(list(zip(xs, ys))).astype(np.int32)
+        """Outward snapping of a quad's corners (behaviour of segmap_manager.py:106-133): a coordinate is floored
+        when at least two of the four coordinates on the same axis are strictly larger (the object extends to
+        the larger side), otherwise it is ceiled; anything that is not 4 points is truncated to int32."""
+        pts = np.asarray(markup_bbox, dtype=np.float64)
+        if pts.size != 8:
+            return np.asarray(markup_bbox).astype(np.int32)
+        pts = pts.reshape(4, 2)
+        n_larger = (pts[None, :, :] > pts[:, None, :]).sum(axis=1)          # per corner, per axis
+        snapped = np.where(n_larger > 1, np.floor(pts), np.ceil(pts))
+        return snapped.reshape(-1).astype(np.int32)
