@@ -53,15 +53,28 @@ def _sep(x, dw, pw, b, stride, fml):
     return F.relu(F.conv2d(x, pw, b))
 
 
-def forward(x_nhwc, tw, fml_compatible=True):
-    """x_nhwc: torch (N,H,W,C).  tw: list from to_torch_weights.  Returns NHWC logits."""
+_ACT_DTYPES = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def _ste_round(t, act_dtype):
+    """Round to a 16-bit storage type with a straight-through gradient (the 16-bit train step stores rounded
+    activations / multiplies with a rounded kernel copy, and back-propagates as if the rounding were identity)."""
+    if act_dtype is None:
+        return t
+    return t + (t.detach().to(_ACT_DTYPES[act_dtype]).to(t.dtype) - t.detach())
+
+
+def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None):
+    """x_nhwc: torch (N,H,W,C).  tw: list from to_torch_weights.  Returns NHWC logits.
+    act_dtype "bfloat16"/"float16": hidden activations and the dense dilated kernels are rounded to that type
+    (straight-through in the backward pass) -- BASELINE.json configs[2..4]."""
     x = x_nhwc.permute(0, 3, 1, 2)
     i = 0
     for stride in (2, 1, 2):
-        x = _sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible)
+        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible), act_dtype)
         i += 3
     for d in DILATIONS:
-        x = F.relu(F.conv2d(x, tw[i], tw[i + 1], padding=d, dilation=d))
+        x = _ste_round(F.relu(F.conv2d(x, _ste_round(tw[i], act_dtype), tw[i + 1], padding=d, dilation=d)), act_dtype)
         i += 2
     x = F.conv2d(x, tw[i], tw[i + 1])
     return x.permute(0, 2, 3, 1)
@@ -125,12 +138,12 @@ def from_torch_grads(tw):
     return out
 
 
-def loss_and_grads(x, y_true, weights, classification_mode, fml_compatible=True, dtype=torch.float64):
+def loss_and_grads(x, y_true, weights, classification_mode, fml_compatible=True, dtype=torch.float64, act_dtype=None):
     """Returns (loss, logits, dlogits, [grads in Keras order])."""
     tw = to_torch_weights(weights, dtype, requires_grad=True)
     xt = torch.as_tensor(np.asarray(x), dtype=dtype)
     yt = torch.as_tensor(np.asarray(y_true), dtype=dtype)
-    logits = forward(xt, tw, fml_compatible)
+    logits = forward(xt, tw, fml_compatible, act_dtype)
     logits.retain_grad()
     loss = total_loss(yt, logits, classification_mode)
     loss.backward()

@@ -59,12 +59,33 @@ def test_bf16_full_batch_property_and_postprocess():
     assert out[4].shape == (4,)
 
 
-def test_training_refuses_16bit_for_now():
-    from ubdvss_amd import Trainer
-    cfg = NetConfig(grey=False)
-    m = Model(cfg, dtype="bfloat16", seed=1)
-    tr = Trainer(m)
-    x = torch.zeros((1, 64, 64, 3), device="cuda")
-    y = torch.zeros((1, 16, 16), dtype=torch.int32, device="cuda")
-    with pytest.raises(RuntimeError):
-        tr.backward_on_device(x, y)
+@pytest.mark.parametrize("dtype,tol", [("bfloat16", 4e-2), ("float16", 6e-3)])
+@pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 2, 64, 64), (1, 2, 2, 64, 96)])
+def test_train_step_16bit(dtype, tol, cin, ncls, n, hh, ww):
+    """configs[2] (bf16 train step) on small shapes: 16-bit activations + 16-bit MFMA forward, fp32 gradient
+    tensors / accumulation / master weights.  Oracle: fp64 torch autograd with the same storage rounding applied
+    straight-through.  Gate: loss and every weight-gradient tensor within `tol` (relative L2; bf16 ulp = 0.4 %)."""
+    from oracle import net_torch as otorch
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
+    model = Model(cfg, dtype=dtype, seed=0)
+    w = onet.init_weights(90 + cin, cin, ncls, bias_scale=0.2)
+    w[-2] = (w[-2] * 4).astype(np.float32)
+    model.set_weights(w)
+    labels = synthetic.rectangle_maps(91, n, hh // 4, ww // 4, n_classes=ncls)
+    x = synthetic.textured_images(92, labels, 4, cin).astype(np.float32) / 127.5 - 1.0
+    tr = Trainer(model, Adam())
+    tr.backward_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
+    loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, act_dtype=dtype)
+    l = tr.loss.cpu().numpy()
+    assert abs(l[0] - loss_ref) <= tol * abs(loss_ref), (l[0], loss_ref)
+    g = tr.grads.cpu().numpy().astype(np.float64)
+    off = 0
+    for (nm, _), gr in zip(onet.weight_shapes(cin, ncls), grads_ref):
+        k = gr.size
+        err = np.linalg.norm(g[off:off + k] - gr.reshape(-1)) / max(np.linalg.norm(gr), 1e-30)
+        assert err <= tol, (nm, err)
+        off += k
+    # and the optimiser step runs on the fp32 master weights
+    tr.apply_gradients()
+    assert torch.isfinite(model.params).all()

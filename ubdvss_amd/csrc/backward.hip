@@ -20,6 +20,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Activation element access: the saved forward activations are fp32 (UBD_F32) or 16-bit (UBD_BF16 / UBD_F16);
+// gradient tensors are always fp32.
+template <typename TX> __device__ __forceinline__ float ld_act(const void *base, size_t idx)
+{
+    return (float)((const TX *)base)[idx];
+}
+// six consecutive channels starting at element index idx (idx % 2 == 0)
+template <typename TX> __device__ __forceinline__ void ld_act6(const void *base, size_t idx, float (&v)[6])
+{
+    if constexpr (sizeof(TX) == 4) {
+        const f32x2 *p = (const f32x2 *)((const float *)base + idx);
+        const f32x2 a = p[0], c = p[1], d = p[2];
+        v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1]; v[4] = d[0]; v[5] = d[1];
+    } else {
+        const unsigned *p = (const unsigned *)((const unsigned short *)base + idx);
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+        v[0] = (float)__builtin_bit_cast(TX, (unsigned short)(w0 & 0xFFFFu)); v[1] = (float)__builtin_bit_cast(TX, (unsigned short)(w0 >> 16));
+        v[2] = (float)__builtin_bit_cast(TX, (unsigned short)(w1 & 0xFFFFu)); v[3] = (float)__builtin_bit_cast(TX, (unsigned short)(w1 >> 16));
+        v[4] = (float)__builtin_bit_cast(TX, (unsigned short)(w2 & 0xFFFFu)); v[5] = (float)__builtin_bit_cast(TX, (unsigned short)(w2 >> 16));
+    }
+}
+
 #define UBD_BWD_DGRAD_FLOATS (UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
 #define UBD_BWD_SEP_FLOATS (6 * 2 * 64)
 #define UBD_BWD_DIRECT_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
@@ -101,7 +123,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------ head
-__global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dlogits, const float *__restrict__ a9,
+template <typename TX>
+__global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dlogits, const void *__restrict__ a9,
                                                       const float *__restrict__ hk, float *__restrict__ g, long npix, int k_out)
 {
     __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
@@ -110,17 +133,23 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         float dl[UBD_MAX_CLASSES + 1];
         for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
-        const f32x4 *pa = (const f32x4 *)(a9 + p * UBD_C);
         f32x4 *pg = (f32x4 *)(g + p * UBD_C);
+        float av[UBD_C];
+#pragma unroll
+        for (int c6 = 0; c6 < 4; ++c6) {
+            float t6[6];
+            ld_act6<TX>(a9, (size_t)p * UBD_C + 6 * c6, t6);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) av[6 * c6 + e] = t6[e];
+        }
 #pragma unroll
         for (int c4 = 0; c4 < 6; ++c4) {
-            const f32x4 av = pa[c4];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float acc = 0.f;
                 for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[(c4 * 4 + e) * k_out + k], acc);
-                o[e] = av[e] > 0.f ? acc : 0.f;
+                o[e] = av[c4 * 4 + e] > 0.f ? acc : 0.f;
             }
             pg[c4] = o;
         }
@@ -128,7 +157,8 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
 }
 
 // dhk[c][k] = sum_p a9[p][c] dl[p][k]; dhb[k] = sum_p dl[p][k]  (row 24 of the A operand is all ones)
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict__ a9, const float *__restrict__ dlogits,
+template <typename TX>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict__ a9, const float *__restrict__ dlogits,
                                                          float *__restrict__ g_hk, float *__restrict__ g_hb, long npix, int k_out)
 {
     const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
@@ -144,8 +174,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
         for (int u = 0; u < 8; ++u) {                          // 8 k-steps of loads in flight
             const long p = (sb + u) * 4 + k;
             const bool ok = (sb + u < s1) && p < npix;
-            a0[u] = ok ? a9[p * UBD_C + m] : 0.f;
-            a1[u] = ok ? (m < 8 ? a9[p * UBD_C + 16 + m] : (m == 8 ? 1.f : 0.f)) : 0.f;
+            a0[u] = ok ? ld_act<TX>(a9, (size_t)p * UBD_C + m) : 0.f;
+            a1[u] = ok ? (m < 8 ? ld_act<TX>(a9, (size_t)p * UBD_C + 16 + m) : (m == 8 ? 1.f : 0.f)) : 0.f;
             b0[u] = (ok && m < k_out) ? dlogits[p * k_out + m] : 0.f;
             b1[u] = (ok && 16 + m < k_out) ? dlogits[p * k_out + 16 + m] : 0.f;
         }
@@ -199,17 +229,20 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
 #define WG_XW (WG_TW + 2)
 #define WG_XPIX ((WG_TH + 2) * WG_XW)          // 180
 #define WG_GPIX (WG_TH * WG_TW)                // 128
-#define WG_CHUNKS ((WG_XPIX + WG_GPIX) * 6)    // 1848 16-byte chunks
-#define WG_ROUNDS ((WG_CHUNKS + 255) / 256)    // 8
+#define WG_ROUNDS 8                            // (180 * 6 + 128 * 6 + 255) / 256 with fp32 activations (7 with 16-bit)
 #define WG_BUF_FLOATS (WG_ROUNDS * 256 * 4)    // 8192 floats = 32 KiB
 
-__global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gz,
+template <typename TX>
+__global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restrict__ x, const float *__restrict__ gz,
                                                            float *__restrict__ partials, int n, int h,
                                                            int w, int d)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF_FLOATS];     // 64 KiB: two tile buffers / final reduction
     const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int XCH = (int)sizeof(TX) * UBD_C / 16;              // 16-byte chunks per X pixel: 6 (fp32) or 3 (16-bit)
+    constexpr int WG_CHUNKS = WG_XPIX * XCH + WG_GPIX * 6;
+    constexpr int XBYTES = WG_XPIX * UBD_C * (int)sizeof(TX);      // G tile starts here (multiple of 16)
 
     // A-operand rows of the 14 M-tiles: dword offset of (tap, ci) relative to the X-tile pixel of the output position
     int aoff[14];
@@ -238,27 +271,29 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restri
         return r;
     };
     // chunk c of the combined tile: c < XPIX*6 -> X pixel (with halo), else G pixel; returns image coords
+    // chunk c of the combined tile: X pixels (with halo, XCH chunks each) first, then G pixels (6 chunks each)
     auto chunk_src = [&](const item_t &I, int c, bool &is_x, int &gy, int &gx, int &part) {
         c = c < WG_CHUNKS ? c : WG_CHUNKS - 1;
-        const int pix = c / 6;
-        part = c - pix * 6;
-        is_x = pix < WG_XPIX;
+        is_x = c < WG_XPIX * XCH;
         int sy, sx;
-        if (is_x) { sy = pix / WG_XW - 1; sx = pix % WG_XW - 1; }
-        else { const int gp = pix - WG_XPIX; sy = gp / WG_TW; sx = gp % WG_TW; }
+        if (is_x) { const int pix = c / XCH; part = c - pix * XCH; sy = pix / WG_XW - 1; sx = pix % WG_XW - 1; }
+        else { const int cg = c - WG_XPIX * XCH; const int gp = cg / 6; part = cg - gp * 6; sy = gp / WG_TW; sx = gp % WG_TW; }
         gy = I.ry + (I.sy0 + sy) * d;
         gx = I.rx + (I.sx0 + sx) * d;
     };
     auto dma_item = [&](int it, float *buf) {
         const item_t I = decode(it);
+        constexpr int ROUNDS = (WG_CHUNKS + 255) / 256;
 #pragma unroll
-        for (int rd = 0; rd < WG_ROUNDS; ++rd) {
+        for (int rd = 0; rd < ROUNDS; ++rd) {
             const int cbase = rd * 256 + wid * 64;
             bool is_x; int gy, gx, part;
             chunk_src(I, cbase + lane, is_x, gy, gx, part);
             gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                 // clamped; out-of-image pixels are zeroed later
             gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-            const float *src = (is_x ? x : gz) + (((size_t)I.img * h + gy) * w + gx) * UBD_C + part * 4;
+            const size_t pixel = ((size_t)I.img * h + gy) * w + gx;
+            const char *src = is_x ? (const char *)x + pixel * (UBD_C * sizeof(TX)) + part * 16
+                                   : (const char *)gz + pixel * (UBD_C * sizeof(float)) + part * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, 0, 0);
         }
@@ -278,12 +313,13 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restri
         if (ragged) {
             for (int pix = threadIdx.x; pix < WG_XPIX + WG_GPIX; pix += 256) {
                 bool is_x; int gy, gx, part;
-                chunk_src(I, pix * 6, is_x, gy, gx, part);
+                const bool xp_ = pix < WG_XPIX;
+                chunk_src(I, xp_ ? pix * XCH : WG_XPIX * XCH + (pix - WG_XPIX) * 6, is_x, gy, gx, part);
                 if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
-                    f32x4 *z = (f32x4 *)(buf + pix * UBD_C);
+                    f32x4 *z = (f32x4 *)((char *)buf + (xp_ ? pix * UBD_C * (int)sizeof(TX) : XBYTES + (pix - WG_XPIX) * UBD_C * 4));
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q6 = 0; q6 < 6; ++q6) z[q6] = zero;
+                    const int nq = xp_ ? XCH : 6;
+                    for (int q6 = 0; q6 < nq; ++q6) z[q6] = zero;
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -292,18 +328,19 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restri
         // k-steps: (row py, group of 4 consecutive sub-pixels); this wave takes every 4th
         const int rows_eff = min(WG_TH, sh - I.sy0), grp_eff = (min(WG_TW, sw - I.sx0) + 3) >> 2;
         const int nsteps = rows_eff * grp_eff;
-        const float *xt = buf, *gt = buf + WG_XPIX * UBD_C;
+        const TX *xt = (const TX *)buf;
+        const float *gt = (const float *)((const char *)buf + XBYTES);
         for (int s = wid; s < nsteps; s += 4) {
             const int py = (int)((unsigned)s / (unsigned)grp_eff), pg = s - py * grp_eff;
             const int px = pg * 4 + k;                                 // this lane's sub-pixel column
-            const float *xp = xt + (py * WG_XW + px) * UBD_C;          // X-tile pixel of tap (0,0)
+            const TX *xp = xt + (py * WG_XW + px) * UBD_C;             // X-tile pixel of tap (0,0)
             const float *gp = gt + (py * WG_TW + px) * UBD_C;
             const float b0 = gp[m];
             const float b1 = m < 8 ? gp[16 + m] : 0.f;
             float a[14];
 #pragma unroll
-            for (int mt = 0; mt < 13; ++mt) a[mt] = xp[aoff[mt]];
-            a[13] = row13_real ? xp[aoff[13]] : (row13_ones ? 1.f : 0.f);
+            for (int mt = 0; mt < 13; ++mt) a[mt] = (float)xp[aoff[mt]];
+            a[13] = row13_real ? (float)xp[aoff[13]] : (row13_ones ? 1.f : 0.f);
 #pragma unroll
             for (int mt = 0; mt < 14; ++mt) {
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
@@ -332,26 +369,27 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const float *__restri
 // Persistent blocks over output tiles of 16 columns x TH rows (as the forward sepconv_kernel): the input
 // patch and the G tile are staged in LDS (24 channels: LDS-DMA, clamped + zero-fixed at the image border;
 // 1/3 channels: converted on the way through registers), every tap and both G layouts are then read from LDS.
-template <int CIN, int STRIDE> struct sepb_cfg {
+template <int CIN, int STRIDE, int XB> struct sepb_cfg {          // XB = bytes per element of a 24-channel input
     static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int XPIX = PH * PW;
     static constexpr int GPIX = TH * 16;
-    static constexpr int XFLOATS = (CIN == UBD_C) ? XPIX * UBD_C : (XPIX * CIN + 3) / 4 * 4;
-    static constexpr int CHUNKS = ((CIN == UBD_C) ? XPIX * 6 : 0) + GPIX * 6;         // DMA chunks (X if 24 ch, then G)
+    static constexpr int XCH = XB * UBD_C / 16;                                        // DMA chunks per X pixel
+    static constexpr int XFLOATS = (CIN == UBD_C) ? XPIX * XCH * 4 : (XPIX * CIN + 3) / 4 * 4;
+    static constexpr int CHUNKS = ((CIN == UBD_C) ? XPIX * XCH : 0) + GPIX * 6;       // DMA chunks (X if 24 ch, then G)
     static constexpr int ROUNDS = (CHUNKS + 255) / 256;
     static constexpr int GOFF = (CIN == UBD_C) ? 0 : XFLOATS;                          // float offset of the DMA region
     static constexpr int LDS_FLOATS = GOFF + ROUNDS * 256 * 4;
 };
 
-template <int CIN, int STRIDE, int IN_U8>
+template <int CIN, int STRIDE, int IN_U8, typename TX>
 __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
                                                       const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
                                                       int OH, int OW, int pad_lo, float pre_sub, float pre_div)
 {
-    using C = sepb_cfg<CIN, STRIDE>;
+    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;           // tiles of the dDW product
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;          // M tiles of the dpw product (CIN rows + ones row)
@@ -361,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
     const int i = lane & 15, q = lane >> 4;
     const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
     float *xpatch = lds;                                                // CIN==24: part of the DMA region
-    float *gtile = lds + C::GOFF + ((CIN == UBD_C) ? C::XPIX * UBD_C : 0);
+    float *gtile = lds + C::GOFF + ((CIN == UBD_C) ? C::XPIX * C::XCH * 4 : 0);
 
     float dwk[9][CPL];
 #pragma unroll
@@ -399,21 +437,21 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
             const int cbase = rd * 256 + wid * 64;
             int c = cbase + lane;
             c = c < C::CHUNKS ? c : C::CHUNKS - 1;
-            const float *src;
-            if (CIN == UBD_C && c < C::XPIX * 6) {
-                const int pix = c / 6, part = c - pix * 6;
+            const char *src;
+            if (CIN == UBD_C && c < C::XPIX * C::XCH) {
+                const int pix = c / C::XCH, part = c - pix * C::XCH;
                 const int pr = pix / C::PW, pc = pix - pr * C::PW;
                 int gy = iy0 + pr, gx = ix0 + pc;
                 gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
                 gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-                src = (const float *)xin + (((size_t)img * H + gy) * W + gx) * UBD_C + part * 4;
+                src = (const char *)xin + (((size_t)img * H + gy) * W + gx) * (UBD_C * sizeof(TX)) + part * 16;
             } else {
-                const int cg = c - ((CIN == UBD_C) ? C::XPIX * 6 : 0);
+                const int cg = c - ((CIN == UBD_C) ? C::XPIX * C::XCH : 0);
                 const int pix = cg / 6, part = cg - pix * 6;
                 int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
                 gy = gy >= OH ? OH - 1 : gy;
                 gx = gx >= OW ? OW - 1 : gx;
-                src = G + (((size_t)img * OH + gy) * OW + gx) * UBD_C + part * 4;
+                src = (const char *)(G + (((size_t)img * OH + gy) * OW + gx) * UBD_C) + part * 16;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(lds + C::GOFF + cbase * 4), 16, 0, 0);
@@ -443,9 +481,9 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
                         const int pr = pix / C::PW, pc = pix - pr * C::PW;
                         const int gy = iy0 + pr, gx = ix0 + pc;
                         if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                            f32x4 *z = (f32x4 *)(xpatch + pix * UBD_C);
+                            f32x4 *z = (f32x4 *)((char *)xpatch + pix * (UBD_C * (int)sizeof(TX)));
 #pragma unroll
-                            for (int k6 = 0; k6 < 6; ++k6) z[k6] = zero;
+                            for (int k6 = 0; k6 < C::XCH; ++k6) z[k6] = zero;
                         }
                     }
                 if (gborder)
@@ -474,12 +512,13 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int t = ky * 3 + kx;
-                    const float *p = xpatch + ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    const int pe = ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    const float *p = xpatch + pe;
                     if constexpr (CIN == UBD_C) {
-                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
-                        dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]); dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
-                        dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]); dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
-                        dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]); dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
+                        float v[6];
+                        ld_act6<TX>(xpatch, pe, v);
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]);
                     } else {
                         dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);        // dwk is zero for lanes without a channel
                     }
@@ -510,12 +549,13 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int t = ky * 3 + kx;
-                    const float *p = xpatch + ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    const int pe = ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    const float *p = xpatch + pe;
                     if constexpr (CIN == UBD_C) {
-                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
-                        ddw[t][0] = fmaf(v0[0], ddwv[0], ddw[t][0]); ddw[t][1] = fmaf(v0[1], ddwv[1], ddw[t][1]);
-                        ddw[t][2] = fmaf(v1[0], ddwv[2], ddw[t][2]); ddw[t][3] = fmaf(v1[1], ddwv[3], ddw[t][3]);
-                        ddw[t][4] = fmaf(v2[0], ddwv[4], ddw[t][4]); ddw[t][5] = fmaf(v2[1], ddwv[5], ddw[t][5]);
+                        float v[6];
+                        ld_act6<TX>(xpatch, pe, v);
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
                     } else {
                         ddw[t][0] = fmaf(ch_ok ? p[0] : 0.f, ddwv[0], ddw[t][0]);
                     }
@@ -590,8 +630,8 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 }
 
 // G_below[q][c] = (sum_t dDW[(q + pad - t)/s][c] dw[t][c]) * (X[q][c] > 0)   (24-channel layers only)
-template <int STRIDE>
-__global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ dDW, const float *__restrict__ xmask,
+template <int STRIDE, typename TX>
+__global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ dDW, const void *__restrict__ xmask,
                                                      float *__restrict__ gout, const float *__restrict__ fwdfrag, int n, int H,
                                                      int W, int OH, int OW, int pad_lo)
 {
@@ -634,25 +674,29 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
             }
         }
         const size_t e = (((size_t)img * H + iy) * W + ix) * UBD_C + 6 * q;
-        const f32x2 *pm = (const f32x2 *)(xmask + e);
-        const f32x2 m0 = pm[0], m1 = pm[1], m2 = pm[2];
+        float mk[6];
+        ld_act6<TX>(xmask, e, mk);
         f32x2 *po = (f32x2 *)(gout + e);
-        po[0] = (f32x2){m0[0] > 0.f ? acc[0] : 0.f, m0[1] > 0.f ? acc[1] : 0.f};
-        po[1] = (f32x2){m1[0] > 0.f ? acc[2] : 0.f, m1[1] > 0.f ? acc[3] : 0.f};
-        po[2] = (f32x2){m2[0] > 0.f ? acc[4] : 0.f, m2[1] > 0.f ? acc[5] : 0.f};
+        po[0] = (f32x2){mk[0] > 0.f ? acc[0] : 0.f, mk[1] > 0.f ? acc[1] : 0.f};
+        po[1] = (f32x2){mk[2] > 0.f ? acc[2] : 0.f, mk[3] > 0.f ? acc[3] : 0.f};
+        po[2] = (f32x2){mk[4] > 0.f ? acc[4] : 0.f, mk[5] > 0.f ? acc[5] : 0.f};
     }
 }
 
 // ------------------------------------------------------------------------------------ host
+// Workspace of a train step: forward layout (all activations kept; fp32 or 16-bit), then backward fragments,
+// logits, dlogits, fp32 gradient ping-pong buffers, loss scratch, partial-sum matrix.
 struct train_layout {
-    ubd_fwd_layout fwd;
+    ubd_fwd_layout fwd;            // dtype == UBD_F32
+    ubd_fwd16_layout fwd16;        // 16-bit activations
     size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, off_partials, total;
 };
 
 static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train_layout *T)
 {
-    ubd_fwd_layout_compute(h, n, H, W, 1, &T->fwd);
-    size_t off = T->fwd.total;
+    size_t off;
+    if (h->cfg.dtype == UBD_F32) { ubd_fwd_layout_compute(h, n, H, W, 1, &T->fwd); off = T->fwd.total; }
+    else { ubd_fwd16_layout_compute(n, H, W, 1, &T->fwd16); off = T->fwd16.total; }
     const size_t small = ubd_align_up((size_t)n * (H / 4) * (W / 4) * UBD_C * sizeof(float), 256);
     const size_t big = ubd_align_up((size_t)n * (H / 2) * (W / 2) * UBD_C * sizeof(float), 256);
     const size_t lg = ubd_align_up((size_t)n * (H / 4) * (W / 4) * h->k_out * sizeof(float), 256);
@@ -677,48 +721,37 @@ extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int heig
     return T.total;
 }
 
-template <int CIN, int STRIDE>
+template <int CIN, int STRIDE, typename TX>
 static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
                            const float *bfrag, float *g_dw, float *g_pw, float *g_b, float *partials, int n, int H, int W,
                            int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
 {
-    const int th = sepb_cfg<CIN, STRIDE>::TH;
+    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
+    const int th = C::TH;
     const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
-    const size_t lds_bytes = sepb_cfg<CIN, STRIDE>::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float);
+    const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float);
     int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
     if (grid > tiles) grid = (int)tiles;
     if (in_u8)
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     else
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + 63) / 64), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
-extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
-                              const int32_t *y_true, int n, int height, int width, float *grads, float *loss,
-                              void *workspace, size_t workspace_bytes, void *stream)
+// Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9
+// outputs at quarter resolution; wfrag = forward fp32 fragments (depthwise / pointwise per-lane weights).
+template <typename TX>
+static int backward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
+                         int W, const void *a1, const void *a2, const void *const *acts, const float *wfrag, float *dlogits,
+                         float *grads, char *ws, const train_layout &T, hipStream_t st)
 {
-    UBD_REQUIRE(h && params && images && y_true && grads && loss && workspace, "ubd_train_step: null argument");
-    UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_train_step: only UBD_F32 in this build");
-    train_layout T;
-    train_layout_compute(h, n, height, width, &T);
-    UBD_REQUIRE(workspace_bytes >= T.total, "ubd_train_step: workspace too small (%zu < %zu)", workspace_bytes, T.total);
-    hipStream_t st = (hipStream_t)stream;
-    char *ws = (char *)workspace;
-    const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
-    float *logits = (float *)(ws + T.off_logits), *dlogits = (float *)(ws + T.off_dlogits);
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    const int act_dtype = h->cfg.dtype;
     float *bfrag = (float *)(ws + T.off_bfrag);
-    const float *wfrag = (const float *)(ws + T.fwd.off_wfrag);
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
-
-    // forward (activations kept), loss + dlogits
-    int rc = ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, T.fwd, st);
-    if (rc) return rc;
     const long npix = (long)n * H4 * W4;
-    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
-    if (rc) return rc;
-
     UBD_CHECK_HIP(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), st));
     pack_bwd_args pa;
     for (int s = 0; s < 3; ++s) pa.off_sep_pw[s] = h->off_sep_pw[s];
@@ -727,9 +760,6 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
     if (h->use_wino) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
 
-    const float *a1 = (const float *)(ws + T.fwd.off_a1), *a2 = (const float *)(ws + T.fwd.off_a2);
-    const float *acts[7];
-    for (int k = 0; k < 7; ++k) acts[k] = (const float *)(ws + T.fwd.off_acts[k]);     // L3, L4..L9 outputs
     float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
     float *ddw3 = (float *)(ws + T.off_ddw3);
     float *gb[2] = {(float *)(ws + T.off_gb[0]), (float *)(ws + T.off_gb[1])};
@@ -738,29 +768,29 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     int grid = (int)((npix + 255) / 256);
     if (grid > h->num_cus * 8) grid = h->num_cus * 8;
     // head
-    hipLaunchKernelGGL(head_dx_kernel, dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
+    hipLaunchKernelGGL((head_dx_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
     {
         const long nsteps = (npix + 3) / 4;
         int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
-        hipLaunchKernelGGL(head_wgrad_kernel, dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
+        hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
     }
     // dilated layers, top to bottom
     int cur = 0;
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
-        const float *X = acts[k];                               // input of dilated layer k (= output of the layer below)
+        const void *X = acts[k];                                // input of dilated layer k (= output of the layer below)
         {
             const int dd = UBD_DILATIONS[k];
             const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + WG_TH - 1) / WG_TH) * (((W4 + dd - 1) / dd + WG_TW - 1) / WG_TW);
             int gw = h->num_cus * 2;
             if (gw > items) gw = (int)items;
-            hipLaunchKernelGGL(dil_wgrad_kernel, dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
+            hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + 63) / 64), dim3(256), 0, st, partials, gw, 217 * UBD_C,
                                grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
         }
         if (h->use_wino)
-            ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
+            ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, act_dtype, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         else
-            ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
+            ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, (const float *)X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         cur ^= 1;
     }
     // separable layers
@@ -768,23 +798,61 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
     const float *bs0 = bfrag + UBD_BWD_DGRAD_FLOATS, *bs1 = bs0 + UBD_BWD_SEP_FLOATS, *bs2 = bs1 + UBD_BWD_SEP_FLOATS;
     // L3: input a2 (H2 x W2), output H4 x W4, G = gq[cur]
-    launch_sep_bwd<UBD_C, 2>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    launch_sep_bwd<UBD_C, 2, TX>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
     {
         const long tiles = (long)n * H2 * ((W2 + 15) / 16);
         const int g3 = ubd_grid_for(tiles, h->num_cus, 4, 8);
-        hipLaunchKernelGGL(sep_dx_kernel<2>, dim3(g3), dim3(256), 0, st, ddw3, a2, gb[0], sf2, n, H2, W2, H4, W4, pad_s2);
+        hipLaunchKernelGGL((sep_dx_kernel<2, TX>), dim3(g3), dim3(256), 0, st, ddw3, a2, gb[0], sf2, n, H2, W2, H4, W4, pad_s2);
         // L2: input a1, output H2 x W2, G = gb[0]
-        launch_sep_bwd<UBD_C, 1>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
-        hipLaunchKernelGGL(sep_dx_kernel<1>, dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
+        launch_sep_bwd<UBD_C, 1, TX>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+        hipLaunchKernelGGL((sep_dx_kernel<1, TX>), dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
     }
-    // L1: input = images, no data gradient
+    // L1: input = images (fp32 / uint8), no data gradient
     float sub = 0.f, div = 1.f;
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
     if (h->cfg.c_in == 1)
-        launch_sep_bwd<1, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<1, 2, float>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     else
-        launch_sep_bwd<3, 2>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<3, 2, float>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                              const int32_t *y_true, int n, int height, int width, float *grads, float *loss,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    UBD_REQUIRE(h && params && images && y_true && grads && loss && workspace, "ubd_train_step: null argument");
+    UBD_REQUIRE(n > 0 && height > 0 && width > 0 && (height % 4) == 0 && (width % 4) == 0, "ubd_train_step: height and width must be positive multiples of 4");
+    UBD_REQUIRE(h->cfg.dtype == UBD_F32 || h->use_wino, "ubd_train_step: 16-bit activations need the Winograd data-gradient kernel (unset UBD_DILCONV=direct)");
+    train_layout T;
+    train_layout_compute(h, n, height, width, &T);
+    UBD_REQUIRE(workspace_bytes >= T.total, "ubd_train_step: workspace too small (%zu < %zu)", workspace_bytes, T.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *logits = (float *)(ws + T.off_logits), *dlogits = (float *)(ws + T.off_dlogits);
+    const long npix = (long)n * (height / 4) * (width / 4);
+    const void *acts[7];
+    int rc;
+    if (h->cfg.dtype == UBD_F32) {
+        rc = ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, ws, T.fwd, st);
+        if (rc) return rc;
+        rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
+        if (rc) return rc;
+        for (int k = 0; k < 7; ++k) acts[k] = ws + T.fwd.off_acts[k];
+        return backward_impl<float>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd.off_a1, ws + T.fwd.off_a2,
+                                    acts, (const float *)(ws + T.fwd.off_wfrag), dlogits, grads, ws, T, st);
+    }
+    UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_train_step: bad in_dtype %d", in_dtype);
+    rc = ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, height, width, logits, ws, T.fwd16, st);
+    if (rc) return rc;
+    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
+    if (rc) return rc;
+    for (int k = 0; k < 7; ++k) acts[k] = ws + T.fwd16.off_acts[k];
+    if (h->cfg.dtype == UBD_BF16)
+        return backward_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd16.off_a1, ws + T.fwd16.off_a2,
+                                     acts, (const float *)(ws + T.fwd16.off_wfrag32), dlogits, grads, ws, T, st);
+    return backward_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd16.off_a1, ws + T.fwd16.off_a2,
+                                   acts, (const float *)(ws + T.fwd16.off_wfrag32), dlogits, grads, ws, T, st);
 }

@@ -73,9 +73,13 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
                   char *ws, hipStream_t st);
 extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
-void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
+void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,
                              const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st);
 size_t ubd_forward16_workspace_bytes(int n, int H, int W);
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st);
+struct ubd_fwd16_layout { size_t off_wfrag32, off_wfrag16, off_a1, off_a2, off_acts[7], total; };
+void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layout *L);
+int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
+                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st);

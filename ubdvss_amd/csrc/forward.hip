@@ -616,7 +616,7 @@ static void launch_dil(const ubd_handle *h, const float *params, const float *wf
                        int n, int H4, int W4, hipStream_t st)
 {
     if (h->use_wino) {
-        ubd_launch_dilconv_wino(h, 0, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k],
+        ubd_launch_dilconv_wino(h, 0, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k], UBD_F32,
                                 UBD_DILATIONS[k], in, out, n, H4, W4, st);
         return;
     }

@@ -271,9 +271,7 @@ __global__ __launch_bounds__(256) void head16_kernel(const unsigned short *__res
 }
 
 // ------------------------------------------------------------------------------------ host
-struct fwd16_layout { size_t off_wfrag32, off_wfrag16, off_a1, off_a2, off_b[2], total; };
-
-static void fwd16_layout_compute(int n, int H, int W, fwd16_layout *L)
+void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layout *L)
 {
     size_t off = 0;
     L->off_wfrag32 = off; off += ubd_align_up((size_t)UBD_FWD_DIRECT_FLOATS * sizeof(float), 256);
@@ -282,15 +280,20 @@ static void fwd16_layout_compute(int n, int H, int W, fwd16_layout *L)
     const size_t b = ubd_align_up((size_t)n * (H / 4) * (W / 4) * UBD_C * 2, 256);
     L->off_a1 = off; off += a;
     L->off_a2 = off; off += a;
-    L->off_b[0] = off; off += b;
-    L->off_b[1] = off; off += b;
+    if (training) {
+        for (int k = 0; k < 7; ++k) { L->off_acts[k] = off; off += b; }
+    } else {
+        const size_t b0 = off, b1 = off + b;
+        off += 2 * b;
+        for (int k = 0; k < 7; ++k) L->off_acts[k] = (k & 1) ? b1 : b0;
+    }
     L->total = off;
 }
 
 size_t ubd_forward16_workspace_bytes(int n, int H, int W)
 {
-    fwd16_layout L;
-    fwd16_layout_compute(n, H, W, &L);
+    ubd_fwd16_layout L;
+    ubd_fwd16_layout_compute(n, H, W, 0, &L);
     return L.total;
 }
 
@@ -305,15 +308,12 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
 
 template <typename T>
 static int forward16_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n,
-                          int H, int W, float *logits, char *ws, hipStream_t st)
+                          int H, int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
 {
-    fwd16_layout L;
-    fwd16_layout_compute(n, H, W, &L);
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
     float *wfrag = (float *)(ws + L.off_wfrag32);
     unsigned *wfrag16 = (unsigned *)(ws + L.off_wfrag16);
     unsigned short *a1 = (unsigned short *)(ws + L.off_a1), *a2 = (unsigned short *)(ws + L.off_a2);
-    unsigned short *bb[2] = {(unsigned short *)(ws + L.off_b[0]), (unsigned short *)(ws + L.off_b[1])};
     ubd_launch_pack_direct(h, params, wfrag, st);                      // fp32 depthwise / pointwise fragments
     hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0]);
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
@@ -330,31 +330,40 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
         else launch_sep16<3, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
     }
     launch_sep16<UBD_C, 1, 2, T>(h, a1, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
-    launch_sep16<UBD_C, 2, 2, T>(h, a2, bb[0], sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
+    launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
     const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 2);
     const long tiles = (long)n * H4 * ((W4 + 15) / 16);
-    int cur = 0;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
         int grid = ubd_grid_for(tiles, h->num_cus, 4, 4);
         grid = (grid + 7) / 8 * 8;
-        hipLaunchKernelGGL((dilconv16_kernel<T>), dim3(grid), dim3(256), 0, st, bb[cur], bb[cur ^ 1],
+        unsigned short *nxt = (unsigned short *)(ws + L.off_acts[k + 1]);
+        hipLaunchKernelGGL((dilconv16_kernel<T>), dim3(grid), dim3(256), 0, st, cur, nxt,
                            (const u32x4 *)(wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32), params + h->off_dil_b[k], n, H4, W4,
                            UBD_DILATIONS[k], in_bytes);
-        cur ^= 1;
+        cur = nxt;
     }
     const long npix = (long)n * H4 * W4;
     int hgrid = (int)((npix + 255) / 256);
     if (hgrid > h->num_cus * 8) hgrid = h->num_cus * 8;
-    hipLaunchKernelGGL((head16_kernel<T>), dim3(hgrid), dim3(256), 0, st, bb[cur], logits, params + h->off_head_k, params + h->off_head_b, npix, h->k_out);
+    hipLaunchKernelGGL((head16_kernel<T>), dim3(hgrid), dim3(256), 0, st, cur, logits, params + h->off_head_k, params + h->off_head_b, npix, h->k_out);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
+                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
+{
+    UBD_REQUIRE((size_t)n * (H / 4) * (W / 4) * UBD_C * 2 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
+    if (h->cfg.dtype == UBD_BF16) return forward16_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
+    return forward16_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
 }
 
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st)
 {
     UBD_REQUIRE(ws_bytes >= ubd_forward16_workspace_bytes(n, H, W), "ubd_forward: workspace too small for the 16-bit path");
-    UBD_REQUIRE((size_t)n * (H / 4) * (W / 4) * UBD_C * 2 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
-    if (h->cfg.dtype == UBD_BF16) return forward16_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, st);
-    return forward16_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, st);
+    ubd_fwd16_layout L;
+    ubd_fwd16_layout_compute(n, H, W, 0, &L);
+    return ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
 }

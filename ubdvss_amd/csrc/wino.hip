@@ -36,6 +36,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct wino_pack_args {
     size_t off_dil_k[UBD_NUM_DIL];
     int transpose;
+    int round_dtype;      // UBD_F32: exact; UBD_BF16 / UBD_F16: kernel values rounded to that type first (the copy the
+                          // 16-bit forward pass multiplies with), so that the data gradient matches the forward pass
 };
 
 __global__ void pack_wino_kernel(const float *__restrict__ params, float *__restrict__ out, wino_pack_args a)
@@ -54,8 +56,10 @@ __global__ void pack_wino_kernel(const float *__restrict__ params, float *__rest
             const float *wk = params + a.off_dil_k[L];
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float g = a.transpose ? wk[(((2 - ky) * 3 + (2 - kx)) * UBD_C + co) * UBD_C + ci]
-                                                : wk[((ky * 3 + kx) * UBD_C + ci) * UBD_C + co];
+                    float g = a.transpose ? wk[(((2 - ky) * 3 + (2 - kx)) * UBD_C + co) * UBD_C + ci]
+                                          : wk[((ky * 3 + kx) * UBD_C + ci) * UBD_C + co];
+                    if (a.round_dtype == UBD_BF16) g = (float)(__bf16)g;
+                    else if (a.round_dtype == UBD_F16) g = (float)(_Float16)g;
                     v += G[ta][ky] * G[tb][kx] * g;
                 }
         }
@@ -68,6 +72,7 @@ void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, 
     wino_pack_args a;
     for (int k = 0; k < UBD_NUM_DIL; ++k) a.off_dil_k[k] = h->off_dil_k[k];
     a.transpose = transpose;
+    a.round_dtype = transpose ? h->cfg.dtype : UBD_F32;
     hipLaunchKernelGGL(pack_wino_kernel, dim3(96), dim3(256), 0, st, params, out, a);
 }
 
@@ -76,18 +81,20 @@ struct wsamples {
     f32x2 v2[4][4];
 };
 
-template <int EPI>
+// TAUX: element type of the ReLU-mask source (EPI 1): fp32 or a 16-bit activation type
+template <int EPI, typename TAUX>
 __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               const float *__restrict__ ufrag,
-                                                              const float *__restrict__ aux, int n, int h, int w, int d,
+                                                              const void *__restrict__ aux_, int n, int h, int w, int d,
                                                               int log2d, unsigned in_bytes)
 {
+    const TAUX *__restrict__ aux = (const TAUX *)aux_;
     __shared__ __attribute__((aligned(16))) float s_u[UBD_WINO_FRAG_FLOATS];       // 48 KiB
     for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
     float b0 = 0.f, b1 = 0.f;
-    if constexpr (EPI == 0) { b0 = aux[i]; b1 = (i < 8) ? aux[16 + i] : 0.f; }
+    if constexpr (EPI == 0) { b0 = ((const float *)aux_)[i]; b1 = (i < 8) ? ((const float *)aux_)[16 + i] : 0.f; }
     __syncthreads();
 
     const int dm1 = d - 1;
@@ -230,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
                                 y[e + co] = fmaxf(Y[rr][c][0][r] + b0, 0.f);
                                 if (co < 8) y[e + 16 + co] = fmaxf(Y[rr][c][1][r] + b1, 0.f);
                             } else {
-                                y[e + co] = aux[e + co] > 0.f ? Y[rr][c][0][r] : 0.f;
-                                if (co < 8) y[e + 16 + co] = aux[e + 16 + co] > 0.f ? Y[rr][c][1][r] : 0.f;
+                                y[e + co] = (float)aux[e + co] > 0.f ? Y[rr][c][0][r] : 0.f;
+                                if (co < 8) y[e + 16 + co] = (float)aux[e + 16 + co] > 0.f ? Y[rr][c][1][r] : 0.f;
                             }
                         }
                     }
@@ -246,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // frag: this layer's UBD_WINO_FRAG_FLOATS packed floats; aux: bias (epi 0) or mask source (epi 1)
-void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
+// aux_dtype: element type of `aux` for epi 1 (UBD_F32 / UBD_BF16 / UBD_F16); epi 0 ignores it (bias is fp32)
+void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,
                              const float *in, float *out, int n, int H4, int W4, hipStream_t st)
 {
     const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
@@ -256,7 +264,11 @@ void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, co
     int grid = ubd_grid_for(groups, h->num_cus, 4, 2);
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
-        hipLaunchKernelGGL(dilconv_wino_kernel<0>, dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+    else if (aux_dtype == UBD_F32)
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+    else if (aux_dtype == UBD_BF16)
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, __bf16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
     else
-        hipLaunchKernelGGL(dilconv_wino_kernel<1>, dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, _Float16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
 }
