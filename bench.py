@@ -138,14 +138,15 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH * args.steps / elapsed
 
-    # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), fp32, batch/GPU = --train-batch
-    train = None
-    if not args.no_train:
+    # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), batch/GPU = --train-batch:
+    #      configs[2] / configs[3] name bf16 activations (fp32 master weights, fp32 accumulation); the fp32
+    #      variant is measured beside it
+    def time_train(dtype):
         tb = args.train_batch
         tlabels = synthetic.rectangle_maps(30 + rank, tb, SIDE // 4, SIDE // 4)
         tx = torch.from_numpy(synthetic.textured_images(31 + rank, tlabels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
         ty = torch.from_numpy(tlabels).to(dev)
-        tmodel = Model(cfg, seed=1)
+        tmodel = Model(cfg, dtype=dtype, seed=1)
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup)):
@@ -160,14 +161,22 @@ def main():
             t = torch.tensor([tel], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tel = float(t.item())
-        train_bytes_per_image = (3 * 12599296 - SIDE * SIDE * C_IN) * 4.0       # E_train elements, fp32
-        train = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
-                 "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb, "dtype": "f32",
-                 "parallelism": f"dp{world}: per-replica loss, one flat-gradient all-reduce (RCCL) per step" if world > 1 else "single GPU",
-                 "loss_last": round(float(trainer.loss[0]), 5),
-                 "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
+        bpe = 4.0 if dtype == "float32" else 2.0
+        train_bytes_per_image = (3 * 12599296 - SIDE * SIDE * C_IN) * bpe       # E_train elements
+        res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
+               "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb,
+               "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype],
+               "parallelism": f"dp{world}: per-replica loss, one flat-gradient all-reduce (RCCL) per step" if world > 1 else "single GPU",
+               "loss_last": round(float(trainer.loss[0]), 5),
+               "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
         del trainer, tmodel, tx, ty
         torch.cuda.empty_cache()
+        return res
+
+    train = train_f32 = None
+    if not args.no_train:
+        train = time_train("bfloat16")
+        train_f32 = time_train("float32")
 
     line = None
     if rank == 0:
@@ -237,7 +246,7 @@ def main():
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_f32": train_f32,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},
