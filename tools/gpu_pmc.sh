@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters for one kernel (name pattern $1) of the fp32 forward pass (separate passes, kernel-trace only)
+# PMC counters for one kernel (name pattern $1) of the forward pass (UBD_PMC_DTYPE=float32|bfloat16|float16; separate passes, kernel-trace only)
 PAT=${1:-dilconv_wino}
 TAG=$(echo "$PAT" | tr -c "A-Za-z0-9_\n" "_")
 OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}.txt"
@@ -10,7 +10,7 @@ import sys, os, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from ubdvss_amd import NetConfig, Model, synthetic
 torch.cuda.set_device(0)
-m = Model(NetConfig(grey=False), seed=1)
+m = Model(NetConfig(grey=False), dtype=os.environ.get("UBD_PMC_DTYPE", "float32"), seed=1)
 x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
 for _ in range(3): m.predict_on_device(x)
 torch.cuda.synchronize()

@@ -142,7 +142,7 @@ template <int CIN, int STRIDE> struct sep_cfg {
 // tile t is computed (24 channels: LDS-DMA into the other half of a double buffer; 1/3 channels: loads held
 // in registers across the compute phase, written to LDS afterwards).  Per-lane weights are loaded once.
 template <int CIN, int STRIDE, int IN_U8>
-__global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
+__global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                       const float *__restrict__ frag,  // pwfrag then dwlane
                                                       const float *__restrict__ bias, int n, int H, int W, int OH,
                                                       int OW, int pad_lo, float pre_sub, float pre_div)
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
             ld_rel[k] = (pr * W + pc) * CIN + ch;
         }
     }
-    auto load_regs = [&](int tile, float (&st)[C::STAGE_REGS]) {
+    auto load_regs = [&](int tile, unsigned (&st)[C::STAGE_REGS]) {
         int img, oy0, ox0;
         tile_coords(tile, img, oy0, ox0);
         const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
@@ -252,23 +252,23 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
             const size_t origin = (((size_t)img * H + iy0) * W + ix0) * CIN;
 #pragma unroll
             for (int k = 0; k < C::STAGE_REGS; ++k) {
-                if constexpr (IN_U8) st[k] = ((float)((const unsigned char *)xin)[origin + ld_rel[k]] - pre_sub) / pre_div;
-                else st[k] = (((const float *)xin)[origin + ld_rel[k]] - pre_sub) / pre_div;
+                if constexpr (IN_U8) st[k] = ((const unsigned char *)xin)[origin + ld_rel[k]];
+                else st[k] = ((const unsigned *)xin)[origin + ld_rel[k]];
             }
             return;
         }
 #pragma unroll
         for (int k = 0; k < C::STAGE_REGS; ++k) {
             const int e = k * 256 + threadIdx.x;
-            float v = 0.f;
+            unsigned v = (IN_U8) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);   // out-of-image: exactly 0 after the preprocessing below
             if (e < C::ELEMS) {
                 const int pix = e / CIN, ch = e - pix * CIN;
                 const int pr = pix / C::PW, pc = pix - pr * C::PW;
                 const int gy = iy0 + pr, gx = ix0 + pc;
                 if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
                     const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
-                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
-                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
+                    if constexpr (IN_U8) v = ((const unsigned char *)xin)[ge];
+                    else v = ((const unsigned *)xin)[ge];
                 }
             }
             st[k] = v;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
 
     int tile = blockIdx.x;
     if (tile >= total) return;
-    float stage[C::STAGE_REGS];
+    unsigned stage[C::STAGE_REGS];      // raw loaded bits (fp32 pattern or zero-extended byte): nothing consumes them before the LDS write
     if constexpr (CIN == UBD_C) dma_tile(tile, patch_mem);
     else load_regs(tile, stage);
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
         int img, oy0, ox0;
         tile_coords(tile, img, oy0, ox0);
         const int nxt = tile + gridDim.x;
-        const bool has_next = nxt < total;                           // block-uniform
+        const bool has_next = (CIN == UBD_C) && nxt < total;         // block-uniform; 1/3-channel tiles: one per block (see launch)
         if constexpr (CIN == UBD_C) {
             // This tile's DMA must have landed.  vmcnt counts stores too (CDNA4) and __syncthreads() would drain
             // them all (~2 us of store latency per tile): every wave issues exactly NSTORE buffer stores per tile
@@ -318,7 +318,10 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const void *__restrict__ x
 #pragma unroll
             for (int k = 0; k < C::STAGE_REGS; ++k) {
                 const int e = k * 256 + threadIdx.x;
-                if (e < C::ELEMS) patch[e] = stage[k];
+                if (e < C::ELEMS) {                                   // raw values were in flight during the previous compute phase
+                    if constexpr (IN_U8) patch[e] = stage[k] > 255u ? 0.f : ((float)stage[k] - pre_sub) / pre_div;
+                    else patch[e] = (__builtin_bit_cast(float, stage[k]) - pre_sub) / pre_div;
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): LDS writes done
             __builtin_amdgcn_s_barrier();
@@ -570,9 +573,9 @@ static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, 
 {
     const int th = sep_cfg<CIN, STRIDE>::TH;
     const int tiles = n * ((OH + th - 1) / th) * ((OW + 15) / 16);
-    const int per_cu = (CIN == UBD_C) ? ((sep_cfg<CIN, STRIDE>::BUF_FLOATS * 8 > 80 * 1024) ? 1 : 2) : 4;   // LDS-limited residency
+    const int per_cu = (CIN == UBD_C) ? ((sep_cfg<CIN, STRIDE>::BUF_FLOATS * 8 > 80 * 1024) ? 1 : 2) : 5;   // LDS-limited residency
     int grid = h->num_cus * per_cu;
-    if (grid > tiles) grid = tiles;
+    if (grid > tiles || CIN != UBD_C) grid = tiles;      // 1/3 channels: one tile per block, residency (not a register prefetch) hides the load latency
     if (in_u8)
         hipLaunchKernelGGL((sepconv_kernel<CIN, STRIDE, 1>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sc, sh);
     else

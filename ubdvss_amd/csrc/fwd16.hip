@@ -16,6 +16,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -79,86 +80,288 @@ __device__ __forceinline__ void store_tile16(unsigned short *__restrict__ y, siz
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    if (lane * 16 < npx * UBD_C * 2) {
-        const u32x4 v = *(const u32x4 *)((const char *)stile + lane * 16);
-        *(u32x4 *)((char *)(y + first_pixel * UBD_C) + lane * 16) = v;
+    const u32x4 v = *(const u32x4 *)((const char *)stile + (lane < 48 ? lane : 0) * 16);
+    // ONE unconditional buffer store per tile (callers count them for s_waitcnt vmcnt): the record count clips the
+    // lanes beyond the valid pixels; the descriptor is made provably wave-uniform (no waterfall loop)
+    const unsigned long long rp = (unsigned long long)(y + first_pixel * UBD_C);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
+    npx = npx < 0 ? 0 : npx;
+    const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 2);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)rhi << 32) | rlo), 0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// NR row tiles of one wave at once: one LDS round trip (and one pair of waits) for all of them.  `stile` holds NR tiles.
+template <typename T, int NR>
+__device__ __forceinline__ void store_tiles16(unsigned short *__restrict__ y, const size_t (&first_pixel)[NR], const int (&npx)[NR],
+                                              int lane, unsigned short *__restrict__ stile, const f32x4 (&acc0)[NR],
+                                              const f32x4 (&acc1)[NR], float b0, float b1)
+{
+    const int co = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        unsigned short *t = stile + k * 16 * UBD_C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t[(4 * q + r) * UBD_C + co] = to_bits<T>(fmaxf(acc0[k][r] + b0, 0.f));
+            if (co < 8) t[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(fmaxf(acc1[k][r] + b1, 0.f));
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    u32x4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = *(const u32x4 *)((const char *)stile + k * 16 * UBD_C * 2 + (lane < 48 ? lane : 0) * 16);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const unsigned long long rp = (unsigned long long)(y + first_pixel[k] * UBD_C);
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
+        const int np = npx[k] < 0 ? 0 : npx[k];
+        const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(np * UBD_C * 2);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)rhi << 32) | rlo), 0, (int)bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, lane * 16, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------ separable layers
-// IN_MODE 0: fp32 input, 1: uint8 input (CIN 1/3 only), 2: 16-bit input (CIN 24)
+// LDS-staged like the fp32 sepconv_kernel (forward.hip): persistent blocks walk output tiles of 16 columns x TH
+// rows; the input patch crosses L2->CU once per tile.  IN_MODE 0: fp32 input, 1: uint8 input (CIN 1/3, patch
+// converted to fp32 on the way into LDS), 2: 16-bit input (CIN 24): the raw 48-byte pixels are copied with
+// LDS-DMA (3 x 16 B per pixel, double-buffered against the compute phase) and widened when the taps are read.
+// Channel split of a 24-channel pixel over the 4 k-groups: q takes channels 4q..4q+3 (one ds_read_b64 at byte 8q)
+// and 16+2q, 17+2q (one ds_read_b32 at byte 32+4q); pixel stride 48 B = 12 banks keeps 16 neighbouring pixels
+// conflict-free at stride 1.  The per-lane depthwise / pointwise weights are re-gathered to that split.
+template <int CIN, int STRIDE> struct sep16_cfg {
+    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int PH = (TH - 1) * STRIDE + 3;
+    static constexpr int PW = 15 * STRIDE + 3;
+    static constexpr int CHUNKS = (CIN == UBD_C) ? PH * PW * 3 : 0;           // 16-byte chunks of the 16-bit patch
+    static constexpr int ROUNDS = (CIN == UBD_C) ? (CHUNKS + 255) / 256 : 1;
+    static constexpr int ELEMS = PH * PW * CIN;
+    static constexpr int BUF_BYTES = (CIN == UBD_C) ? ROUNDS * 256 * 16 : (ELEMS + 3) / 4 * 16;
+    static constexpr int STAGE_REGS = (CIN == UBD_C) ? 1 : (ELEMS + 255) / 256;
+    static constexpr int NSTORE = TH / 4;                                     // buffer stores per wave per tile
+};
+
 template <int CIN, int STRIDE, int IN_MODE, typename T>
-__global__ __launch_bounds__(256) void sepconv16_kernel(const void *__restrict__ xin, unsigned short *__restrict__ y,
+__global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(const void *__restrict__ xin, unsigned short *__restrict__ y,
                                                         const float *__restrict__ frag, const float *__restrict__ bias, int n,
                                                         int H, int W, int OH, int OW, int pad_lo, float pre_sub, float pre_div)
 {
+    using C = sep16_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned short s_tile[4][16 * UBD_C];
+    constexpr int NBUF = (CIN == UBD_C) ? 2 : 1;
+    constexpr int NR = C::TH / 4;                                           // row tiles per wave per block tile
+    // ONE LDS object: with a second __shared__ array hipcc orders every LDS read behind the LDS-DMA in flight (s_waitcnt vmcnt(0))
+    constexpr int TILE_HALVES = NR * 16 * UBD_C;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * C::BUF_BYTES + 4 * TILE_HALVES * 2];
+    char *patch_mem = smem;
+    unsigned short *s_tile_base = (unsigned short *)(smem + NBUF * C::BUF_BYTES);
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *pwfrag = frag, *dwlane = frag + UBD_SEP_FRAG_FLOATS;
     float dwk[9][CPL], pwf[CPL][2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int s = 0; s < CPL; ++s) {
+        // the fragments are packed for channel 6q'+s' (forward.hip); fetch the entry of this lane's channel
+        const int ch = (CIN == UBD_C) ? (s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4)) : 0;
+        const int qs = (CIN == UBD_C) ? ch / 6 : q, ss = (CIN == UBD_C) ? ch % 6 : s;
+        const int src_lane = 16 * qs + i;
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
-#pragma unroll
-    for (int s = 0; s < CPL; ++s) { pwf[s][0] = pwfrag[(s * 2 + 0) * 64 + lane]; pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane]; }
+        for (int t = 0; t < 9; ++t) dwk[t][s] = dwlane[(t * 6 + ss) * 64 + src_lane];
+        pwf[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
+        pwf[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
+    }
     const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
-    const bool ch_ok = (CIN == UBD_C) || (q < CIN);
-    const int cb = (CIN == UBD_C) ? 6 * q : q;
+    const int cb = (q < CIN) ? q : 0;                                       // CIN < 24: this lane's channel (weights are 0 beyond)
 
-    const int tiles_x = (OW + 15) >> 4;
-    const int total = n * OH * tiles_x;
-    const int nwaves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + wid; tile < total; tile += nwaves) {
-        const int xt = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int rowid = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int oy = (int)((unsigned)rowid % (unsigned)OH);
-        const int img = (int)((unsigned)rowid / (unsigned)OH);
-        const int x0 = xt * 16, ox = x0 + i;
-        float dwv[CPL];
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
+    const int total = n * tiles_y * tiles_x;
+    auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
+        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int r = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)r % (unsigned)tiles_y);
+        img = (int)((unsigned)r / (unsigned)tiles_y);
+        oy0 = ty * C::TH; ox0 = tx * 16;
+    };
+    int dma_rel[C::ROUNDS];
+    if constexpr (CIN == UBD_C) {
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            int c = rd * 256 + wid * 64 + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const int pix = c / 3, sp = c - pix * 3;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            dma_rel[rd] = (pr * W + pc) * (UBD_C * 2) + sp * 16;
+        }
+    }
+    auto dma_tile = [&](int tile, char *buf) {
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        const char *src = (const char *)xin;
+        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::PH <= H) && (ix0 + C::PW <= W);   // block-uniform
+        if (interior) {
+            const char *origin = src + (((size_t)img * H + iy0) * W + ix0) * (UBD_C * 2);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * STRIDE + ky - pad_lo;
-            const bool rok = (iy >= 0) && (iy < H);
+            for (int rd = 0; rd < C::ROUNDS; ++rd)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(origin + dma_rel[rd]),
+                                                 (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 16), 16, 0, 0);
+            return;
+        }
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int t = ky * 3 + kx;
-                const int ix = ox * STRIDE + kx - pad_lo;
-                const bool ok = rok && ch_ok && (ix >= 0) && (ix < W) && (ox < OW);
-                const size_t e = (((size_t)img * H + (size_t)(rok ? iy : 0)) * W + (size_t)(ok ? ix : 0)) * CIN + cb;
-                if constexpr (CIN == UBD_C) {
-                    unsigned w0 = 0, w1 = 0, w2 = 0;
-                    if (ok) {
-                        const unsigned *p = (const unsigned *)((const unsigned short *)xin + e);     // 12 B, 4-byte aligned
-                        w0 = p[0]; w1 = p[1]; w2 = p[2];
-                    }
-                    float v[6];
-                    widen2<T>(w0, v[0], v[1]); widen2<T>(w1, v[2], v[3]); widen2<T>(w2, v[4], v[5]);
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int cbase = rd * 256 + wid * 64;
+            int c = cbase + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const int pix = c / 3, sp = c - pix * 3;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            int gy = iy0 + pr, gx = ix0 + pc;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);                 // clamped; out-of-image pixels are zeroed afterwards
+            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const char *g = src + (((size_t)img * H + gy) * W + gx) * (UBD_C * 2) + sp * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(buf + cbase * 16), 16, 0, 0);
+        }
+    };
+    int ld_rel[C::STAGE_REGS];
+    if constexpr (CIN != UBD_C) {
 #pragma unroll
-                    for (int s = 0; s < 6; ++s) dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]);
-                } else {
-                    float v = 0.f;
-                    if (ok) {
-                        if constexpr (IN_MODE == 1) v = ((float)((const unsigned char *)xin)[e] - pre_sub) / pre_div;
-                        else v = (((const float *)xin)[e] - pre_sub) / pre_div;
-                    }
-                    dwv[0] = fmaf(v, dwk[t][0], dwv[0]);
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            int e = k * 256 + threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
+            const int pix = e / CIN, ch = e - pix * CIN;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            ld_rel[k] = (pr * W + pc) * CIN + ch;
+        }
+    }
+    auto load_regs = [&](int tile, unsigned (&st)[C::STAGE_REGS]) {
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::PH <= H) && (ix0 + C::PW <= W);   // block-uniform
+        if (interior) {
+            const size_t origin = (((size_t)img * H + iy0) * W + ix0) * CIN;
+#pragma unroll
+            for (int k = 0; k < C::STAGE_REGS; ++k) {
+                if constexpr (IN_MODE == 1) st[k] = ((const unsigned char *)xin)[origin + ld_rel[k]];
+                else st[k] = ((const unsigned *)xin)[origin + ld_rel[k]];
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            const int e = k * 256 + threadIdx.x;
+            unsigned v = (IN_MODE == 1) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);   // out-of-image: exactly 0 after the preprocessing below
+            if (e < C::ELEMS) {
+                const int pix = e / CIN, ch = e - pix * CIN;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                const int gy = iy0 + pr, gx = ix0 + pc;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
+                    if constexpr (IN_MODE == 1) v = ((const unsigned char *)xin)[ge];
+                    else v = ((const unsigned *)xin)[ge];
                 }
             }
+            st[k] = v;
         }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    unsigned stage[C::STAGE_REGS];      // raw loaded bits (fp32 pattern or zero-extended byte): nothing consumes them before the LDS write
+    if constexpr (CIN == UBD_C) dma_tile(tile, patch_mem);
+    else load_regs(tile, stage);
+
+    for (int it = 0;; ++it) {
+        char *patch = patch_mem + ((CIN == UBD_C) ? (it & 1) * C::BUF_BYTES : 0);
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int nxt = tile + gridDim.x;
+        const bool has_next = (CIN == UBD_C) && nxt < total;         // block-uniform; 1/3-channel tiles: one per block (see launch)
+        if constexpr (CIN == UBD_C) {
+            // counted wait as in forward.hip: exactly NSTORE buffer stores per wave follow each tile's DMA
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (C::NSTORE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_BYTES);
+            const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+            const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
+            if (border) {                                            // block-uniform
+                for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
+                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                    const int gy = iy0 + pr, gx = ix0 + pc;
+                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                        u32x4 *z = (u32x4 *)(patch + pix * (UBD_C * 2));
+                        const u32x4 zero = {0u, 0u, 0u, 0u};
+                        z[0] = zero; z[1] = zero; z[2] = zero;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
+            for (int k = 0; k < C::STAGE_REGS; ++k) {
+                const int e = k * 256 + threadIdx.x;
+                if (e < C::ELEMS) {                                   // raw values were in flight during the previous compute phase
+                    if constexpr (IN_MODE == 1) ((float *)patch)[e] = stage[k] > 255u ? 0.f : ((float)stage[k] - pre_sub) / pre_div;
+                    else ((float *)patch)[e] = (__builtin_bit_cast(float, stage[k]) - pre_sub) / pre_div;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            if (has_next) load_regs(nxt, stage);
         }
-        const int npx = OW - x0 < 16 ? OW - x0 : 16;
-        store_tile16<T>(y, ((size_t)img * OH + oy) * OW + x0, npx, lane, s_tile[wid], acc0, acc1, b0, b1);
+
+        f32x4 acc0[NR], acc1[NR];
+        size_t fpx[NR];
+        int npxs[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = wid + 4 * k;
+            const int oy = oy0 + r;
+            float dwv[CPL];
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int t = ky * 3 + kx;
+                    const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
+                    if constexpr (CIN == UBD_C) {
+                        const char *p = patch + pix * (UBD_C * 2);
+                        const u32x2 a = *(const u32x2 *)(p + 8 * q);
+                        const unsigned b = *(const unsigned *)(p + 32 + 4 * q);
+                        float v[6];
+                        widen2<T>(a[0], v[0], v[1]); widen2<T>(a[1], v[2], v[3]); widen2<T>(b, v[4], v[5]);
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]);
+                    } else {
+                        dwv[0] = fmaf(((const float *)patch)[pix * CIN + cb], dwk[t][0], dwv[0]);
+                    }
+                }
+            }
+            acc0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0[k], 0, 0, 0);
+                acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1[k], 0, 0, 0);
+            }
+            const int npx = OW - ox0 < 16 ? OW - ox0 : 16;
+            npxs[k] = (oy < OH) ? npx : 0;
+            fpx[k] = ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0;
+        }
+        store_tiles16<T, NR>(y, fpx, npxs, lane, s_tile_base + wid * TILE_HALVES, acc0, acc1, b0, b1);
+        if (!has_next) break;
+        tile = nxt;
     }
 }
 
@@ -301,8 +504,11 @@ template <int CIN, int STRIDE, int IN_MODE, typename T>
 static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, const float *frag, const float *bias, int n,
                          int H, int W, int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
 {
-    const long tiles = (long)n * OH * ((OW + 15) / 16);
-    const int grid = ubd_grid_for(tiles, h->num_cus, 4, 8);
+    using C = sep16_cfg<CIN, STRIDE>;
+    const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
+    const int per_cu = (CIN == UBD_C) ? (STRIDE == 2 ? 2 : 4) : 5;                 // LDS-limited residency
+    long grid = (long)h->num_cus * per_cu;
+    if (grid > tiles || CIN != UBD_C) grid = tiles;      // 1/3 channels: one tile per block
     hipLaunchKernelGGL((sepconv16_kernel<CIN, STRIDE, IN_MODE, T>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sub, div);
 }
 
