@@ -39,7 +39,17 @@ def to_torch_weights(weights, dtype=torch.float32, requires_grad=False):
     return out
 
 
-def _sep(x, dw, pw, b, stride, fml):
+def _grad_round(t, grad_dtype):
+    """Identity in the forward pass; the gradient that flows back through `t` is rounded to `grad_dtype` (models a
+    gradient tensor stored in 16 bit by the backward kernels)."""
+    if grad_dtype is None or not t.requires_grad:
+        return t
+    dt = _ACT_DTYPES[grad_dtype]
+    t.register_hook(lambda g: g.to(dt).to(g.dtype))
+    return t
+
+
+def _sep(x, dw, pw, b, stride, fml, grad_dtype=None):
     c = x.shape[1]
     dwk = dw.permute(1, 0, 2, 3)                          # (1,C,3,3) -> (C,1,3,3)
     if stride == 2:
@@ -50,7 +60,7 @@ def _sep(x, dw, pw, b, stride, fml):
         x = F.conv2d(x, dwk, None, stride=2, padding=0, groups=c)
     else:
         x = F.conv2d(x, dwk, None, stride=1, padding=1, groups=c)
-    return F.relu(F.conv2d(x, pw, b))
+    return F.relu(_grad_round(F.conv2d(x, pw, b), grad_dtype))
 
 
 _ACT_DTYPES = {"bfloat16": torch.bfloat16, "float16": torch.float16}
@@ -64,17 +74,20 @@ def _ste_round(t, act_dtype):
     return t + (t.detach().to(_ACT_DTYPES[act_dtype]).to(t.dtype) - t.detach())
 
 
-def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None):
+def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None, grad_dtype=None):
     """x_nhwc: torch (N,H,W,C).  tw: list from to_torch_weights.  Returns NHWC logits.
     act_dtype "bfloat16"/"float16": hidden activations and the dense dilated kernels are rounded to that type
-    (straight-through in the backward pass) -- BASELINE.json configs[2..4]."""
+    (straight-through in the backward pass) -- BASELINE.json configs[2..4].
+    grad_dtype: the gradient w.r.t. the pre-activation of L3 and of the six dilated layers (the G tensors the backward
+    kernels hand from layer to layer) is rounded to that type (the bf16 train step stores them in bf16)."""
     x = x_nhwc.permute(0, 3, 1, 2)
     i = 0
-    for stride in (2, 1, 2):
-        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible), act_dtype)
+    for li, stride in enumerate((2, 1, 2)):
+        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype if li == 2 else None), act_dtype)
         i += 3
     for d in DILATIONS:
-        x = _ste_round(F.relu(F.conv2d(x, _ste_round(tw[i], act_dtype), tw[i + 1], padding=d, dilation=d)), act_dtype)
+        z = _grad_round(F.conv2d(x, _ste_round(tw[i], act_dtype), tw[i + 1], padding=d, dilation=d), grad_dtype)
+        x = _ste_round(F.relu(z), act_dtype)
         i += 2
     x = F.conv2d(x, tw[i], tw[i + 1])
     return x.permute(0, 2, 3, 1)
@@ -138,12 +151,13 @@ def from_torch_grads(tw):
     return out
 
 
-def loss_and_grads(x, y_true, weights, classification_mode, fml_compatible=True, dtype=torch.float64, act_dtype=None):
+def loss_and_grads(x, y_true, weights, classification_mode, fml_compatible=True, dtype=torch.float64, act_dtype=None,
+                   grad_dtype=None):
     """Returns (loss, logits, dlogits, [grads in Keras order])."""
     tw = to_torch_weights(weights, dtype, requires_grad=True)
     xt = torch.as_tensor(np.asarray(x), dtype=dtype)
     yt = torch.as_tensor(np.asarray(y_true), dtype=dtype)
-    logits = forward(xt, tw, fml_compatible, act_dtype)
+    logits = forward(xt, tw, fml_compatible, act_dtype, grad_dtype)
     logits.retain_grad()
     loss = total_loss(yt, logits, classification_mode)
     loss.backward()

@@ -62,9 +62,11 @@ def test_bf16_full_batch_property_and_postprocess():
 @pytest.mark.parametrize("dtype,tol", [("bfloat16", 4e-2), ("float16", 6e-3)])
 @pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 2, 64, 64), (1, 2, 2, 64, 96)])
 def test_train_step_16bit(dtype, tol, cin, ncls, n, hh, ww):
-    """configs[2] (bf16 train step) on small shapes: 16-bit activations + 16-bit MFMA forward, fp32 gradient
-    tensors / accumulation / master weights.  Oracle: fp64 torch autograd with the same storage rounding applied
-    straight-through.  Gate: loss and every weight-gradient tensor within `tol` (relative L2; bf16 ulp = 0.4 %)."""
+    """configs[2] (bf16 train step) on small shapes: 16-bit activations + 16-bit MFMA forward, fp32 accumulation /
+    weight gradients / master weights; bf16 mode also keeps the gradient tensors between L3..L9 in bf16 (fp16 mode
+    keeps them fp32).  Oracle: fp64 torch autograd with the same storage roundings (activations and kernels
+    straight-through, gradient tensors by backward hooks).  Gate: loss and every weight-gradient tensor within `tol`
+    (relative L2; bf16 ulp = 0.4 %)."""
     from oracle import net_torch as otorch
     from ubdvss_amd import Trainer, Adam
     cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
@@ -76,7 +78,8 @@ def test_train_step_16bit(dtype, tol, cin, ncls, n, hh, ww):
     x = synthetic.textured_images(92, labels, 4, cin).astype(np.float32) / 127.5 - 1.0
     tr = Trainer(model, Adam())
     tr.backward_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
-    loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, act_dtype=dtype)
+    loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, act_dtype=dtype,
+                                                      grad_dtype="bfloat16" if dtype == "bfloat16" else None)
     l = tr.loss.cpu().numpy()
     assert abs(l[0] - loss_ref) <= tol * abs(loss_ref), (l[0], loss_ref)
     g = tr.grads.cpu().numpy().astype(np.float64)

@@ -1,4 +1,4 @@
-"""Times the train step (fwd + loss + bwd + Adam) at batch 64, 512x512x3 fp32."""
+"""Times the train step (fwd + loss + bwd + Adam) at batch 64, 512x512x3: tools/bench_train.py [batch] [dtype]."""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +6,8 @@ from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
 torch.cuda.set_device(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cfg = NetConfig(grey=False)
-m = Model(cfg, seed=1)
+dtype = sys.argv[2] if len(sys.argv) > 2 else "float32"
+m = Model(cfg, dtype=dtype, seed=1)
 tr = Trainer(m, Adam())
 lab = synthetic.rectangle_maps(30, n, 128, 128)
 x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
@@ -15,4 +16,4 @@ for _ in range(2): tr.train_step_on_device(x, y)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): tr.train_step_on_device(x, y)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"UBD_DBG={os.environ.get('UBD_DBG','0')}: train step {dt*1e3:.3f} ms  ({n/dt:.0f} img/s)")
+print(f"{dtype}: train step {dt*1e3:.3f} ms  ({n/dt:.0f} img/s)")

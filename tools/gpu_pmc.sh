@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters for one kernel (name pattern $1) of the forward pass (UBD_PMC_DTYPE=float32|bfloat16|float16; separate passes, kernel-trace only)
+# PMC counters for one kernel (name pattern $1) of the forward pass (UBD_PMC_DTYPE=float32|bfloat16|float16, UBD_PMC_TRAIN=1: train step at batch 32; separate passes, kernel-trace only)
 PAT=${1:-dilconv_wino}
 TAG=$(echo "$PAT" | tr -c "A-Za-z0-9_\n" "_")
 OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}.txt"
@@ -12,7 +12,15 @@ from ubdvss_amd import NetConfig, Model, synthetic
 torch.cuda.set_device(0)
 m = Model(NetConfig(grey=False), dtype=os.environ.get("UBD_PMC_DTYPE", "float32"), seed=1)
 x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
-for _ in range(3): m.predict_on_device(x)
+if os.environ.get("UBD_PMC_TRAIN"):
+    import numpy as np
+    from ubdvss_amd import Trainer, Adam
+    lab = synthetic.rectangle_maps(30, 32, 128, 128)
+    tx = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    tr = Trainer(m, Adam())
+    for _ in range(2): tr.train_step_on_device(tx, torch.from_numpy(lab).cuda())
+else:
+    for _ in range(3): m.predict_on_device(x)
 torch.cuda.synchronize()
 PY
 i=0

@@ -42,6 +42,21 @@ template <typename TX> __device__ __forceinline__ void ld_act6(const void *base,
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma16<__bf16>(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma16<_Float16>(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// gradient tensors between layers: bf16 for bf16 activations, fp32 otherwise (fp16 would underflow without loss scaling)
+template <typename TX> struct UBD_G16 { static constexpr bool value = false; };
+template <> struct UBD_G16<__bf16> { static constexpr bool value = true; };
+
 #define UBD_BWD_DGRAD_FLOATS (UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
 #define UBD_BWD_SEP_FLOATS (6 * 2 * 64)
 #define UBD_BWD_DIRECT_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
@@ -119,6 +134,37 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
         if (e < n0) out0[e] = v;
         else if (e < n0 + n1) out1[e - n0] = v;
         else out2[e - n0 - n1] = v;
+    }
+}
+
+// Sum the four waves' 224 x 32 accumulator sets and write this block's row of the partial-sum matrix
+// ([216*24 kernel gradient | 24 bias gradient]).  Waves take turns adding into one lane-linear LDS image
+// (ds_read/write_b128, conflict-free): LDS float atomics cost ~3 cycles per LANE on gfx950 and made this epilogue
+// the longest phase of the kernel.
+__device__ __forceinline__ void wgrad_block_reduce(const f32x4 (&acc)[14][2], float *__restrict__ red /* 28 KiB */,
+                                                   float *__restrict__ prow, int lane, int wid)
+{
+    f32x4 *img = (f32x4 *)red;                         // [(mt, nt)][lane] x 4 floats (r)
+    __syncthreads();                                   // tile buffers are free now
+    for (int ph = 0; ph < 4; ++ph) {
+        if (wid == ph) {
+#pragma unroll
+            for (int mt = 0; mt < 14; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 v = acc[mt][nt];
+                    if (ph > 0) v += img[(mt * 2 + nt) * 64 + lane];
+                    img[(mt * 2 + nt) * 64 + lane] = v;
+                }
+        }
+        __syncthreads();
+    }
+    // D layout: col = lane & 15 (co), row = 4 * (lane >> 4) + r (rho within the M tile)
+    for (int t = threadIdx.x; t < 217 * UBD_C; t += blockDim.x) {
+        const int row = t / UBD_C, col = t - row * UBD_C;
+        const int mt = row >> 4, rr = row & 15, nt = col >> 4;
+        const int ln = 16 * (rr >> 2) + (col & 15);
+        prow[t] = red[(((mt * 2 + nt) * 64 + ln) << 2) + (rr & 3)];
     }
 }
 
@@ -213,6 +259,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict_
         }
     }
 }
+
+#include "bwd16.h"
 
 // ------------------------------------------------------------------------------------ dilated wgrad
 // dW[t][ci][co] = sum_p X[p + off_t][ci] G[p][co],  db[co] = sum_p G[p][co].
@@ -348,21 +396,7 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
             }
         }
     }
-    // block reduction through LDS (the tile buffers are free now), then one atomic per output per block
-    __syncthreads();
-    float *red = smem;                                 // 224 x 32 floats = 28 KiB
-    for (int t = threadIdx.x; t < 224 * 32; t += blockDim.x) red[t] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 14; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * mt + 4 * k + r) * 32 + m + 16 * nt], acc[mt][nt][r]);
-    __syncthreads();
-    // row of the partial-sum matrix: [216*24 kernel gradient | 24 bias gradient]
-    float *prow = partials + (size_t)blockIdx.x * (217 * UBD_C);
-    for (int t = threadIdx.x; t < 217 * UBD_C; t += blockDim.x) prow[t] = red[(t / UBD_C) * 32 + (t % UBD_C)];
+    wgrad_block_reduce(acc, smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
 }
 
 // ------------------------------------------------------------------------------------ separable backward
@@ -709,7 +743,7 @@ static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train
     T->off_gb[0] = off;   off += big;
     T->off_gb[1] = off;   off += big;
     T->off_loss = off;    off += ubd_align_up(ubd_loss_workspace_bytes(h, n, H / 4, W / 4), 256);
-    T->off_partials = off; off += ubd_align_up((size_t)2 * h->num_cus * (217 * UBD_C) * sizeof(float), 256);
+    T->off_partials = off; off += ubd_align_up((size_t)4 * h->num_cus * (217 * UBD_C) * sizeof(float), 256);
     T->total = off;
 }
 
@@ -758,7 +792,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
     pa.c_in = h->cfg.c_in;
     hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
-    if (h->use_wino) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
+    if (h->use_wino && !(sizeof(TX) == 2 && UBD_G16<TX>::value)) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
 
     float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
     float *ddw3 = (float *)(ws + T.off_ddw3);
@@ -767,6 +801,34 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
 
     int grid = (int)((npix + 255) / 256);
     if (grid > h->num_cus * 8) grid = h->num_cus * 8;
+    int cur = 0;
+    if constexpr (sizeof(TX) == 2 && UBD_G16<TX>::value) {
+        // ---- bf16 gradient tensors (bwd16.h): G9..G3 live in the two halves of gq[0]; G3 is widened into gq[1] for the
+        //      separable backward kernels; the transposed 16-bit fragments reuse the Winograd part of bfrag
+        unsigned short *g16[2] = {(unsigned short *)gq[0], (unsigned short *)gq[0] + (size_t)npix * UBD_C};
+        unsigned *frag16t = (unsigned *)(bfrag + UBD_BWD_DIRECT_FLOATS);
+        ubd_launch_pack16(h, params, frag16t, 1, st);
+        hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
+        {
+            const long nsteps = (npix + 3) / 4;
+            int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
+            hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
+        }
+        for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
+            const void *X = acts[k];
+            const int dd = UBD_DILATIONS[k];
+            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH - 1) / W16_TH) * (((W4 + dd - 1) / dd + W16_TW - 1) / W16_TW);
+            int gw = h->num_cus * 3;
+            if (gw > items) gw = (int)items;
+            hipLaunchKernelGGL((dil_wgrad16_kernel<TX>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + 63) / 64), dim3(256), 0, st, partials, gw, 217 * UBD_C,
+                               grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
+            ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL((cvt16_to_f32_kernel<TX>), dim3(h->num_cus * 8), dim3(256), 0, st, g16[cur], gq[1], npix * UBD_C / 8);
+        cur = 1;
+    } else {
     // head
     hipLaunchKernelGGL((head_dx_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
     {
@@ -775,7 +837,6 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
     }
     // dilated layers, top to bottom
-    int cur = 0;
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
         const void *X = acts[k];                                // input of dilated layer k (= output of the layer below)
         {
@@ -792,6 +853,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         else
             ubd_launch_dilconv(h, 1, bfrag + (size_t)k * UBD_DIL_FRAG_FLOATS, (const float *)X, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
         cur ^= 1;
+    }
     }
     // separable layers
     const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;

@@ -1,0 +1,211 @@
+// bf16-gradient kernels of the UBD_BF16 train step (included by backward.hip).
+//
+// BASELINE.json configs[2]/[3] ("bf16 train step"): activations AND the gradient tensors that flow between layers
+// (G = dL/dZ) are stored in bf16, every product is accumulated in fp32, weight gradients / master weights / Adam
+// state are fp32.  With both GEMM operands in bf16 the weight gradient of a dilated layer runs on
+// v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) and becomes an HBM/LDS-bound kernel.
+// (UBD_F16 keeps fp32 gradient tensors: fp16 gradients of a mean loss over ~1e6 pixels underflow without loss scaling.)
+//
+//   head_dx16_kernel      G9 = (dlogits . hk^T) * (A9 > 0), stored as T
+//   dil_wgrad16_kernel    dW[t][ci][co] = sum_p X[p+off_t][ci] G[p][co], db = sum_p G: M = 216 (+ ones row), N = 24,
+//                         K = pixels; X and G tiles staged by LDS-DMA as plain [pixel][24 ch] rows, both operands read
+//                         with ds_read_b64_tr_b16 (the K index = pixel is the row index of both LDS images)
+//   (data gradient)       dilconv16_kernel<T, 1> in fwd16.hip
+//   cvt16_to_f32_kernel   G3 -> fp32 for the separable backward kernels
+#pragma once
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict__ dlogits, const unsigned short *__restrict__ a9,
+                                                        const float *__restrict__ hk, unsigned short *__restrict__ g, long npix, int k_out)
+{
+    __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
+    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        float dl[UBD_MAX_CLASSES + 1];
+        for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
+        const u32x4 *pa = (const u32x4 *)(a9 + p * UBD_C);
+        u32x4 *pg = (u32x4 *)(g + p * UBD_C);
+#pragma unroll
+        for (int c8 = 0; c8 < 3; ++c8) {
+            const u32x4 av = pa[c8];
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short hbits[2];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int c = c8 * 8 + 2 * e + hlf;
+                    float acc = 0.f;
+                    for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[c * k_out + k], acc);
+                    const short abits = (short)(hlf ? (av[e] >> 16) : (av[e] & 0xFFFFu));
+                    hbits[hlf] = abits > 0 ? __builtin_bit_cast(unsigned short, (T)acc) : (unsigned short)0;
+                }
+                o[e] = (unsigned)hbits[0] | ((unsigned)hbits[1] << 16);
+            }
+            pg[c8] = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cvt16_to_f32_kernel(const unsigned short *__restrict__ in, float *__restrict__ out, long n8)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const u32x4 v = ((const u32x4 *)in)[i];
+        f32x4 a, b;
+        a[0] = (float)__builtin_bit_cast(T, (unsigned short)(v[0] & 0xFFFFu)); a[1] = (float)__builtin_bit_cast(T, (unsigned short)(v[0] >> 16));
+        a[2] = (float)__builtin_bit_cast(T, (unsigned short)(v[1] & 0xFFFFu)); a[3] = (float)__builtin_bit_cast(T, (unsigned short)(v[1] >> 16));
+        b[0] = (float)__builtin_bit_cast(T, (unsigned short)(v[2] & 0xFFFFu)); b[1] = (float)__builtin_bit_cast(T, (unsigned short)(v[2] >> 16));
+        b[2] = (float)__builtin_bit_cast(T, (unsigned short)(v[3] & 0xFFFFu)); b[3] = (float)__builtin_bit_cast(T, (unsigned short)(v[3] >> 16));
+        ((f32x4 *)out)[2 * i] = a;
+        ((f32x4 *)out)[2 * i + 1] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------ dilated wgrad, bf16 MFMA
+// Work items as in dil_wgrad_kernel: (image, phase (ry, rx) of the d x d sub-grid, 8 x 16 tile of that sub-grid).
+// LDS per buffer: X tile with halo, 10 x 18 pixels x 48 B, then the G tile, 8 x 16 pixels x 48 B (LDS-DMA, chunk c at
+// byte 16 c).  One k-block = 32 sub-pixels = 2 tile rows; wave w takes k-block w of every item.
+// v_mfma_f32_16x16x32_bf16: lane (i = lane & 15, kg = lane >> 4) holds A[i][8kg .. 8kg+7] and B[8kg .. 8kg+7][i];
+// ds_read_b64_tr_b16 fills 4 of the 8 k-values: in the 16-lane group kg, lane 4q+p supplies the address of LDS row
+// (= pixel) q, columns 4p .. 4p+3 and lane i receives column i of the 4 rows.  Columns of the A operand are the
+// flat (tap, ci) index rho = 16 mt + i, so segment p of M-tile mt starts at rho0 = 16 mt + 4p: tap t = rho0 / 24 shifts the
+// pixel, ci = rho0 % 24 the channel (24 = 6 x 4: a segment never straddles a tap).  rho = 216 is the all-ones column
+// (bias gradient), 217.. are zero: those segments read 8-byte constants kept behind the tile buffers.
+#define W16_TH 8
+#define W16_TW 16
+#define W16_XW (W16_TW + 2)
+#define W16_XPIX ((W16_TH + 2) * W16_XW)              // 180
+#define W16_GPIX (W16_TH * W16_TW)                    // 128
+#define W16_XBYTES (W16_XPIX * UBD_C * 2)             // 8640
+#define W16_CHUNKS ((W16_XPIX + W16_GPIX) * 3)        // 924
+#define W16_ROUNDS ((W16_CHUNKS + 255) / 256)         // 4
+#define W16_BUF_BYTES (W16_ROUNDS * 256 * 16)         // 16 KiB
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
+                                                             float *__restrict__ partials, int n, int h, int w, int d)
+{
+    constexpr int CONST_OFF = 2 * W16_BUF_BYTES;                          // [0,8): {1,0,0,0}   [8,16): zeros
+    __shared__ __attribute__((aligned(16))) char smem[2 * W16_BUF_BYTES + 64];   // ONE LDS object (see fwd16.hip)
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int grp = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+    if (threadIdx.x < 16)
+        ((unsigned *)(smem + CONST_OFF))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
+
+    // A operand: byte offset of segment p of M-tile mt relative to the X-tile pixel of the output position
+    int aoff[14];
+#pragma unroll
+    for (int mt = 0; mt < 14; ++mt) {
+        const int rho0 = 16 * mt + 4 * p;
+        const int t = rho0 / UBD_C, ci = rho0 - t * UBD_C;
+        aoff[mt] = ((t / 3) * W16_XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below)
+    }
+    // pixel of this lane inside a k-block (2 tile rows x 16 columns): k = 8 grp + 4 j + qq, j = 0, 1
+    const int krow = grp >> 1, kcol = 8 * (grp & 1) + qq;
+
+    // DMA chunk -> (tile row, tile column, 16-byte part, X or G) of this lane, per round
+    int cinfo[W16_ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < W16_ROUNDS; ++rd) {
+        int c = rd * 256 + wid * 64 + lane;
+        c = c < W16_CHUNKS ? c : W16_CHUNKS - 1;
+        int sy, sx, part, isx;
+        if (c < W16_XPIX * 3) { const int pix = c / 3; part = c - pix * 3; sy = pix / W16_XW; sx = pix - sy * W16_XW; isx = 1; }   // sy, sx include the +1 halo shift
+        else { const int cg = c - W16_XPIX * 3; const int gp = cg / 3; part = cg - gp * 3; sy = gp / W16_TW + 1; sx = gp % W16_TW + 1; isx = 0; }
+        cinfo[rd] = sy | (sx << 8) | (part << 16) | (isx << 24);
+    }
+
+    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
+    const int tiles_y = (sh + W16_TH - 1) / W16_TH, tiles_x = (sw + W16_TW - 1) / W16_TW;
+    const int items = n * d * d * tiles_y * tiles_x;
+    struct item_t { int img, ry, rx, sy0, sx0; };
+    auto decode = [&](int it) {
+        item_t r;
+        const int tx = (int)((unsigned)it % (unsigned)tiles_x); it = (int)((unsigned)it / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)it % (unsigned)tiles_y); it = (int)((unsigned)it / (unsigned)tiles_y);
+        r.rx = (int)((unsigned)it % (unsigned)d); it = (int)((unsigned)it / (unsigned)d);
+        r.ry = (int)((unsigned)it % (unsigned)d);
+        r.img = (int)((unsigned)it / (unsigned)d);
+        r.sy0 = ty * W16_TH; r.sx0 = tx * W16_TW;
+        return r;
+    };
+    auto dma_item = [&](int it, char *buf) {
+        const item_t I = decode(it);
+#pragma unroll
+        for (int rd = 0; rd < W16_ROUNDS; ++rd) {
+            const int ci = cinfo[rd];
+            int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;
+            int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
+            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                 // clamped; out-of-image pixels are zeroed later
+            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+            const size_t pixel = ((size_t)I.img * h + gy) * w + gx;
+            const char *src = (const char *)((ci >> 24) ? x : gz) + pixel * (UBD_C * 2) + ((ci >> 16) & 0xFF) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[14][2] = {};
+    int it = blockIdx.x;
+    if (it < items) dma_item(it, smem);
+    for (int iter = 0; it < items; ++iter, it += gridDim.x) {
+        char *buf = smem + (iter & 1) * W16_BUF_BYTES;
+        const item_t I = decode(it);
+        __syncthreads();                              // this item's DMA landed; everyone left the other buffer
+        if (it + (int)gridDim.x < items) dma_item(it + gridDim.x, smem + ((iter + 1) & 1) * W16_BUF_BYTES);
+        const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
+                            (I.ry + (I.sy0 + W16_TH) * d >= h) || (I.rx + (I.sx0 + W16_TW) * d >= w);   // block-uniform
+        if (ragged) {
+            for (int pix = threadIdx.x; pix < W16_XPIX + W16_GPIX; pix += 256) {
+                int sy, sx;
+                if (pix < W16_XPIX) { sy = pix / W16_XW - 1; sx = pix % W16_XW - 1; }
+                else { sy = (pix - W16_XPIX) / W16_TW; sx = (pix - W16_XPIX) % W16_TW; }
+                const int gy = I.ry + (I.sy0 + sy) * d, gx = I.rx + (I.sx0 + sx) * d;
+                if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
+                    u32x4 *z = (u32x4 *)(buf + pix * (UBD_C * 2));
+                    const u32x4 zero = {0u, 0u, 0u, 0u};
+                    z[0] = zero; z[1] = zero; z[2] = zero;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();             // raw barrier: the next item's DMA stays in flight
+        }
+        const int rows_eff = min(W16_TH, sh - I.sy0);
+        if (2 * wid < rows_eff) {                     // wave-uniform: this wave's two tile rows hold real sub-pixels
+            const int py = 2 * wid + krow;
+            const char *xb = buf + (py * W16_XW + kcol) * (UBD_C * 2);
+            const char *gb = buf + W16_XBYTES + (py * W16_TW + kcol) * (UBD_C * 2);
+            // B operand: segments of the two N tiles (co 0..15, 16..23 + zero padding)
+            u32x4 b[2];
+            {
+                const char *g0 = gb + 8 * p;
+                const char *g1 = p < 2 ? gb + 32 + 8 * p : smem + CONST_OFF + 8;
+                const s16x4 v00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)g0);
+                const s16x4 v01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(g0 + 4 * UBD_C * 2));
+                const s16x4 v10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)g1);
+                const s16x4 v11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p < 2 ? g1 + 4 * UBD_C * 2 : g1));
+                b[0] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v00, v01, 0, 1, 2, 3, 4, 5, 6, 7));
+                b[1] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v10, v11, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 14; ++mt) {
+                const char *a0 = xb + aoff[mt];
+                const char *a1 = a0 + 4 * UBD_C * 2;
+                if (mt == 13 && p >= 2) { a0 = smem + CONST_OFF + (p == 2 ? 0 : 8); a1 = a0; }
+                const s16x4 va0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+                const s16x4 va1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
+                const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(va0, va1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[mt][0] = mfma16<T>(a, b[0], acc[mt][0]);
+                acc[mt][1] = mfma16<T>(a, b[1], acc[mt][1]);
+            }
+        }
+    }
+    wgrad_block_reduce(acc, (float *)smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
+}

@@ -79,6 +79,10 @@ void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfr
 size_t ubd_forward16_workspace_bytes(int n, int H, int W);
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st);
+#define UBD_DIL16_FRAG_U32 (7 * 2 * 64 * 4)          // 16-bit dilated layer: [chunk 7][nt 2][lane 64] x 4 dwords (8 halves)
+void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
+                          const void *in, void *out, int n, int H4, int W4, hipStream_t st);
+void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, int transpose, hipStream_t st);
 struct ubd_fwd16_layout { size_t off_wfrag32, off_wfrag16, off_a1, off_a2, off_acts[7], total; };
 void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layout *L);
 int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,

@@ -39,13 +39,14 @@ template <typename T> __device__ __forceinline__ void widen2(unsigned w, float &
     hi = from_bits<T>((unsigned short)(w >> 16));
 }
 
-#define UBD_DIL16_FRAG_U32 (7 * 2 * 64 * 4)          // per dilated layer: [chunk 7][nt 2][lane 64] x 4 dwords (8 halves)
 
 // ------------------------------------------------------------------------------------ pack
 // 16-bit B fragments of the dilated layers: lane (n = lane&15, q = lane>>4), chunk c, element j:
 //   k = 32c + 8q + j (flat (tap, ci) index, zero for k >= 216), co = n + 16 nt (zero for co >= 24)
+// transpose = 1: fragments of the data-gradient convolution, W'[t][ci'][co'] = W[8 - t][co'][ci'] (flipped taps,
+// channels swapped), same lane layout.
 template <typename T>
-__global__ void pack16_kernel(const float *__restrict__ params, unsigned *__restrict__ out, size_t off0, size_t layer_stride)
+__global__ void pack16_kernel(const float *__restrict__ params, unsigned *__restrict__ out, size_t off0, size_t layer_stride, int transpose)
 {
     const int total = UBD_NUM_DIL * UBD_DIL16_FRAG_U32;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -58,7 +59,10 @@ __global__ void pack16_kernel(const float *__restrict__ params, unsigned *__rest
         for (int e = 0; e < 2; ++e) {
             const int k = 32 * c + 8 * q + 2 * dw + e;
             float v = 0.f;
-            if (k < 216 && co < UBD_C) v = wk[(size_t)k * UBD_C + co];
+            if (k < 216 && co < UBD_C) {
+                if (!transpose) v = wk[(size_t)k * UBD_C + co];
+                else { const int t = k / UBD_C, ci = k - t * UBD_C; v = wk[((size_t)(8 - t) * UBD_C + co) * UBD_C + ci]; }
+            }
             h[e] = to_bits<T>(v);
         }
         out[idx] = (unsigned)h[0] | ((unsigned)h[1] << 16);
@@ -68,19 +72,32 @@ __global__ void pack16_kernel(const float *__restrict__ params, unsigned *__rest
 // ------------------------------------------------------------------------------------ shared epilogue
 // D layout: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).  y = relu(acc + bias), narrowed to T and
 // written through this wave's 768-byte LDS tile so that the 16 pixels x 48 B leave as 16-byte stores.
-template <typename T>
+template <typename T, int EPI>
 __device__ __forceinline__ void store_tile16(unsigned short *__restrict__ y, size_t first_pixel, int npx, int lane,
-                                             unsigned short *__restrict__ stile, f32x4 acc0, f32x4 acc1, float b0, float b1)
+                                             unsigned short *__restrict__ stile, f32x4 acc0, f32x4 acc1, float b0, float b1, u32x4 m)
 {
     const int co = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        stile[(4 * q + r) * UBD_C + co] = to_bits<T>(fmaxf(acc0[r] + b0, 0.f));
-        if (co < 8) stile[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(fmaxf(acc1[r] + b1, 0.f));
+        if constexpr (EPI == 0) {
+            stile[(4 * q + r) * UBD_C + co] = to_bits<T>(fmaxf(acc0[r] + b0, 0.f));
+            if (co < 8) stile[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(fmaxf(acc1[r] + b1, 0.f));
+        } else {
+            stile[(4 * q + r) * UBD_C + co] = to_bits<T>(acc0[r]);
+            if (co < 8) stile[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(acc1[r]);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    const u32x4 v = *(const u32x4 *)((const char *)stile + (lane < 48 ? lane : 0) * 16);
+    u32x4 v = *(const u32x4 *)((const char *)stile + (lane < 48 ? lane : 0) * 16);
+    if constexpr (EPI == 1) {                        // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = ((short)(m[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u;
+            const unsigned hi = ((int)m[e] >> 16) > 0 ? 0xFFFF0000u : 0u;
+            v[e] &= (lo | hi);
+        }
+    }
     // ONE unconditional buffer store per tile (callers count them for s_waitcnt vmcnt): the record count clips the
     // lanes beyond the valid pixels; the descriptor is made provably wave-uniform (no waterfall loop)
     const unsigned long long rp = (unsigned long long)(y + first_pixel * UBD_C);
@@ -366,11 +383,14 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
 }
 
 // ------------------------------------------------------------------------------------ dilated layers
-struct a16_frags { u32x4 v[7]; };
+struct a16_frags { u32x4 v[7]; u32x4 m; };
 
-template <typename T>
+// EPI 0: y = relu(conv + bias).  EPI 1 (data gradient of the 16-bit train step): y = conv * (mask > 0), no bias; `wfrag`
+// then holds the flipped / transposed kernel and `mask` the saved output of the layer below (same shape as y).
+template <typename T, int EPI>
 __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
-                                                        const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
+                                                        const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
+                                                        const unsigned short *__restrict__ mask, int n, int h,
                                                         int w, int d, unsigned in_bytes)
 {
     __shared__ __attribute__((aligned(16))) unsigned short s_tile[4][16 * UBD_C];
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
     u32x4 wr[7][2];
 #pragma unroll
     for (int c = 0; c < 7; ++c) { wr[c][0] = wfrag[(c * 2 + 0) * 64 + lane]; wr[c][1] = wfrag[(c * 2 + 1) * 64 + lane]; }
-    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const float b0 = EPI == 0 ? bias[i] : 0.f, b1 = (EPI == 0 && i < 8) ? bias[16 + i] : 0.f;
     // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c+q)/3, channel group ((4c+q)%3)*8
     int dyc[7], dxc[7], cic[7];
 #pragma unroll
@@ -400,6 +420,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
     int tile = t_begin + (int)(blockIdx.x >> 3) * 4 + wid;
     if (tile >= t_end) return;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(EPI == 1 ? mask : x), 0, (int)in_bytes, 0x00020000);
     const unsigned oob = in_bytes;
 
     auto load = [&](a16_frags &a, int tl) {
@@ -414,6 +435,11 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
             const unsigned off = ((unsigned)(rowid + dyc[c]) * (unsigned)w + (unsigned)ix) * (unsigned)(UBD_C * 2) + (unsigned)cic[c];
             a.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : oob), 0, 0);
         }
+        if constexpr (EPI == 1) {                    // the 16 bytes of the mask this lane will need in the store phase
+            const unsigned moff = ((unsigned)rowid * (unsigned)w + (unsigned)(xt * 16)) * (unsigned)(UBD_C * 2) + (unsigned)lane * 16u;
+            const int npx = w - xt * 16 < 16 ? w - xt * 16 : 16;
+            a.m = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (int)(lane * 16 < npx * UBD_C * 2 ? moff : oob), 0, 0);
+        }
     };
     auto compute_store = [&](const a16_frags &a, int tl) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -426,7 +452,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         const int rowid = (int)((unsigned)tl / (unsigned)tiles_x);
         const int x0 = xt * 16;
         const int npx = w - x0 < 16 ? w - x0 : 16;
-        store_tile16<T>(y, (size_t)rowid * w + x0, npx, lane, s_tile[wid], acc0, acc1, b0, b1);
+        store_tile16<T, EPI>(y, (size_t)rowid * w + x0, npx, lane, s_tile[wid], acc0, acc1, b0, b1, a.m);
     };
     a16_frags A0, A1;
     const int t_last = t_end - 1;
@@ -513,6 +539,39 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
 }
 
 template <typename T>
+static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
+                         const void *in, void *out, int n, int H4, int W4, hipStream_t st)
+{
+    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 2);
+    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
+    int grid = ubd_grid_for(tiles, h->num_cus, 4, 4);
+    grid = (grid + 7) / 8 * 8;
+    if (epi == 0)
+        hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                           (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, in_bytes);
+    else
+        hipLaunchKernelGGL((dilconv16_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, in_bytes);
+}
+
+// 16-bit dense dilated layer (epi 0: forward, epi 1: data gradient with ReLU mask); element type from the handle
+void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
+                          const void *in, void *out, int n, int H4, int W4, hipStream_t st)
+{
+    if (h->cfg.dtype == UBD_BF16) launch_dil16<__bf16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st);
+    else launch_dil16<_Float16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st);
+}
+
+// packed 16-bit fragments of all six dilated layers (transpose = 1: data-gradient kernels)
+void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, int transpose, hipStream_t st)
+{
+    if (h->cfg.dtype == UBD_BF16)
+        hipLaunchKernelGGL((pack16_kernel<__bf16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose);
+    else
+        hipLaunchKernelGGL((pack16_kernel<_Float16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose);
+}
+
+template <typename T>
 static int forward16_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n,
                           int H, int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
 {
@@ -521,7 +580,7 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     unsigned *wfrag16 = (unsigned *)(ws + L.off_wfrag16);
     unsigned short *a1 = (unsigned short *)(ws + L.off_a1), *a2 = (unsigned short *)(ws + L.off_a2);
     ubd_launch_pack_direct(h, params, wfrag, st);                      // fp32 depthwise / pointwise fragments
-    hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0]);
+    hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], 0);
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
     const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;
@@ -538,15 +597,9 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     launch_sep16<UBD_C, 1, 2, T>(h, a1, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
     unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
     launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
-    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 2);
-    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
-        int grid = ubd_grid_for(tiles, h->num_cus, 4, 4);
-        grid = (grid + 7) / 8 * 8;
         unsigned short *nxt = (unsigned short *)(ws + L.off_acts[k + 1]);
-        hipLaunchKernelGGL((dilconv16_kernel<T>), dim3(grid), dim3(256), 0, st, cur, nxt,
-                           (const u32x4 *)(wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32), params + h->off_dil_b[k], n, H4, W4,
-                           UBD_DILATIONS[k], in_bytes);
+        ubd_launch_dilconv16(h, 0, wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32, params + h->off_dil_b[k], nullptr, UBD_DILATIONS[k], cur, nxt, n, H4, W4, st);
         cur = nxt;
     }
     const long npix = (long)n * H4 * W4;
