@@ -49,7 +49,9 @@ def _grad_round(t, grad_dtype):
     return t
 
 
-def _sep(x, dw, pw, b, stride, fml, grad_dtype=None):
+def _sep(x, dw, pw, b, stride, fml, z_grad_dtype=None, dw_grad_dtype=None):
+    """z_grad_dtype rounds the gradient w.r.t. the pre-activation, dw_grad_dtype the gradient w.r.t. the depthwise
+    output (the two gradient tensors the bf16 backward kernels store for a separable layer)."""
     c = x.shape[1]
     dwk = dw.permute(1, 0, 2, 3)                          # (1,C,3,3) -> (C,1,3,3)
     if stride == 2:
@@ -60,7 +62,8 @@ def _sep(x, dw, pw, b, stride, fml, grad_dtype=None):
         x = F.conv2d(x, dwk, None, stride=2, padding=0, groups=c)
     else:
         x = F.conv2d(x, dwk, None, stride=1, padding=1, groups=c)
-    return F.relu(_grad_round(F.conv2d(x, pw, b), grad_dtype))
+    x = _grad_round(x, dw_grad_dtype)
+    return F.relu(_grad_round(F.conv2d(x, pw, b), z_grad_dtype))
 
 
 _ACT_DTYPES = {"bfloat16": torch.bfloat16, "float16": torch.float16}
@@ -78,12 +81,14 @@ def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None, grad_dtype=None):
     """x_nhwc: torch (N,H,W,C).  tw: list from to_torch_weights.  Returns NHWC logits.
     act_dtype "bfloat16"/"float16": hidden activations and the dense dilated kernels are rounded to that type
     (straight-through in the backward pass) -- BASELINE.json configs[2..4].
-    grad_dtype: the gradient w.r.t. the pre-activation of L3 and of the six dilated layers (the G tensors the backward
-    kernels hand from layer to layer) is rounded to that type (the bf16 train step stores them in bf16)."""
+    grad_dtype: the gradient tensors the bf16 train step stores in bf16 are rounded to that type: the gradient w.r.t.
+    the pre-activation of L3 and of the six dilated layers, and w.r.t. the depthwise output of L2 and L3 (the
+    gradients w.r.t. the pre-activations of L1 and L2 only ever exist tile-wise in fp32)."""
     x = x_nhwc.permute(0, 3, 1, 2)
     i = 0
     for li, stride in enumerate((2, 1, 2)):
-        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype if li == 2 else None), act_dtype)
+        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype if li == 2 else None,
+                            grad_dtype if li >= 1 else None), act_dtype)
         i += 3
     for d in DILATIONS:
         z = _grad_round(F.conv2d(x, _ste_round(tw[i], act_dtype), tw[i + 1], padding=d, dilation=d), grad_dtype)

@@ -19,6 +19,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Activation element access: the saved forward activations are fp32 (UBD_F32) or 16-bit (UBD_BF16 / UBD_F16);
 // gradient tensors are always fp32.
@@ -537,7 +538,27 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
             if (oy >= OH) break;
             const int ox = ox0 + i;
             const bool pvalid = ox < OW;
-            // ---- 1. depthwise output (taps are re-read from LDS in step 4 instead of being kept in 54 VGPRs)
+            // ---- 1. G of this pixel, channels 6q..6q+5 (zero outside the map: zero-fixed tile)
+            float g6[6];
+            {
+                const f32x2 *pg = (const f32x2 *)(gtile + (r * 16 + i) * UBD_C + 6 * q);
+                const f32x2 v0 = pg[0], v1 = pg[1], v2 = pg[2];
+                g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
+            }
+            // ---- 2. dDW[i][ch] = sum_co G[i][co] pw[ch][co]  (rows = channels in lane layout, cols = pixels)
+            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
+                if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
+            }
+            float ddwv[CPL];
+            if constexpr (CIN == UBD_C) {
+                ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
+            } else {
+                ddwv[0] = dA[0];
+            }
+            // ---- 3. one pass over the taps: depthwise output (for dpw) and depthwise kernel gradient
             float dwv[CPL];
 #pragma unroll
             for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
@@ -552,45 +573,9 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
                         float v[6];
                         ld_act6<TX>(xpatch, pe, v);
 #pragma unroll
-                        for (int s = 0; s < 6; ++s) dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]);
+                        for (int s = 0; s < 6; ++s) { dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]); ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]); }
                     } else {
                         dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);        // dwk is zero for lanes without a channel
-                    }
-                }
-            // ---- 2. G of this pixel, channels 6q..6q+5 (zero outside the map: zero-fixed tile)
-            float g6[6];
-            {
-                const f32x2 *pg = (const f32x2 *)(gtile + (r * 16 + i) * UBD_C + 6 * q);
-                const f32x2 v0 = pg[0], v1 = pg[1], v2 = pg[2];
-                g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
-            }
-            // ---- 3. dDW[i][ch] = sum_co G[i][co] pw[ch][co]  (rows = channels in lane layout, cols = pixels)
-            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
-                if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
-            }
-            float ddwv[CPL];
-            if constexpr (CIN == UBD_C) {
-                ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
-            } else {
-                ddwv[0] = dA[0];
-            }
-            // ---- 4. depthwise kernel gradient
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int t = ky * 3 + kx;
-                    const int pe = ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
-                    const float *p = xpatch + pe;
-                    if constexpr (CIN == UBD_C) {
-                        float v[6];
-                        ld_act6<TX>(xpatch, pe, v);
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
-                    } else {
                         ddw[t][0] = fmaf(ch_ok ? p[0] : 0.f, ddwv[0], ddw[t][0]);
                     }
                 }
@@ -717,6 +702,8 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
     }
 }
 
+#include "sepbwd16.h"
+
 // ------------------------------------------------------------------------------------ host
 // Workspace of a train step: forward layout (all activations kept; fp32 or 16-bit), then backward fragments,
 // logits, dlogits, fp32 gradient ping-pong buffers, loss scratch, partial-sum matrix.
@@ -774,6 +761,23 @@ static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + 63) / 64), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
+template <int CIN, int STRIDE, int GSRC, typename T>
+static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const unsigned short *D, const unsigned short *maskact,
+                          unsigned short *dDW, const float *dw_own, const float *pw_own, const float *dw_up, float *g_dw, float *g_pw,
+                          float *g_b, float *partials, int n, int H, int W, int OH, int OW, int pad_lo, int DH, int DWd, int pad_up,
+                          float sub, float div, hipStream_t st)
+{
+    using C = sepb16_cfg<CIN, STRIDE, GSRC>;
+    const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
+    int grid = h->num_cus * (C::LDS_BYTES > 78 * 1024 ? 1 : (C::LDS_BYTES > 52 * 1024 || CIN != UBD_C ? 2 : 3));
+    if (grid > tiles) grid = (int)tiles;
+    if (in_u8)
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(256), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+    else
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(256), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + 63) / 64), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
+}
+
 // Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9
 // outputs at quarter resolution; wfrag = forward fp32 fragments (depthwise / pointwise per-lane weights).
 template <typename TX>
@@ -826,8 +830,26 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }
-        hipLaunchKernelGGL((cvt16_to_f32_kernel<TX>), dim3(h->num_cus * 8), dim3(256), 0, st, g16[cur], gq[1], npix * UBD_C / 8);
-        cur = 1;
+        // separable layers: G1 / G2 are built tile-wise in LDS from the bf16 dDW tensor of the layer above (sepbwd16.h)
+        const int pad2 = h->cfg.fml_compatible ? 1 : 0;
+        const float *dw0 = params + h->off_sep_dw[0], *dw1 = params + h->off_sep_dw[1], *dw2 = params + h->off_sep_dw[2];
+        const float *pw0 = params + h->off_sep_pw[0], *pw1 = params + h->off_sep_pw[1], *pw2 = params + h->off_sep_pw[2];
+        unsigned short *ddw3 = (unsigned short *)(ws + T.off_ddw3), *ddw2 = (unsigned short *)(ws + T.off_gb[0]);
+        launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
+                                       grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad2, H4, W4, 0, 0.f, 1.f, st);
+        launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, (const unsigned short *)a2, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
+                                       grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, H4, W4, pad2, 0.f, 1.f, st);
+        float sub = 0.f, div = 1.f;
+        if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
+        const int u8 = in_dtype == UBD_IN_U8;
+        if (h->cfg.c_in == 1)
+            launch_sepb16<1, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+                                       grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
+        else
+            launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+                                       grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
+        UBD_CHECK_HIP(hipGetLastError());
+        return 0;
     } else {
     // head
     hipLaunchKernelGGL((head_dx_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);

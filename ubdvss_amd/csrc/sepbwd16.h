@@ -1,0 +1,392 @@
+// Separable-layer backward of the UBD_BF16 train step (included by backward.hip after sep_bwd_kernel).
+//
+// Same math as sep_bwd_kernel + sep_dx_kernel, but the gradient tensor G = dL/dZ of layers L1 and L2 is never written
+// to memory: the kernel of layer L builds its G tile in LDS from the depthwise-output gradient dDW of the layer ABOVE
+// (a 3x3 depthwise transposed convolution, masked with L's saved output), then runs the usual per-tile work.
+// dDW tensors are stored in bf16.  Per 64-image batch this removes the G1/G2 round trips (2 x 403 MB written and
+// read as fp32) and halves the dDW traffic.
+//
+//   GSRC 0  (L3)  G tile = bf16 tensor G3 written by the dilated data-gradient kernel
+//   GSRC 1  (L1)  G = dwT(dDW of L2; stride 1, pad 1)            * (a1 > 0)
+//   GSRC 2  (L2)  G = dwT(dDW of L3; stride 2, pad_up top/left)  * (a2 > 0)
+//
+// Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers), of the raw bf16 D tile
+// (G3 tile, or dDW-above tile with halo) and of the mask tile; clamped addresses, out-of-map pixels zero-fixed.
+// Phase 1: fp32 G tile [pixel][24] from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q, 17+2q}).
+// Phase 2: as sep_bwd_kernel: depthwise recompute, dDW = G pw^T (MFMA, lands in the depthwise lane layout),
+// ddw (VALU), dpw / db (MFMA through an LDS transpose), dDW stored as bf16.
+#pragma once
+
+template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
+    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int PH = (TH - 1) * STRIDE + 3;
+    static constexpr int PW = 15 * STRIDE + 3;
+    static constexpr int XPIX = PH * PW;
+    static constexpr int GPIX = TH * 16;
+    static constexpr int DROWS = GSRC == 0 ? TH : (GSRC == 1 ? TH + 2 : TH / 2 + 2);
+    static constexpr int DCOLS = GSRC == 0 ? 16 : (GSRC == 1 ? 18 : 10);
+    static constexpr int DPIX = DROWS * DCOLS;
+    static constexpr int MPIX = GSRC == 0 ? 0 : GPIX;
+    // DMA region (16-byte chunks, 3 per bf16 pixel): [X patch (24 ch only)] [D tile] [mask tile]
+    static constexpr int XCHUNKS = (CIN == UBD_C) ? XPIX * 3 : 0;
+    static constexpr int CHUNKS = XCHUNKS + DPIX * 3 + MPIX * 3;
+    static constexpr int ROUNDS = (CHUNKS + 255) / 256;
+    static constexpr int DMA_BYTES = ROUNDS * 256 * 16;
+    static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
+    static constexpr int OFF_DMA = XF32_BYTES;
+    static constexpr int OFF_G = OFF_DMA + DMA_BYTES;                  // fp32 G tile
+    static constexpr int OFF_SDW = OFF_G + GPIX * UBD_C * 4;           // per-wave transpose tiles
+    static constexpr int OFF_WT = OFF_SDW + 4 * 16 * UBD_C * 4;        // own depthwise taps [9][24] fp32 (24-channel layers)
+    static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24] fp32 (kx = 3: zeros)
+    static constexpr int LDS_BYTES = OFF_UT + 12 * UBD_C * 4;
+    static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
+};
+
+template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float &lo, float &hi)
+{
+    lo = (float)__builtin_bit_cast(T, (unsigned short)(w & 0xFFFFu));
+    hi = (float)__builtin_bit_cast(T, (unsigned short)(w >> 16));
+}
+
+template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
+__global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
+                                                        const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
+                                                        const float *__restrict__ dw_own, const float *__restrict__ pw_own,
+                                                        const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
+                                                        int W, int OH, int OW, int pad_lo, int DH, int DW_, int pad_up, float pre_sub,
+                                                        float pre_div)
+{
+    using C = sepb16_cfg<CIN, STRIDE, GSRC>;
+    constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
+    constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;
+    constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];             // ONE LDS object
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, q = lane >> 4;
+    float *xf32 = (float *)lds;                                                  // 1/3-channel patch (fp32)
+    char *dma = lds + C::OFF_DMA;
+    const char *xraw = dma;                                                      // 24-channel patch (bf16)
+    const char *draw = dma + C::XCHUNKS * 16;
+    const char *mraw = draw + C::DPIX * 48;
+    float *gtile = (float *)(lds + C::OFF_G);
+    float (*s_dw)[16][UBD_C] = (float (*)[16][UBD_C])(lds + C::OFF_SDW);
+    float *wt = (float *)(lds + C::OFF_WT), *ut = (float *)(lds + C::OFF_UT);
+
+    // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
+    // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
+    // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
+    if constexpr (CIN == UBD_C)
+        for (int t = threadIdx.x; t < 9 * UBD_C; t += 256) wt[t] = dw_own[t];               // Keras (3,3,C,1): [tap][ch]
+    if constexpr (GSRC != 0)
+        for (int t = threadIdx.x; t < 12 * UBD_C; t += 256) {
+            const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
+            ut[t] = kx < 3 ? dw_up[(ky * 3 + kx) * UBD_C + ch] : 0.f;
+        }
+    float dwk1[9];                                                               // 1/3-channel layers: this lane's taps
+    if constexpr (CIN != UBD_C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwk1[t] = q < CIN ? dw_own[t * CIN + q] : 0.f;
+    }
+    // A operand of the dDW product: A[rho = i][k = q] of step s = pw[ch(rho, tile)][co = chs_q(s)]; the result rows
+    // 4q + r then are this lane's own channels: tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r
+    float apw[6][NT_A];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int co = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+        if constexpr (CIN == UBD_C) {
+            apw[s][0] = pw_own[i * UBD_C + co];
+            apw[s][1] = (i & 3) < 2 ? pw_own[(16 + 2 * (i >> 2) + (i & 3)) * UBD_C + co] : 0.f;
+        } else {
+            apw[s][0] = ((i & 3) == 0 && (i >> 2) < CIN) ? pw_own[(i >> 2) * UBD_C + co] : 0.f;
+        }
+    }
+    const bool ch_ok = (CIN == UBD_C) || (q < CIN);
+    const int cb = (q < CIN) ? q : 0;                                            // 1/3 channels
+    // GSRC 2 (stride-2 transposed conv): the taps that reach this lane's pixel column have kx = par, par + 2
+    const int par = (i + pad_up) & 1;
+
+    float ddw[9][CPL];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) ddw[t][s] = 0.f;
+    f32x4 accpw[MT_PW][2] = {};
+
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
+    const int total = n * tiles_y * tiles_x;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
+        const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
+        const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
+        const int img = (int)((unsigned)rr / (unsigned)tiles_y);
+        const int oy0 = ty * C::TH, ox0 = tx * 16;
+        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        // origin of the D tile in the D tensor
+        const int dy0 = GSRC == 0 ? oy0 : (GSRC == 1 ? oy0 - 1 : (oy0 >> 1) - 1);
+        const int dx0 = GSRC == 0 ? ox0 : (GSRC == 1 ? ox0 - 1 : (ox0 >> 1) - 1);
+        __syncthreads();                                               // previous tile fully consumed
+        // ---- phase 0: LDS-DMA, clamped addresses
+#pragma unroll 2
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int cbase = rd * 256 + wid * 64;
+            int c = cbase + lane;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const char *src;
+            if (CIN == UBD_C && c < C::XCHUNKS) {
+                const int pix = c / 3, part = c - pix * 3;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                int gy = iy0 + pr, gx = ix0 + pc;
+                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                src = (const char *)xin + (((size_t)img * H + gy) * W + gx) * (UBD_C * 2) + part * 16;
+            } else if (c < C::XCHUNKS + C::DPIX * 3) {
+                const int cd = c - C::XCHUNKS;
+                const int pix = cd / 3, part = cd - pix * 3;
+                const int pr = pix / C::DCOLS, pc = pix - pr * C::DCOLS;
+                int gy = dy0 + pr, gx = dx0 + pc;
+                gy = gy < 0 ? 0 : (gy >= DH ? DH - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= DW_ ? DW_ - 1 : gx);
+                src = (const char *)D + (((size_t)img * DH + gy) * DW_ + gx) * (UBD_C * 2) + part * 16;
+            } else {
+                const int cm = c - C::XCHUNKS - C::DPIX * 3;
+                const int pix = cm / 3, part = cm - pix * 3;
+                int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+                gy = gy >= OH ? OH - 1 : gy;
+                gx = gx >= OW ? OW - 1 : gx;
+                src = (const char *)maskact + (((size_t)img * OH + gy) * OW + gx) * (UBD_C * 2) + part * 16;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dma + cbase * 16), 16, 0, 0);
+        }
+        if constexpr (CIN != UBD_C) {                                  // small-channel input: through registers
+            for (int e = threadIdx.x; e < C::XPIX * CIN; e += 256) {
+                const int pix = e / CIN, ch = e - pix * CIN;
+                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                const int gy = iy0 + pr, gx = ix0 + pc;
+                float v = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
+                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
+                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
+                }
+                xf32[e] = v;
+            }
+        }
+        __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
+        {
+            const bool xborder = (CIN == UBD_C) && ((iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W));
+            const bool dborder = (dy0 < 0) || (dx0 < 0) || (dy0 + C::DROWS > DH) || (dx0 + C::DCOLS > DW_);
+            const bool mborder = (GSRC != 0) && ((oy0 + C::TH > OH) || (ox0 + 16 > OW));
+            if (xborder || dborder || mborder) {                       // block-uniform
+                const u32x4 zero = {0u, 0u, 0u, 0u};
+                if (xborder)
+                    for (int pix = threadIdx.x; pix < C::XPIX; pix += 256) {
+                        const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                        const int gy = iy0 + pr, gx = ix0 + pc;
+                        if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
+                            u32x4 *z = (u32x4 *)(dma + pix * 48);
+                            z[0] = zero; z[1] = zero; z[2] = zero;
+                        }
+                    }
+                if (dborder)
+                    for (int pix = threadIdx.x; pix < C::DPIX; pix += 256) {
+                        const int pr = pix / C::DCOLS, pc = pix - pr * C::DCOLS;
+                        const int gy = dy0 + pr, gx = dx0 + pc;
+                        if (gy < 0 || gy >= DH || gx < 0 || gx >= DW_) {
+                            u32x4 *z = (u32x4 *)(dma + C::XCHUNKS * 16 + pix * 48);
+                            z[0] = zero; z[1] = zero; z[2] = zero;
+                        }
+                    }
+                if (mborder)
+                    for (int pix = threadIdx.x; pix < C::MPIX; pix += 256)
+                        if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
+                            u32x4 *z = (u32x4 *)(dma + C::XCHUNKS * 16 + C::DPIX * 48 + pix * 48);
+                            z[0] = zero; z[1] = zero; z[2] = zero;
+                        }
+                __syncthreads();
+            }
+        }
+        // ---- phase 1: fp32 G tile
+#pragma unroll 1
+        for (int r = wid; r < C::TH; r += 4) {
+            float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (GSRC == 0) {
+                const char *pd = draw + (r * 16 + i) * 48;
+                const u32x2 a = *(const u32x2 *)(pd + 8 * q);
+                const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
+                widen2b<T>(a[0], acc[0], acc[1]); widen2b<T>(a[1], acc[2], acc[3]); widen2b<T>(b, acc[4], acc[5]);
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    int dr;
+                    if constexpr (GSRC == 1) dr = r + 2 - ky;
+                    else {
+                        if (((r + pad_up - ky) & 1) != 0) continue;     // wave-uniform: row parity (oy0 is even)
+                        dr = ((r + pad_up - ky) >> 1) + 1;
+                    }
+#pragma unroll
+                    for (int j = 0; j < (GSRC == 1 ? 3 : 2); ++j) {
+                        int kx, dc;
+                        if constexpr (GSRC == 1) { kx = j; dc = i + 2 - j; }
+                        else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
+                        const char *pd = draw + (dr * C::DCOLS + dc) * 48;
+                        const u32x2 a = *(const u32x2 *)(pd + 8 * q);
+                        const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
+                        const float *pu = ut + (ky * 4 + kx) * UBD_C;
+                        const f32x4 w4 = *(const f32x4 *)(pu + 4 * q);
+                        const f32x2 w2 = *(const f32x2 *)(pu + 16 + 2 * q);
+                        float v[6];
+                        widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
+                        acc[0] = fmaf(v[0], w4[0], acc[0]); acc[1] = fmaf(v[1], w4[1], acc[1]);
+                        acc[2] = fmaf(v[2], w4[2], acc[2]); acc[3] = fmaf(v[3], w4[3], acc[3]);
+                        acc[4] = fmaf(v[4], w2[0], acc[4]); acc[5] = fmaf(v[5], w2[1], acc[5]);
+                    }
+                }
+                const char *pm = mraw + (r * 16 + i) * 48;
+                const u32x2 ma = *(const u32x2 *)(pm + 8 * q);
+                const unsigned mb = *(const unsigned *)(pm + 32 + 4 * q);
+                acc[0] = (short)(ma[0] & 0xFFFFu) > 0 ? acc[0] : 0.f; acc[1] = ((int)ma[0] >> 16) > 0 ? acc[1] : 0.f;
+                acc[2] = (short)(ma[1] & 0xFFFFu) > 0 ? acc[2] : 0.f; acc[3] = ((int)ma[1] >> 16) > 0 ? acc[3] : 0.f;
+                acc[4] = (short)(mb & 0xFFFFu) > 0 ? acc[4] : 0.f;    acc[5] = ((int)mb >> 16) > 0 ? acc[5] : 0.f;
+            }
+            float *pg = gtile + (r * 16 + i) * UBD_C;
+            *(f32x4 *)(pg + 4 * q) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *(f32x2 *)(pg + 16 + 2 * q) = f32x2{acc[4], acc[5]};
+        }
+        __syncthreads();
+
+        // ---- phase 2 (per row tile, as sep_bwd_kernel)
+#pragma unroll 1
+        for (int r = wid; r < C::TH; r += 4) {
+            const int oy = oy0 + r;
+            if (oy >= OH) break;
+            const int ox = ox0 + i;
+            const bool pvalid = ox < OW;
+            // G of this pixel in the k-split {4q..4q+3, 16+2q, 17+2q} and dDW[i][ch] = sum_co G[i][co] pw[ch][co] first
+            // (rows = this lane's channels, cols = pixels), then ONE pass over the taps feeds both the depthwise
+            // recompute (for dpw) and the depthwise kernel gradient
+            float g6[6];
+            {
+                const float *pg = gtile + (r * 16 + i) * UBD_C;
+                const f32x4 g4 = *(const f32x4 *)(pg + 4 * q);
+                const f32x2 g2 = *(const f32x2 *)(pg + 16 + 2 * q);
+                g6[0] = g4[0]; g6[1] = g4[1]; g6[2] = g4[2]; g6[3] = g4[3]; g6[4] = g2[0]; g6[5] = g2[1];
+            }
+            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
+                if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
+            }
+            float ddwv[CPL];
+            if constexpr (CIN == UBD_C) {
+                ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
+            } else {
+                ddwv[0] = dA[0];
+            }
+            float dwv[CPL];
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int t = ky * 3 + kx;
+                    const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
+                    if constexpr (CIN == UBD_C) {
+                        const char *px = xraw + pix * 48;
+                        const u32x2 a = *(const u32x2 *)(px + 8 * q);
+                        const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
+                        const f32x4 w4 = *(const f32x4 *)(wt + t * UBD_C + 4 * q);
+                        const f32x2 w2 = *(const f32x2 *)(wt + t * UBD_C + 16 + 2 * q);
+                        float v[6];
+                        widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
+                        dwv[0] = fmaf(v[0], w4[0], dwv[0]); dwv[1] = fmaf(v[1], w4[1], dwv[1]);
+                        dwv[2] = fmaf(v[2], w4[2], dwv[2]); dwv[3] = fmaf(v[3], w4[3], dwv[3]);
+                        dwv[4] = fmaf(v[4], w2[0], dwv[4]); dwv[5] = fmaf(v[5], w2[1], dwv[5]);
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
+                    } else {
+                        const float v = xf32[pix * CIN + cb];
+                        dwv[0] = fmaf(v, dwk1[t], dwv[0]);              // dwk1 is zero for lanes without a channel
+                        ddw[t][0] = fmaf(v, ddwv[0], ddw[t][0]);
+                    }
+                }
+            // DW transposed through this wave's LDS tile for the dpw / db product (A = [channel][pixel])
+            if constexpr (CIN == UBD_C) {
+                *(f32x4 *)&s_dw[wid][i][4 * q] = f32x4{dwv[0], dwv[1], dwv[2], dwv[3]};
+                *(f32x2 *)&s_dw[wid][i][16 + 2 * q] = f32x2{dwv[4], dwv[5]};
+            } else {
+                if (ch_ok) s_dw[wid][i][cb] = dwv[0];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int pr = 4 * g4 + q;
+                const float *gp = gtile + (r * 16 + pr) * UBD_C;
+                const float b0 = gp[i];
+                const float b1 = i < 8 ? gp[16 + i] : 0.f;
+                float a0, a1 = 0.f;
+                if constexpr (CIN == UBD_C) {
+                    a0 = s_dw[wid][pr][i];
+                    a1 = i < 8 ? s_dw[wid][pr][16 + i] : (i == 8 ? 1.f : 0.f);
+                } else {
+                    a0 = i < CIN ? s_dw[wid][pr][i] : (i == CIN ? 1.f : 0.f);
+                }
+                accpw[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accpw[0][0], 0, 0, 0);
+                accpw[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accpw[0][1], 0, 0, 0);
+                if constexpr (MT_PW == 2) {
+                    accpw[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accpw[1][0], 0, 0, 0);
+                    accpw[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accpw[1][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (CIN == UBD_C) {
+                if (dDW != nullptr && pvalid) {                        // bf16: 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
+                    char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
+                    u32x2 o;
+                    o[0] = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[1]) << 16);
+                    o[1] = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[3]) << 16);
+                    *(u32x2 *)(pd + 8 * q) = o;
+                    *(unsigned *)(pd + 32 + 4 * q) = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[4]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[5]) << 16);
+                }
+            }
+        }
+    }
+    // ---- flush: wave-sequential reduction of the per-lane sums into this block's row of the partial-sum matrix
+    //      row layout: [9*CIN depthwise | CIN*24 pointwise | 24 bias]
+    __syncthreads();
+    float *red = (float *)lds;
+    for (int t = threadIdx.x; t < C::PART; t += blockDim.x) red[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CPL; ++s) {
+            float v = ddw[t][s];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            ddw[t][s] = v;
+        }
+    for (int ph = 0; ph < 4; ++ph) {
+        if (wid == ph) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < CPL; ++s)
+                    if (i == 0 && ch_ok) red[t * CIN + ((CIN == UBD_C) ? (s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4)) : cb)] += ddw[t][s];
+#pragma unroll
+            for (int mt = 0; mt < MT_PW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + 4 * q + r, col = i + 16 * nt;
+                        if (col < UBD_C && row <= CIN) red[9 * CIN + row * UBD_C + col] += accpw[mt][nt][r];   // row CIN = bias
+                    }
+        }
+        __syncthreads();
+    }
+    float *prow = partials + (size_t)blockIdx.x * C::PART;
+    for (int t = threadIdx.x; t < C::PART; t += blockDim.x) prow[t] = red[t];
+}
