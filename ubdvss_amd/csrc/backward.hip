@@ -772,9 +772,9 @@ static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const u
     int grid = h->num_cus * (C::LDS_BYTES > 78 * 1024 ? 1 : (C::LDS_BYTES > 52 * 1024 || CIN != UBD_C ? 2 : 3));
     if (grid > tiles) grid = (int)tiles;
     if (in_u8)
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(256), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
     else
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(256), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + 63) / 64), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 

@@ -11,7 +11,9 @@ for f in api forward fwd16 wino postprocess loss backward train; do
   extra=""
   # OpenCV-exact float geometry: no FMA contraction in postprocess
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
-  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ common.h -nt _obj/$f.o ] || [ ../../include/ubd.h -nt _obj/$f.o ]; then
+  stale=0
+  for dep in $f.hip *.h ../../include/ubd.h; do [ "$dep" -nt _obj/$f.o ] && stale=1; done
+  if [ ! -f _obj/$f.o ] || [ $stale = 1 ]; then
     ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj/$f.o ${UBD_SAVE_TEMPS:+-save-temps=obj} ) &
     pids+=($!)
   fi

@@ -17,7 +17,11 @@
 // ddw (VALU), dpw / db (MFMA through an LDS transpose), dDW stored as bf16.
 #pragma once
 
+// NW = waves per block: the 1/3-channel layer needs few registers, so 6 waves share one tile's LDS (3 waves per SIMD at two
+// blocks per CU); the 24-channel layers hold 54 + 16 accumulators per lane and run 4 waves per block.
 template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
+    static constexpr int NW = 4;
+    static constexpr int NT = NW * 64;
     static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
@@ -27,16 +31,20 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int DCOLS = GSRC == 0 ? 16 : (GSRC == 1 ? 18 : 10);
     static constexpr int DPIX = DROWS * DCOLS;
     static constexpr int MPIX = GSRC == 0 ? 0 : GPIX;
-    // DMA region (16-byte chunks, 3 per bf16 pixel): [X patch (24 ch only)] [D tile] [mask tile]
+    // DMA regions (16-byte chunks, 3 per bf16 pixel; each region is a whole number of 1 KiB wave-instructions):
+    // [X patch (24 ch only)] [D tile] [mask tile]
     static constexpr int XCHUNKS = (CIN == UBD_C) ? XPIX * 3 : 0;
-    static constexpr int CHUNKS = XCHUNKS + DPIX * 3 + MPIX * 3;
-    static constexpr int ROUNDS = (CHUNKS + 255) / 256;
-    static constexpr int DMA_BYTES = ROUNDS * 256 * 16;
+    static constexpr int XI = (XCHUNKS + 63) / 64, DI = (DPIX * 3 + 63) / 64, MI = (MPIX * 3 + 63) / 64;   // wave-instructions
+    static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW, MK = (MI + NW - 1) / NW;         // per wave
+    static constexpr int OFF_D = XI * 1024, OFF_M = OFF_D + DI * 1024;     // byte offsets inside the DMA area
+    static constexpr int DMA_BYTES = (XI + DI + MI) * 1024;
+    static constexpr int XREGS = (CIN == UBD_C) ? 1 : (XPIX * CIN + NT - 1) / NT;                           // staged input elements per thread
     static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
     static constexpr int OFF_DMA = XF32_BYTES;
     static constexpr int OFF_G = OFF_DMA + DMA_BYTES;                  // fp32 G tile
     static constexpr int OFF_SDW = OFF_G + GPIX * UBD_C * 4;           // per-wave transpose tiles
-    static constexpr int OFF_WT = OFF_SDW + 4 * 16 * UBD_C * 4;        // own depthwise taps [9][24] fp32 (24-channel layers)
+    static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // channels per pixel of the transpose tiles
+    static constexpr int OFF_WT = OFF_SDW + NW * 16 * SDW_W * 4;        // own depthwise taps [9][24] fp32 (24-channel layers)
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24] fp32 (kx = 3: zeros)
     static constexpr int LDS_BYTES = OFF_UT + 12 * UBD_C * 4;
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
@@ -46,6 +54,34 @@ template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float 
 {
     lo = (float)__builtin_bit_cast(T, (unsigned short)(w & 0xFFFFu));
     hi = (float)__builtin_bit_cast(T, (unsigned short)(w >> 16));
+}
+
+// LDS-DMA of one staged region (NINSTR wave-instructions of 64 x 16 B; wave `wid` of NW issues every NW-th): interior
+// tiles add a precomputed per-lane offset to the tile origin, border tiles clamp every pixel into the tensor.
+template <int NK, int NINSTR, int NCHUNKS, int COLS, int NW, int UNROLL>
+__device__ __forceinline__ void sepb16_stage(const char *__restrict__ tensor, int img, int th, int tw, int y0, int x0,
+                                             const int (&rel)[NK > 0 ? NK : 1], bool border, char *dst, int lane, int wid)
+{
+    const char *origin = tensor + (((long)img * th + y0) * tw + x0) * (UBD_C * 2);      // only dereferenced when interior
+#pragma unroll UNROLL
+    for (int k = 0; k < NK; ++k) {
+        const int instr = k * NW + wid;
+        if (instr >= NINSTR) break;                                       // wave-uniform
+        const char *src;
+        if (!border) src = origin + rel[k];
+        else {
+            int c = instr * 64 + lane;
+            c = c < NCHUNKS ? c : NCHUNKS - 1;
+            const int pix = c / 3, part = c - pix * 3;
+            const int pr = pix / COLS, pc = pix - pr * COLS;
+            int gy = y0 + pr, gx = x0 + pc;
+            gy = gy < 0 ? 0 : (gy >= th ? th - 1 : gy);
+            gx = gx < 0 ? 0 : (gx >= tw ? tw - 1 : gx);
+            src = tensor + (((size_t)img * th + gy) * tw + gx) * (UBD_C * 2) + part * 16;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(dst + instr * 1024), 16, 0, 0);
+    }
 }
 
 template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
@@ -66,19 +102,19 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     float *xf32 = (float *)lds;                                                  // 1/3-channel patch (fp32)
     char *dma = lds + C::OFF_DMA;
     const char *xraw = dma;                                                      // 24-channel patch (bf16)
-    const char *draw = dma + C::XCHUNKS * 16;
-    const char *mraw = draw + C::DPIX * 48;
+    const char *draw = dma + C::OFF_D;
+    const char *mraw = dma + C::OFF_M;
     float *gtile = (float *)(lds + C::OFF_G);
-    float (*s_dw)[16][UBD_C] = (float (*)[16][UBD_C])(lds + C::OFF_SDW);
+    float (*s_dw)[16][C::SDW_W] = (float (*)[16][C::SDW_W])(lds + C::OFF_SDW);
     float *wt = (float *)(lds + C::OFF_WT), *ut = (float *)(lds + C::OFF_UT);
 
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
     // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
     if constexpr (CIN == UBD_C)
-        for (int t = threadIdx.x; t < 9 * UBD_C; t += 256) wt[t] = dw_own[t];               // Keras (3,3,C,1): [tap][ch]
+        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) wt[t] = dw_own[t];               // Keras (3,3,C,1): [tap][ch]
     if constexpr (GSRC != 0)
-        for (int t = threadIdx.x; t < 12 * UBD_C; t += 256) {
+        for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
             ut[t] = kx < 3 ? dw_up[(ky * 3 + kx) * UBD_C + ch] : 0.f;
         }
@@ -105,6 +141,36 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     // GSRC 2 (stride-2 transposed conv): the taps that reach this lane's pixel column have kx = par, par + 2
     const int par = (i + pad_up) & 1;
 
+    // staging offsets of interior tiles (everything inside its tensor): byte offset of this lane's 16-byte chunk relative
+    // to the tile origin, per wave-instruction; border tiles recompute clamped addresses
+    auto chunk_rel = [&](int instr, int nchunks, int cols, int row_pitch_pix) {
+        int c = instr * 64 + lane;
+        c = c < nchunks ? c : nchunks - 1;
+        const int pix = c / 3, part = c - pix * 3;
+        const int pr = pix / cols, pc = pix - pr * cols;
+        return (pr * row_pitch_pix + pc) * (UBD_C * 2) + part * 16;
+    };
+    // (the 24-channel kernels have no registers to spare for them and always take the clamped path)
+    constexpr bool PRE = (CIN != UBD_C);
+    int xrel[C::XK > 0 ? C::XK : 1], drel[C::DK], mrel[C::MK > 0 ? C::MK : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < C::DK; ++k) drel[k] = chunk_rel(k * C::NW + wid, C::DPIX * 3, C::DCOLS, DW_);
+#pragma unroll
+        for (int k = 0; k < C::MK; ++k) mrel[k] = chunk_rel(k * C::NW + wid, C::MPIX * 3, 16, OW);
+    }
+    int ld_rel[C::XREGS];                                                       // 1/3 channels: element offsets
+    if constexpr (CIN != UBD_C) {
+#pragma unroll
+        for (int k = 0; k < C::XREGS; ++k) {
+            int e = k * C::NT + (int)threadIdx.x;
+            e = e < C::XPIX * CIN ? e : C::XPIX * CIN - 1;
+            const int pix = e / CIN, ch = e - pix * CIN;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            ld_rel[k] = (pr * W + pc) * CIN + ch;
+        }
+    }
+
     float ddw[9][CPL];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -114,73 +180,90 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
 
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
     const int total = n * tiles_y * tiles_x;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    // Tile geometry and the staging steps.  Pipeline per tile: [X patch DMA (24 ch)] -> wait -> phase 1 (D, mask -> G tile)
+    // -> D / mask DMA of the NEXT tile (their LDS regions are free again) and, for 1/3 channels, the next tile's input
+    // loads into registers -> phase 2.  Only the 24-channel X patch (single-buffered) is fetched with exposed latency.
+    struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder, mborder; };
+    auto tile_geom = [&](int tile) {
+        geom g;
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
         const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
         const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
-        const int img = (int)((unsigned)rr / (unsigned)tiles_y);
-        const int oy0 = ty * C::TH, ox0 = tx * 16;
-        const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
-        // origin of the D tile in the D tensor
-        const int dy0 = GSRC == 0 ? oy0 : (GSRC == 1 ? oy0 - 1 : (oy0 >> 1) - 1);
-        const int dx0 = GSRC == 0 ? ox0 : (GSRC == 1 ? ox0 - 1 : (ox0 >> 1) - 1);
-        __syncthreads();                                               // previous tile fully consumed
-        // ---- phase 0: LDS-DMA, clamped addresses
-#pragma unroll 2
-        for (int rd = 0; rd < C::ROUNDS; ++rd) {
-            const int cbase = rd * 256 + wid * 64;
-            int c = cbase + lane;
-            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
-            const char *src;
-            if (CIN == UBD_C && c < C::XCHUNKS) {
-                const int pix = c / 3, part = c - pix * 3;
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                int gy = iy0 + pr, gx = ix0 + pc;
-                gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-                gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-                src = (const char *)xin + (((size_t)img * H + gy) * W + gx) * (UBD_C * 2) + part * 16;
-            } else if (c < C::XCHUNKS + C::DPIX * 3) {
-                const int cd = c - C::XCHUNKS;
-                const int pix = cd / 3, part = cd - pix * 3;
-                const int pr = pix / C::DCOLS, pc = pix - pr * C::DCOLS;
-                int gy = dy0 + pr, gx = dx0 + pc;
-                gy = gy < 0 ? 0 : (gy >= DH ? DH - 1 : gy);
-                gx = gx < 0 ? 0 : (gx >= DW_ ? DW_ - 1 : gx);
-                src = (const char *)D + (((size_t)img * DH + gy) * DW_ + gx) * (UBD_C * 2) + part * 16;
-            } else {
-                const int cm = c - C::XCHUNKS - C::DPIX * 3;
-                const int pix = cm / 3, part = cm - pix * 3;
-                int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
-                gy = gy >= OH ? OH - 1 : gy;
-                gx = gx >= OW ? OW - 1 : gx;
-                src = (const char *)maskact + (((size_t)img * OH + gy) * OW + gx) * (UBD_C * 2) + part * 16;
+        g.img = (int)((unsigned)rr / (unsigned)tiles_y);
+        g.oy0 = ty * C::TH; g.ox0 = tx * 16;
+        g.ix0 = g.ox0 * STRIDE - pad_lo; g.iy0 = g.oy0 * STRIDE - pad_lo;
+        g.dy0 = GSRC == 0 ? g.oy0 : (GSRC == 1 ? g.oy0 - 1 : (g.oy0 >> 1) - 1);       // origin of the D tile in the D tensor
+        g.dx0 = GSRC == 0 ? g.ox0 : (GSRC == 1 ? g.ox0 - 1 : (g.ox0 >> 1) - 1);
+        g.xborder = (g.iy0 < 0) || (g.ix0 < 0) || (g.iy0 + C::PH > H) || (g.ix0 + C::PW > W);
+        g.dborder = (g.dy0 < 0) || (g.dx0 < 0) || (g.dy0 + C::DROWS > DH) || (g.dx0 + C::DCOLS > DW_);
+        g.mborder = (GSRC != 0) && ((g.oy0 + C::TH > OH) || (g.ox0 + 16 > OW));
+        return g;
+    };
+    auto stage_dm = [&](const geom &g) {
+        sepb16_stage<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW, (PRE ? C::DK : 1)>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, drel, g.dborder || !PRE, dma + C::OFF_D, lane, wid);
+        if constexpr (GSRC != 0)
+            sepb16_stage<C::MK, C::MI, C::MPIX * 3, 16, C::NW, (PRE ? C::MK : 1)>((const char *)maskact, g.img, OH, OW, g.oy0, g.ox0, mrel, g.mborder || !PRE, dma + C::OFF_M, lane, wid);
+    };
+    // 1/3-channel input: raw bits (fp32 pattern or zero-extended byte; 0x100 / pre_sub bits = "outside", exactly 0 after the
+    // preprocessing) held in registers across phase 2
+    unsigned xreg[C::XREGS];
+    auto load_x = [&](const geom &g) {
+        if (!g.xborder) {
+            const size_t origin = (((size_t)g.img * H + g.iy0) * W + g.ix0) * CIN;
+#pragma unroll
+            for (int k = 0; k < C::XREGS; ++k) {
+                if constexpr (IN_U8) xreg[k] = ((const unsigned char *)xin)[origin + ld_rel[k]];
+                else xreg[k] = ((const unsigned *)xin)[origin + ld_rel[k]];
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dma + cbase * 16), 16, 0, 0);
-        }
-        if constexpr (CIN != UBD_C) {                                  // small-channel input: through registers
-            for (int e = threadIdx.x; e < C::XPIX * CIN; e += 256) {
-                const int pix = e / CIN, ch = e - pix * CIN;
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                const int gy = iy0 + pr, gx = ix0 + pc;
-                float v = 0.f;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
-                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
-                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
+        } else {
+#pragma unroll
+            for (int k = 0; k < C::XREGS; ++k) {
+                const int e = k * C::NT + (int)threadIdx.x;
+                unsigned v = IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);
+                if (e < C::XPIX * CIN) {
+                    const int pix = e / CIN, ch = e - pix * CIN;
+                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
+                    const int gy = g.iy0 + pr, gx = g.ix0 + pc;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        const size_t ge = (((size_t)g.img * H + gy) * W + gx) * CIN + ch;
+                        if constexpr (IN_U8) v = ((const unsigned char *)xin)[ge];
+                        else v = ((const unsigned *)xin)[ge];
+                    }
                 }
-                xf32[e] = v;
+                xreg[k] = v;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < total) {
+        const geom g0 = tile_geom(tile);
+        stage_dm(g0);
+        if constexpr (CIN != UBD_C) load_x(g0);
+    }
+    for (; tile < total; tile += gridDim.x) {
+        const geom g = tile_geom(tile);
+        const int img = g.img, oy0 = g.oy0, ox0 = g.ox0, ix0 = g.ix0, iy0 = g.iy0, dy0 = g.dy0, dx0 = g.dx0;
+        const bool xborder = g.xborder, dborder = g.dborder, mborder = g.mborder;
+        __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
+        if constexpr (CIN == UBD_C)
+            sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
+        else {
+#pragma unroll
+            for (int k = 0; k < C::XREGS; ++k) {
+                const int e = k * C::NT + (int)threadIdx.x;
+                if (e < C::XPIX * CIN) {
+                    if constexpr (IN_U8) xf32[e] = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
+                    else xf32[e] = (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
+                }
             }
         }
         __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
         {
-            const bool xborder = (CIN == UBD_C) && ((iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W));
-            const bool dborder = (dy0 < 0) || (dx0 < 0) || (dy0 + C::DROWS > DH) || (dx0 + C::DCOLS > DW_);
-            const bool mborder = (GSRC != 0) && ((oy0 + C::TH > OH) || (ox0 + 16 > OW));
-            if (xborder || dborder || mborder) {                       // block-uniform
+            if ((CIN == UBD_C && xborder) || dborder || mborder) {     // block-uniform
                 const u32x4 zero = {0u, 0u, 0u, 0u};
-                if (xborder)
-                    for (int pix = threadIdx.x; pix < C::XPIX; pix += 256) {
+                if (CIN == UBD_C && xborder)
+                    for (int pix = threadIdx.x; pix < C::XPIX; pix += C::NT) {
                         const int pr = pix / C::PW, pc = pix - pr * C::PW;
                         const int gy = iy0 + pr, gx = ix0 + pc;
                         if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
@@ -189,18 +272,18 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                         }
                     }
                 if (dborder)
-                    for (int pix = threadIdx.x; pix < C::DPIX; pix += 256) {
+                    for (int pix = threadIdx.x; pix < C::DPIX; pix += C::NT) {
                         const int pr = pix / C::DCOLS, pc = pix - pr * C::DCOLS;
                         const int gy = dy0 + pr, gx = dx0 + pc;
                         if (gy < 0 || gy >= DH || gx < 0 || gx >= DW_) {
-                            u32x4 *z = (u32x4 *)(dma + C::XCHUNKS * 16 + pix * 48);
+                            u32x4 *z = (u32x4 *)(dma + C::OFF_D + pix * 48);
                             z[0] = zero; z[1] = zero; z[2] = zero;
                         }
                     }
                 if (mborder)
-                    for (int pix = threadIdx.x; pix < C::MPIX; pix += 256)
+                    for (int pix = threadIdx.x; pix < C::MPIX; pix += C::NT)
                         if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
-                            u32x4 *z = (u32x4 *)(dma + C::XCHUNKS * 16 + C::DPIX * 48 + pix * 48);
+                            u32x4 *z = (u32x4 *)(dma + C::OFF_M + pix * 48);
                             z[0] = zero; z[1] = zero; z[2] = zero;
                         }
                 __syncthreads();
@@ -208,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
         }
         // ---- phase 1: fp32 G tile
 #pragma unroll 1
-        for (int r = wid; r < C::TH; r += 4) {
+        for (int r = wid; r < C::TH; r += C::NW) {
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if constexpr (GSRC == 0) {
                 const char *pd = draw + (r * 16 + i) * 48;
@@ -254,10 +337,15 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
             *(f32x2 *)(pg + 16 + 2 * q) = f32x2{acc[4], acc[5]};
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
+            const geom gn = tile_geom(tile + gridDim.x);
+            stage_dm(gn);
+            if constexpr (CIN != UBD_C) load_x(gn);
+        }
 
         // ---- phase 2 (per row tile, as sep_bwd_kernel)
 #pragma unroll 1
-        for (int r = wid; r < C::TH; r += 4) {
+        for (int r = wid; r < C::TH; r += C::NW) {
             const int oy = oy0 + r;
             if (oy >= OH) break;
             const int ox = ox0 + i;
@@ -368,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
             ddw[t][s] = v;
         }
-    for (int ph = 0; ph < 4; ++ph) {
+    for (int ph = 0; ph < C::NW; ++ph) {
         if (wid == ph) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
