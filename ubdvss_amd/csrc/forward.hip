@@ -160,19 +160,21 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
     const int total = n * tiles_y * tiles_x;
 
     // per-lane weights
+    // 24 channels: lane (i, q) owns channels {4q..4q+3, 16+2q, 17+2q} (one ds_read_b128 + one ds_read_b64 per tap); the
+    // fragments are packed for channel 6q'+s', so fetch the entries of this lane's channels
     float dwk[9][CPL];
     float pwf[CPL][2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
-#pragma unroll
     for (int s = 0; s < CPL; ++s) {
-        pwf[s][0] = pwfrag[(s * 2 + 0) * 64 + lane];
-        pwf[s][1] = pwfrag[(s * 2 + 1) * 64 + lane];
+        const int ch = (CIN == UBD_C) ? (s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4)) : 0;
+        const int src_lane = (CIN == UBD_C) ? 16 * (ch / 6) + i : lane, ss = (CIN == UBD_C) ? ch % 6 : s;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwk[t][s] = dwlane[(t * 6 + ss) * 64 + src_lane];
+        pwf[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
+        pwf[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
     }
     const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
-    const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
+    const int cb = (q < CIN) ? q : 0;                                  // 1/3 channels
 
     auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
     // 24 channels: LDS-DMA (global_load_lds_dwordx4): 64 x 16 B per wave instruction land linearly in LDS, no
     // VGPR round trip.  LDS slot c = pix*6 + sp holds chunk part = (sp + 3*f) % 6 of patch pixel pix,
     // f = (patch column >> 3) & 1: rotating every other octet of columns by half a pixel (12 dwords) makes the
-    // ds_read_b64 of 16 neighbouring pixels bank-conflict free at stride 1 (2-way at stride 2).  Out-of-image
+    // ds_read_b128 (channels 4q..4q+3) and ds_read_b64 (channels 16+2q, 17+2q) of 16 neighbouring pixels
+    // bank-conflict free at stride 1 (pixel pitch 24 dwords: 24 i mod 64 repeats after 8 pixels).  Out-of-image
     // pixels are fetched from a clamped address and zeroed afterwards (border tiles only).
     constexpr int ROUNDS = (CIN == UBD_C) ? (C::CHUNKS + 255) / 256 : 1;
     int dma_rel[ROUNDS];           // interior tiles: byte offset of this lane's chunk relative to the patch origin
@@ -339,20 +342,23 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int pcol = i * STRIDE + kx;
-                    int coff = cb;
-                    if constexpr (CIN == UBD_C) { coff = cb + 12 * ((pcol >> 3) & 1); coff = coff >= UBD_C ? coff - UBD_C : coff; }
-                    const float *p = patch + ((r * STRIDE + ky) * C::PW + pcol) * C::PS + coff;
+                    const float *p = patch + ((r * STRIDE + ky) * C::PW + pcol) * C::PS;
                     const int t = ky * 3 + kx;
                     if constexpr (CIN == UBD_C) {
-                        const f32x2 v0 = ((const f32x2 *)p)[0], v1 = ((const f32x2 *)p)[1], v2 = ((const f32x2 *)p)[2];
-                        dwv[0] = fmaf(v0[0], dwk[t][0], dwv[0]);
-                        dwv[1] = fmaf(v0[1], dwk[t][1], dwv[1]);
-                        dwv[2] = fmaf(v1[0], dwk[t][2], dwv[2]);
-                        dwv[3] = fmaf(v1[1], dwk[t][3], dwv[3]);
+                        // 16-byte chunk c of the pixel sits in slot (c + 3f) % 6, f = (patch column >> 3) & 1
+                        const int rot = 3 * ((pcol >> 3) & 1);
+                        int s4 = q + rot, s2 = 4 + (q >> 1) + rot;
+                        s4 = s4 >= 6 ? s4 - 6 : s4; s2 = s2 >= 6 ? s2 - 6 : s2;
+                        const f32x4 v4 = *(const f32x4 *)(p + 4 * s4);
+                        const f32x2 v2 = *(const f32x2 *)(p + 4 * s2 + 2 * (q & 1));
+                        dwv[0] = fmaf(v4[0], dwk[t][0], dwv[0]);
+                        dwv[1] = fmaf(v4[1], dwk[t][1], dwv[1]);
+                        dwv[2] = fmaf(v4[2], dwk[t][2], dwv[2]);
+                        dwv[3] = fmaf(v4[3], dwk[t][3], dwv[3]);
                         dwv[4] = fmaf(v2[0], dwk[t][4], dwv[4]);
                         dwv[5] = fmaf(v2[1], dwk[t][5], dwv[5]);
                     } else {
-                        dwv[0] = fmaf(p[0], dwk[t][0], dwv[0]);      // dwk is zero for lanes without a channel
+                        dwv[0] = fmaf(p[cb], dwk[t][0], dwv[0]);     // dwk is zero for lanes without a channel
                     }
                 }
             }
