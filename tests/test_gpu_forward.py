@@ -115,3 +115,26 @@ def test_error_paths():
         m.predict(np.zeros((1, 32, 32, 1), np.float32))
     with pytest.raises(ValueError):
         m.set_weights(onet.init_weights(1, 1, 0))
+
+
+def test_packed_fragments_follow_the_parameters():
+    """Model.predict_on_device reuses the packed weight fragments of its workspace (UBD_IN_PREPACKED) until the
+    parameters change: in-place torch writes, set_weights and the trainer's Adam step must all invalidate them."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(grey=False)
+    m = Model(cfg, seed=3)
+    x = torch.from_numpy(synthetic.noise_images(5, 2, 64, 64, 3)).cuda()
+    a = m.predict_on_device(x).clone()
+    b = m.predict_on_device(x).clone()                      # second call: prepacked path
+    assert torch.equal(a, b)
+    m.params.mul_(1.5)                                       # in-place torch write
+    ref = Model(cfg, seed=3); ref.params.copy_(m.params)
+    assert torch.equal(m.predict_on_device(x), ref.predict_on_device(x))
+    w = m.get_weights(); w[0] = w[0] * 0.5
+    m.set_weights(w); ref.set_weights(w)
+    assert torch.equal(m.predict_on_device(x), ref.predict_on_device(x))
+    tr = Trainer(m, Adam())
+    y = torch.from_numpy(synthetic.rectangle_maps(6, 2, 16, 16)).cuda()
+    tr.train_step_on_device(x, y)                            # parameters move through the C-ABI
+    ref2 = Model(cfg, seed=3); ref2.params.copy_(m.params)
+    assert torch.equal(m.predict_on_device(x), ref2.predict_on_device(x))

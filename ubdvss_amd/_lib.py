@@ -7,6 +7,7 @@ LIB_PATH = os.path.join(_HERE, "libubd_hip.so")
 
 UBD_F32, UBD_BF16, UBD_F16 = 0, 1, 2
 UBD_IN_F32, UBD_IN_U8 = 0, 1
+UBD_IN_PREPACKED = 0x100
 UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
 ABI_VERSION = 1
 

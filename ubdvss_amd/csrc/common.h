@@ -77,6 +77,7 @@ void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, co
                              const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st);
 size_t ubd_forward16_workspace_bytes(int n, int H, int W);
+int ubd_pack16_workspace(ubd_handle *h, const float *params, char *ws, size_t ws_bytes, hipStream_t st);
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st);
 #define UBD_DIL16_FRAG_U32 (7 * 2 * 64 * 4)          // 16-bit dilated layer: [chunk 7][nt 2][lane 64] x 4 dwords (8 halves)

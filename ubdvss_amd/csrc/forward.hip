@@ -637,6 +637,7 @@ static void launch_dil(const ubd_handle *h, const float *params, const float *wf
 extern "C" int ubd_pack_weights(ubd_handle *h, const float *params, void *workspace, size_t workspace_bytes, void *stream)
 {
     UBD_REQUIRE(h && params && workspace, "ubd_pack_weights: null argument");
+    if (h->cfg.dtype != UBD_F32) return ubd_pack16_workspace(h, params, (char *)workspace, workspace_bytes, (hipStream_t)stream);
     ubd_fwd_layout L;
     ubd_fwd_layout_compute(h, 1, 4, 4, 0, &L);
     UBD_REQUIRE(workspace_bytes >= L.off_a1, "ubd_pack_weights: workspace too small");
@@ -662,6 +663,8 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
                      int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st)
 {
     UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_forward: only UBD_F32 activations are implemented in this build");
+    const bool prepacked = (in_dtype & UBD_IN_PREPACKED) != 0;
+    in_dtype &= ~UBD_IN_PREPACKED;
     UBD_REQUIRE(n > 0 && H > 0 && W > 0 && (H % 4) == 0 && (W % 4) == 0, "ubd_forward: height and width must be positive multiples of 4 (got %d x %d)", H, W);
     UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
     UBD_REQUIRE(!(in_dtype == UBD_IN_U8 && h->cfg.c_in == UBD_C), "ubd_forward: u8 input needs c_in 1 or 3");
@@ -670,7 +673,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     float *wfrag = (float *)(ws + L.off_wfrag);
     float *a1 = (float *)(ws + L.off_a1), *a2 = (float *)(ws + L.off_a2);
 
-    launch_pack(h, params, wfrag, st);
+    if (!prepacked) launch_pack(h, params, wfrag, st);
 
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
@@ -707,7 +710,7 @@ extern "C" int ubd_forward(ubd_handle *h, const float *params, const void *image
     UBD_REQUIRE(h && params && images && logits && workspace, "ubd_forward: null argument");
     if (h->cfg.dtype != UBD_F32) {
         UBD_REQUIRE(n > 0 && height > 0 && width > 0 && (height % 4) == 0 && (width % 4) == 0, "ubd_forward: height and width must be positive multiples of 4 (got %d x %d)", height, width);
-        UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
+        UBD_REQUIRE((in_dtype & ~UBD_IN_PREPACKED) == UBD_IN_F32 || (in_dtype & ~UBD_IN_PREPACKED) == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
         return ubd_forward16(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, workspace_bytes, (hipStream_t)stream);
     }
     ubd_fwd_layout L;

@@ -519,6 +519,17 @@ void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layou
     L->total = off;
 }
 
+int ubd_pack16_workspace(ubd_handle *h, const float *params, char *ws, size_t ws_bytes, hipStream_t st)
+{
+    ubd_fwd16_layout L;
+    ubd_fwd16_layout_compute(1, 4, 4, 0, &L);
+    UBD_REQUIRE(ws_bytes >= L.off_a1, "ubd_pack_weights: workspace too small");
+    ubd_launch_pack_direct(h, params, (float *)(ws + L.off_wfrag32), st);
+    ubd_launch_pack16(h, params, (unsigned *)(ws + L.off_wfrag16), 0, st);
+    UBD_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 size_t ubd_forward16_workspace_bytes(int n, int H, int W)
 {
     ubd_fwd16_layout L;
@@ -579,8 +590,12 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     float *wfrag = (float *)(ws + L.off_wfrag32);
     unsigned *wfrag16 = (unsigned *)(ws + L.off_wfrag16);
     unsigned short *a1 = (unsigned short *)(ws + L.off_a1), *a2 = (unsigned short *)(ws + L.off_a2);
-    ubd_launch_pack_direct(h, params, wfrag, st);                      // fp32 depthwise / pointwise fragments
-    hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], 0);
+    const bool prepacked = (in_dtype & UBD_IN_PREPACKED) != 0;
+    in_dtype &= ~UBD_IN_PREPACKED;
+    if (!prepacked) {
+        ubd_launch_pack_direct(h, params, wfrag, st);                  // fp32 depthwise / pointwise fragments
+        hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], 0);
+    }
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
     const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;

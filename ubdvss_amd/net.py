@@ -163,6 +163,8 @@ class Model:
         self._h = handle
         n = self._lib.ubd_param_count(self._h)
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._packed_key = None      # (workspace, params, versions) the packed fragments in the workspace belong to
+        self._weights_epoch = 0      # bumped by whoever writes self.params through a raw pointer (Trainer)
         self._ws = None
         self._pp_ws = None
         self.set_weights(self._glorot_init(seed))
@@ -251,6 +253,11 @@ class Model:
             out = torch.empty((n, hh // 4, ww // 4, self.k_out), dtype=torch.float32, device=self.device)
         nbytes = self._lib.ubd_forward_workspace_bytes(self._h, n, hh, ww)
         ws = self._workspace("_ws", nbytes)
+        # the packed weight fragments at the head of the workspace stay valid until the parameters change
+        key = (ws.data_ptr(), self.params.data_ptr(), self.params._version, self._weights_epoch)
+        if key == self._packed_key:
+            in_dtype |= _lib.UBD_IN_PREPACKED
+        self._packed_key = key
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ubd_forward(self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre,
                                              n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),

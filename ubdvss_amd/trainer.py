@@ -70,6 +70,7 @@ class Trainer:
             _lib.check(self._lib.ubd_adam_step(self.model.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                                self.v.data_ptr(), self.grads.numel(), self.iterations, o.lr, o.beta_1,
                                                o.beta_2, o.epsilon, grad_scale, self.model._stream()), "ubd_adam_step")
+        self.model._weights_epoch += 1            # parameters changed behind torch's version counter
 
     def train_step_on_device(self, images, targets):
         self.backward_on_device(images, targets)
