@@ -178,6 +178,35 @@ def main():
         train = time_train("bfloat16")
         train_f32 = time_train("float32")
 
+    # ---- extra: configs[4], batch 8 of 1024x1024x3, fp16 activations, forward only ("HBM-bound roofline run")
+    def time_cfg5():
+        n5, side5 = 8, 1024
+        m5 = Model(cfg, dtype="float16", seed=1)
+        x5 = torch.from_numpy(synthetic.noise_images(7 + rank, n5, side5, side5, C_IN)).to(dev)
+        for _ in range(max(2, args.warmup)):
+            m5.predict_on_device(x5)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps5 = max(5, min(args.steps, 20))
+        e0.record()
+        for _ in range(reps5):
+            m5.predict_on_device(x5)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps5
+        bytes_img = side5 * side5 * C_IN * 4.0 + side5 * side5 * 45.0 * 2.0 + (side5 // 4) ** 2 * 4.0   # fp32 image in, fp16 activations (SURVEY 8(d) element count), fp32 logits out
+        res = {"workload": "configs[4]: batch=8 1024x1024x3 fp16 forward, dilations {1,2,4,8,16,1}", "ms_per_batch": round(ms, 4),
+               "images_per_s": round(n5 / ms * 1e3, 1), "dtype": "f16",
+               "roofline": {"bound": "hbm", "achieved": round(n5 * bytes_img / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s",
+                            "frac": round(n5 * bytes_img / (ms * 1e-3) / 1e9 / PEAK_HBM, 4),
+                            "note": "algorithmic bytes: fp32 image read + every 16-bit activation written once and read once + fp32 logits"}}
+        del m5, x5
+        torch.cuda.empty_cache()
+        return res
+
+    cfg5 = None
+    if not args.no_train and rank == 0:
+        cfg5 = time_cfg5()
+
     line = None
     if rank == 0:
         # ---- parts: net only / postprocess only (rectangle maps) -- HIP events on the launch stream
@@ -246,7 +275,7 @@ def main():
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_f32": train_f32,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},

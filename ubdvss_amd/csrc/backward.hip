@@ -1,4 +1,4 @@
-// Backward pass + train-step orchestration of the ubdvss hot path on gfx950 (fp32 path).
+// Backward pass + train-step orchestration of the ubdvss hot path on gfx950.
 //
 // The reference gets its gradients from TensorFlow autodiff of the Keras graph
 // (model.compile / fit_generator, train.py:110-112, :176-188); here every gradient kernel is
@@ -12,8 +12,8 @@
 //   sep_bwd      separable layer: recomputes the depthwise output, dpw/db (MFMA), dDW = G pw^T (MFMA,
 //                lands directly in the depthwise lane layout), ddw (VALU), writes dDW
 //   sep_dx       G_below = depthwise-transpose(dDW) * (X > 0)
-// Weight gradients are accumulated with fp32 atomics into the zeroed flat gradient vector
-// (Keras get_weights() order, same as the parameters).
+// Weight gradients: every block writes one row of a partial-sum matrix, reduce_partials_kernel adds the rows in a
+// fixed order into the flat gradient vector (Keras get_weights() order, same as the parameters).
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,7 +22,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Activation element access: the saved forward activations are fp32 (UBD_F32) or 16-bit (UBD_BF16 / UBD_F16);
-// gradient tensors are always fp32.
+// gradient tensors between layers are fp32, except in UBD_BF16 mode (bf16: bwd16.h, sepbwd16.h).
 template <typename TX> __device__ __forceinline__ float ld_act(const void *base, size_t idx)
 {
     return (float)((const TX *)base)[idx];
