@@ -261,6 +261,44 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict_
     }
 }
 
+// k_out == 1 (detection only, the benchmark configuration): dhk[c] = sum_p a9[p][c] dl[p], dhb = sum_p dl[p] is a
+// plain streaming reduction: one pixel per lane per step (the 24 channels are 96 / 48 contiguous bytes), 25 fp32
+// accumulators per lane, butterfly reduction per wave, one partial row per block (summed by reduce_partials_kernel).
+template <typename TX>
+__global__ __launch_bounds__(256) void head_wgrad1_kernel(const void *__restrict__ a9, const float *__restrict__ dlogits,
+                                                          float *__restrict__ partials, long npix)
+{
+    float acc[UBD_C + 1];
+#pragma unroll
+    for (int c = 0; c <= UBD_C; ++c) acc[c] = 0.f;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const float dl = dlogits[p];
+        float av[UBD_C];
+#pragma unroll
+        for (int c6 = 0; c6 < 4; ++c6) {
+            float t6[6];
+            ld_act6<TX>(a9, (size_t)p * UBD_C + 6 * c6, t6);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) av[6 * c6 + e] = t6[e];
+        }
+#pragma unroll
+        for (int c = 0; c < UBD_C; ++c) acc[c] = fmaf(av[c], dl, acc[c]);
+        acc[UBD_C] += dl;
+    }
+    __shared__ float s_red[4][UBD_C + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c <= UBD_C; ++c) {
+        float v = acc[c];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) s_red[wid][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= UBD_C)
+        partials[(size_t)blockIdx.x * (UBD_C + 1) + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
 #include "bwd16.h"
 
 // ------------------------------------------------------------------------------------ dilated wgrad
@@ -778,6 +816,23 @@ static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const u
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + 63) / 64), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
+template <typename TX>
+static void launch_head_wgrad(const ubd_handle *h, const void *a9, const float *dlogits, float *grads, float *partials, long npix,
+                              hipStream_t st)
+{
+    if (h->k_out == 1) {
+        long g1 = (npix + 255) / 256;
+        if (g1 > h->num_cus * 4) g1 = h->num_cus * 4;
+        hipLaunchKernelGGL((head_wgrad1_kernel<TX>), dim3((int)g1), dim3(256), 0, st, a9, dlogits, partials, npix);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials, (int)g1, UBD_C + 1, grads + h->off_head_k, UBD_C,
+                           grads + h->off_head_b, 1, (float *)nullptr);
+        return;
+    }
+    const long nsteps = (npix + 3) / 4;
+    int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
+    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
+}
+
 // Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9
 // outputs at quarter resolution; wfrag = forward fp32 fragments (depthwise / pointwise per-lane weights).
 template <typename TX>
@@ -813,11 +868,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         unsigned *frag16t = (unsigned *)(bfrag + UBD_BWD_DIRECT_FLOATS);
         ubd_launch_pack16(h, params, frag16t, 1, st);
         hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
-        {
-            const long nsteps = (npix + 3) / 4;
-            int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
-            hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
-        }
+        launch_head_wgrad<TX>(h, acts[6], dlogits, grads, partials, npix, st);
         for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];
@@ -853,11 +904,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     } else {
     // head
     hipLaunchKernelGGL((head_dx_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
-    {
-        const long nsteps = (npix + 3) / 4;
-        int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
-        hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, acts[6], dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
-    }
+    launch_head_wgrad<TX>(h, acts[6], dlogits, grads, partials, npix, st);
     // dilated layers, top to bottom
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
         const void *X = acts[k];                                // input of dilated layer k (= output of the layer below)

@@ -11,7 +11,7 @@
 //                         K = pixels; X and G tiles staged by LDS-DMA as plain [pixel][24 ch] rows, both operands read
 //                         with ds_read_b64_tr_b16 (the K index = pixel is the row index of both LDS images)
 //   (data gradient)       dilconv16_kernel<T, 1> in fwd16.hip
-//   cvt16_to_f32_kernel   G3 -> fp32 for the separable backward kernels
+//   (separable layers)    sepb16_kernel in sepbwd16.h
 #pragma once
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -49,21 +49,6 @@ __global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict_
             }
             pg[c8] = o;
         }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cvt16_to_f32_kernel(const unsigned short *__restrict__ in, float *__restrict__ out, long n8)
-{
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const u32x4 v = ((const u32x4 *)in)[i];
-        f32x4 a, b;
-        a[0] = (float)__builtin_bit_cast(T, (unsigned short)(v[0] & 0xFFFFu)); a[1] = (float)__builtin_bit_cast(T, (unsigned short)(v[0] >> 16));
-        a[2] = (float)__builtin_bit_cast(T, (unsigned short)(v[1] & 0xFFFFu)); a[3] = (float)__builtin_bit_cast(T, (unsigned short)(v[1] >> 16));
-        b[0] = (float)__builtin_bit_cast(T, (unsigned short)(v[2] & 0xFFFFu)); b[1] = (float)__builtin_bit_cast(T, (unsigned short)(v[2] >> 16));
-        b[2] = (float)__builtin_bit_cast(T, (unsigned short)(v[3] & 0xFFFFu)); b[3] = (float)__builtin_bit_cast(T, (unsigned short)(v[3] >> 16));
-        ((f32x4 *)out)[2 * i] = a;
-        ((f32x4 *)out)[2 * i + 1] = b;
     }
 }
 
