@@ -109,14 +109,16 @@ def _out_hw(x, xp, stride, dilation):
     return (xp.shape[1] - span) // stride + 1, (xp.shape[2] - span) // stride + 1
 
 
-def separable_conv(x, dw, pw, b, stride, fml_compatible=True, relu=True):
+def separable_conv(x, dw, pw, b, stride, fml_compatible=True, relu=True, act_dtype=None):
     """SeparableConv2D: depthwise 3x3 (multiplier 1, no bias/activation) ->
-    pointwise 1x1 + bias + relu (net.py:234-246)."""
+    pointwise 1x1 + bias + relu (net.py:234-246).  act_dtype: the depthwise output is stored in that 16-bit type
+    before the pointwise product (16-bit configs)."""
     xp = _pad_for(x, stride, 1, fml_compatible)
     oh, ow = _out_hw(x, xp, stride, 1)
     acc = np.zeros((x.shape[0], oh, ow, x.shape[3]), dtype=x.dtype)
     for ky, kx, xs in _taps(xp, stride, 1, oh, ow):
         acc = acc + xs * dw[ky, kx, :, 0].astype(x.dtype)
+    acc = round_to(acc, act_dtype)
     y = acc @ pw[0, 0].astype(x.dtype) + b.astype(x.dtype)
     return np.maximum(y, 0) if relu else y
 
@@ -150,15 +152,17 @@ def round_to(a, act_dtype):
 def forward(x, weights, fml_compatible=True, dtype=np.float64, return_all=False, act_dtype=None):
     """x: (N,H,W,C_in) already preprocessed.  Returns logits (N,H/4,W/4,1+n_cls);
     with return_all also the list of the 9 hidden activations.
-    act_dtype "bfloat16"/"float16": every hidden activation is rounded to that type when it is stored and the
-    dense dilated kernels are used in that type too (the 16-bit configs of BASELINE.json); accumulation stays
-    in `dtype`, logits are not rounded."""
+    act_dtype "bfloat16"/"float16" (the 16-bit configs of BASELINE.json): every hidden activation -- including the
+    depthwise output inside a separable layer -- is rounded to that type when it is stored, and every 3x3 / depthwise /
+    pointwise kernel of L1..L9 is used in that type; biases, the 1x1 head and all accumulation stay in `dtype`, logits
+    are not rounded."""
     x = np.asarray(x, dtype=dtype)
     w = [np.asarray(a, dtype=dtype) for a in weights]
     acts = []
     i = 0
     for stride in (2, 1, 2):
-        x = round_to(separable_conv(x, w[i], w[i + 1], w[i + 2], stride, fml_compatible), act_dtype)
+        x = round_to(separable_conv(x, round_to(w[i], act_dtype), round_to(w[i + 1], act_dtype), w[i + 2], stride,
+                                    fml_compatible, act_dtype=act_dtype), act_dtype)
         acts.append(x)
         i += 3
     for d in DILATIONS:

@@ -49,10 +49,12 @@ def _grad_round(t, grad_dtype):
     return t
 
 
-def _sep(x, dw, pw, b, stride, fml, z_grad_dtype=None, dw_grad_dtype=None):
+def _sep(x, dw, pw, b, stride, fml, z_grad_dtype=None, dw_grad_dtype=None, act_dtype=None):
     """z_grad_dtype rounds the gradient w.r.t. the pre-activation, dw_grad_dtype the gradient w.r.t. the depthwise
-    output (the two gradient tensors the bf16 backward kernels store for a separable layer)."""
+    output (the two gradient tensors the bf16 backward kernels store for a separable layer); act_dtype: depthwise /
+    pointwise kernels and the depthwise output are used in that 16-bit type (straight-through)."""
     c = x.shape[1]
+    dw, pw = _ste_round(dw, act_dtype), _ste_round(pw, act_dtype)
     dwk = dw.permute(1, 0, 2, 3)                          # (1,C,3,3) -> (C,1,3,3)
     if stride == 2:
         if fml:
@@ -62,7 +64,7 @@ def _sep(x, dw, pw, b, stride, fml, z_grad_dtype=None, dw_grad_dtype=None):
         x = F.conv2d(x, dwk, None, stride=2, padding=0, groups=c)
     else:
         x = F.conv2d(x, dwk, None, stride=1, padding=1, groups=c)
-    x = _grad_round(x, dw_grad_dtype)
+    x = _grad_round(_ste_round(x, act_dtype), dw_grad_dtype)
     return F.relu(_grad_round(F.conv2d(x, pw, b), z_grad_dtype))
 
 
@@ -79,8 +81,9 @@ def _ste_round(t, act_dtype):
 
 def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None, grad_dtype=None):
     """x_nhwc: torch (N,H,W,C).  tw: list from to_torch_weights.  Returns NHWC logits.
-    act_dtype "bfloat16"/"float16": hidden activations and the dense dilated kernels are rounded to that type
-    (straight-through in the backward pass) -- BASELINE.json configs[2..4].
+    act_dtype "bfloat16"/"float16": hidden activations (including the depthwise output of a separable layer) and all
+    3x3 / depthwise / pointwise kernels are rounded to that type (straight-through in the backward pass) --
+    BASELINE.json configs[2..4].
     grad_dtype: the gradient tensors the bf16 train step stores in bf16 are rounded to that type: the gradient w.r.t.
     the pre-activation of L3 and of the six dilated layers, and w.r.t. the depthwise output of L2 and L3 (the
     gradients w.r.t. the pre-activations of L1 and L2 only ever exist tile-wise in fp32)."""
@@ -88,7 +91,7 @@ def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None, grad_dtype=None):
     i = 0
     for li, stride in enumerate((2, 1, 2)):
         x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype if li == 2 else None,
-                            grad_dtype if li >= 1 else None), act_dtype)
+                            grad_dtype if li >= 1 else None, act_dtype), act_dtype)
         i += 3
     for d in DILATIONS:
         z = _grad_round(F.conv2d(x, _ste_round(tw[i], act_dtype), tw[i + 1], padding=d, dilation=d), grad_dtype)

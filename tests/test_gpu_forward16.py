@@ -59,14 +59,17 @@ def test_bf16_full_batch_property_and_postprocess():
     assert out[4].shape == (4,)
 
 
-@pytest.mark.parametrize("dtype,tol", [("bfloat16", 4e-2), ("float16", 6e-3)])
+@pytest.mark.parametrize("dtype,tol64", [("bfloat16", 4e-2), ("float16", 3e-2)])
 @pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 2, 64, 64), (1, 2, 2, 64, 96)])
-def test_train_step_16bit(dtype, tol, cin, ncls, n, hh, ww):
-    """configs[2] (bf16 train step) on small shapes: 16-bit activations + 16-bit MFMA forward, fp32 accumulation /
-    weight gradients / master weights; bf16 mode also keeps the gradient tensors between L3..L9 in bf16 (fp16 mode
-    keeps them fp32).  Oracle: fp64 torch autograd with the same storage roundings (activations and kernels
-    straight-through, gradient tensors by backward hooks).  Gate: loss and every weight-gradient tensor within `tol`
-    (relative L2; bf16 ulp = 0.4 %)."""
+def test_train_step_16bit(dtype, tol64, cin, ncls, n, hh, ww):
+    """configs[2] (bf16 train step) on small shapes: 16-bit activations, kernels and depthwise intermediates, 16-bit
+    MFMA forward, fp32 accumulation / weight gradients / master weights; bf16 mode also keeps the gradient tensors
+    between L3..L9 and the depthwise-output gradients of L2/L3 in bf16 (fp16 mode keeps them fp32).
+    Oracle: torch autograd with the SAME storage roundings (activations and kernels straight-through, gradient tensors
+    by backward hooks).  A storage rounding can flip by one 16-bit ulp between two correct evaluations that accumulate
+    differently (fp32 vs fp64), and such flips compound down the layers, so there are two gates:
+      * against the oracle evaluated in fp32, like the kernels: every weight-gradient tensor within 5e-3 (relative L2);
+      * against the oracle evaluated in fp64: within `tol64` (the fp32-vs-fp64 oracle spread itself reaches 2e-2)."""
     from oracle import net_torch as otorch
     from ubdvss_amd import Trainer, Adam
     cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
@@ -78,17 +81,19 @@ def test_train_step_16bit(dtype, tol, cin, ncls, n, hh, ww):
     x = synthetic.textured_images(92, labels, 4, cin).astype(np.float32) / 127.5 - 1.0
     tr = Trainer(model, Adam())
     tr.backward_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
-    loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, act_dtype=dtype,
-                                                      grad_dtype="bfloat16" if dtype == "bfloat16" else None)
     l = tr.loss.cpu().numpy()
-    assert abs(l[0] - loss_ref) <= tol * abs(loss_ref), (l[0], loss_ref)
     g = tr.grads.cpu().numpy().astype(np.float64)
-    off = 0
-    for (nm, _), gr in zip(onet.weight_shapes(cin, ncls), grads_ref):
-        k = gr.size
-        err = np.linalg.norm(g[off:off + k] - gr.reshape(-1)) / max(np.linalg.norm(gr), 1e-30)
-        assert err <= tol, (nm, err)
-        off += k
+    gdt = "bfloat16" if dtype == "bfloat16" else None
+    for odt, tol in ((torch.float32, 5e-3), (torch.float64, tol64)):
+        loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, dtype=odt, act_dtype=dtype,
+                                                          grad_dtype=gdt)
+        assert abs(l[0] - loss_ref) <= tol * abs(loss_ref), (l[0], loss_ref)
+        off = 0
+        for (nm, _), gr in zip(onet.weight_shapes(cin, ncls), grads_ref):
+            k = gr.size
+            err = np.linalg.norm(g[off:off + k] - gr.reshape(-1)) / max(np.linalg.norm(gr), 1e-30)
+            assert err <= tol, (nm, err, str(odt))
+            off += k
     # and the optimiser step runs on the fp32 master weights
     tr.apply_gradients()
     assert torch.isfinite(model.params).all()

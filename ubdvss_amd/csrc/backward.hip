@@ -27,6 +27,12 @@ template <typename TX> __device__ __forceinline__ float ld_act(const void *base,
 {
     return (float)((const TX *)base)[idx];
 }
+// 16-bit activation modes use every convolution kernel (and the depthwise intermediate) in the activation type
+template <typename TX> __device__ __forceinline__ float rnd_act(float v)
+{
+    if constexpr (sizeof(TX) == 2) return (float)(TX)v;
+    else return v;
+}
 // six consecutive channels starting at element index idx (idx % 2 == 0)
 template <typename TX> __device__ __forceinline__ void ld_act6(const void *base, size_t idx, float (&v)[6])
 {
@@ -456,7 +462,9 @@ template <int CIN, int STRIDE, int XB> struct sepb_cfg {          // XB = bytes 
     static constexpr int LDS_FLOATS = GOFF + ROUNDS * 256 * 4;
 };
 
-template <int CIN, int STRIDE, int IN_U8, typename TX>
+// TX: element type of a 24-channel input patch; TR: activation type of the model (16-bit: kernels and the depthwise
+// output are used rounded to TR, as in the forward pass)
+template <int CIN, int STRIDE, int IN_U8, typename TX, typename TR>
 __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
                                                       const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
@@ -478,12 +486,12 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int s = 0; s < CPL; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+        for (int s = 0; s < CPL; ++s) dwk[t][s] = rnd_act<TR>(dwlane[(t * 6 + s) * 64 + lane]);
     float apw[6][NT_A];
 #pragma unroll
     for (int s = 0; s < 6; ++s)
 #pragma unroll
-        for (int tl = 0; tl < NT_A; ++tl) apw[s][tl] = bwdfrag[(s * 2 + tl) * 64 + lane];
+        for (int tl = 0; tl < NT_A; ++tl) apw[s][tl] = rnd_act<TR>(bwdfrag[(s * 2 + tl) * 64 + lane]);
     const bool ch_ok = (CIN == UBD_C) || (q < CIN);
     const int cb = (CIN == UBD_C) ? 6 * q : (q < CIN ? q : 0);
 
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
             // ---- 5. pointwise kernel / bias gradient: DW transposed through this wave's LDS tile, G read in place
 #pragma unroll
             for (int s = 0; s < CPL; ++s)
-                if (ch_ok) s_dw[wid][i][cb + s] = dwv[s];
+                if (ch_ok) s_dw[wid][i][cb + s] = rnd_act<TR>(dwv[s]);
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int s = 0; s < 6; ++s) dwk[t][s] = dwlane[(t * 6 + s) * 64 + lane];
+        for (int s = 0; s < 6; ++s) dwk[t][s] = rnd_act<TX>(dwlane[(t * 6 + s) * 64 + lane]);
     const int tiles_x = (W + 15) >> 4;
     const int total = n * H * tiles_x;
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -780,7 +788,7 @@ extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int heig
     return T.total;
 }
 
-template <int CIN, int STRIDE, typename TX>
+template <int CIN, int STRIDE, typename TX, typename TR = TX>
 static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
                            const float *bfrag, float *g_dw, float *g_pw, float *g_b, float *partials, int n, int H, int W,
                            int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
@@ -792,9 +800,9 @@ static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const 
     int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
     if (grid > tiles) grid = (int)tiles;
     if (in_u8)
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     else
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + 63) / 64), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
@@ -943,9 +951,9 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
     if (h->cfg.c_in == 1)
-        launch_sep_bwd<1, 2, float>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<1, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     else
-        launch_sep_bwd<3, 2, float>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        launch_sep_bwd<3, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -40,6 +40,24 @@ template <typename T> __device__ __forceinline__ void widen2(unsigned w, float &
 }
 
 
+// acc + a.lo * b.lo + a.hi * b.hi with 16-bit inputs and fp32 accumulation (v_dot2c_f32_{bf16,f16})
+template <typename T> __device__ __forceinline__ float dot2_16(unsigned a, unsigned b, float acc);
+template <> __device__ __forceinline__ float dot2_16<__bf16>(unsigned a, unsigned b, float acc)
+{
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_16<_Float16>(unsigned a, unsigned b, float acc)
+{
+    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), acc, false);
+}
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi)
+{
+    return (unsigned)to_bits<T>(lo) | ((unsigned)to_bits<T>(hi) << 16);
+}
+template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
+
 // ------------------------------------------------------------------------------------ pack
 // 16-bit B fragments of the dilated layers: lane (n = lane&15, q = lane>>4), chunk c, element j:
 //   k = 32c + 8q + j (flat (tap, ci) index, zero for k >= 216), co = n + 16 nt (zero for co >= 24)
@@ -181,17 +199,37 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *pwfrag = frag, *dwlane = frag + UBD_SEP_FRAG_FLOATS;
+    // 16-bit mode uses every convolution kernel in the activation type (oracle: net_numpy.forward act_dtype).
+    // 24 channels: the depthwise taps are packed as (w, 0) / (0, w) 16-bit pairs so that ONE v_dot2c per channel and tap
+    // multiplies the raw 16-bit activation pair from LDS (no widening), and the pointwise product is ONE
+    // v_mfma_f32_16x16x32_{bf16,f16} per N tile: k-slot 8q + e holds channel chs(q, e) for e < 6, zero for e = 6, 7.
+    // 1/3 channels: fp32 image x rounded taps on the VALU, rounded depthwise output, fp32 MFMA (K = 4).
     float dwk[9][CPL], pwf[CPL][2];
+    unsigned dwp[9][CPL];                              // 24 channels: packed tap pairs
+    u32x4 pwb[2];                                      // 24 channels: B operands of the two N tiles
+    if constexpr (CIN == UBD_C) {
+        float pw6[6][2];
 #pragma unroll
-    for (int s = 0; s < CPL; ++s) {
-        // the fragments are packed for channel 6q'+s' (forward.hip); fetch the entry of this lane's channel
-        const int ch = (CIN == UBD_C) ? (s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4)) : 0;
-        const int qs = (CIN == UBD_C) ? ch / 6 : q, ss = (CIN == UBD_C) ? ch % 6 : s;
-        const int src_lane = 16 * qs + i;
+        for (int s = 0; s < 6; ++s) {
+            // the fragments are packed for channel 6q'+s' (forward.hip); fetch the entry of this lane's channel
+            const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+            const int src_lane = 16 * (ch / 6) + i, ss = ch % 6;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dwk[t][s] = dwlane[(t * 6 + ss) * 64 + src_lane];
-        pwf[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
-        pwf[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
+            for (int t = 0; t < 9; ++t) {
+                const unsigned wbits = to_bits<T>(dwlane[(t * 6 + ss) * 64 + src_lane]);
+                dwp[t][s] = (s & 1) ? (wbits << 16) : wbits;
+            }
+            pw6[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
+            pw6[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            pwb[nt] = u32x4{pack2<T>(pw6[0][nt], pw6[1][nt]), pack2<T>(pw6[2][nt], pw6[3][nt]), pack2<T>(pw6[4][nt], pw6[5][nt]), 0u};
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwk[t][0] = round16<T>(dwlane[(t * 6) * 64 + lane]);
+        pwf[0][0] = round16<T>(pwfrag[0 * 64 + lane]);
+        pwf[0][1] = round16<T>(pwfrag[1 * 64 + lane]);
     }
     const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
     const int cb = (q < CIN) ? q : 0;                                       // CIN < 24: this lane's channel (weights are 0 beyond)
@@ -357,20 +395,23 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
                         const char *p = patch + pix * (UBD_C * 2);
                         const u32x2 a = *(const u32x2 *)(p + 8 * q);
                         const unsigned b = *(const unsigned *)(p + 32 + 4 * q);
-                        float v[6];
-                        widen2<T>(a[0], v[0], v[1]); widen2<T>(a[1], v[2], v[3]); widen2<T>(b, v[4], v[5]);
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) dwv[s] = fmaf(v[s], dwk[t][s], dwv[s]);
+                        dwv[0] = dot2_16<T>(a[0], dwp[t][0], dwv[0]); dwv[1] = dot2_16<T>(a[0], dwp[t][1], dwv[1]);
+                        dwv[2] = dot2_16<T>(a[1], dwp[t][2], dwv[2]); dwv[3] = dot2_16<T>(a[1], dwp[t][3], dwv[3]);
+                        dwv[4] = dot2_16<T>(b, dwp[t][4], dwv[4]);    dwv[5] = dot2_16<T>(b, dwp[t][5], dwv[5]);
                     } else {
                         dwv[0] = fmaf(((const float *)patch)[pix * CIN + cb], dwk[t][0], dwv[0]);
                     }
                 }
             }
             acc0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < CPL; ++s) {
-                acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0[k], 0, 0, 0);
-                acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1[k], 0, 0, 0);
+            if constexpr (CIN == UBD_C) {
+                const u32x4 av = {pack2<T>(dwv[0], dwv[1]), pack2<T>(dwv[2], dwv[3]), pack2<T>(dwv[4], dwv[5]), 0u};
+                acc0[k] = h16<T>::mfma(av, pwb[0], acc0[k]);
+                acc1[k] = h16<T>::mfma(av, pwb[1], acc1[k]);
+            } else {
+                const float dr = round16<T>(dwv[0]);
+                acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, pwf[0][0], acc0[k], 0, 0, 0);
+                acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, pwf[0][1], acc1[k], 0, 0, 0);
             }
             const int npx = OW - ox0 < 16 ? OW - ox0 : 16;
             npxs[k] = (oy < OH) ? npx : 0;

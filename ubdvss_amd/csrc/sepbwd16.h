@@ -112,16 +112,16 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
     // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
     if constexpr (CIN == UBD_C)
-        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) wt[t] = dw_own[t];               // Keras (3,3,C,1): [tap][ch]
+        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) wt[t] = (float)(T)dw_own[t];      // Keras (3,3,C,1): [tap][ch]; 16-bit mode uses the kernels in T
     if constexpr (GSRC != 0)
         for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
-            ut[t] = kx < 3 ? dw_up[(ky * 3 + kx) * UBD_C + ch] : 0.f;
+            ut[t] = kx < 3 ? (float)(T)dw_up[(ky * 3 + kx) * UBD_C + ch] : 0.f;
         }
     float dwk1[9];                                                               // 1/3-channel layers: this lane's taps
     if constexpr (CIN != UBD_C) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) dwk1[t] = q < CIN ? dw_own[t * CIN + q] : 0.f;
+        for (int t = 0; t < 9; ++t) dwk1[t] = q < CIN ? (float)(T)dw_own[t * CIN + q] : 0.f;
     }
     // A operand of the dDW product: A[rho = i][k = q] of step s = pw[ch(rho, tile)][co = chs_q(s)]; the result rows
     // 4q + r then are this lane's own channels: tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     for (int s = 0; s < 6; ++s) {
         const int co = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
         if constexpr (CIN == UBD_C) {
-            apw[s][0] = pw_own[i * UBD_C + co];
-            apw[s][1] = (i & 3) < 2 ? pw_own[(16 + 2 * (i >> 2) + (i & 3)) * UBD_C + co] : 0.f;
+            apw[s][0] = (float)(T)pw_own[i * UBD_C + co];
+            apw[s][1] = (i & 3) < 2 ? (float)(T)pw_own[(16 + 2 * (i >> 2) + (i & 3)) * UBD_C + co] : 0.f;
         } else {
-            apw[s][0] = ((i & 3) == 0 && (i >> 2) < CIN) ? pw_own[(i >> 2) * UBD_C + co] : 0.f;
+            apw[s][0] = ((i & 3) == 0 && (i >> 2) < CIN) ? (float)(T)pw_own[(i >> 2) * UBD_C + co] : 0.f;
         }
     }
     const bool ch_ok = (CIN == UBD_C) || (q < CIN);
@@ -401,11 +401,12 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                     }
                 }
             // DW transposed through this wave's LDS tile for the dpw / db product (A = [channel][pixel])
+            // (the forward pass stores the depthwise output in T before the pointwise product)
             if constexpr (CIN == UBD_C) {
-                *(f32x4 *)&s_dw[wid][i][4 * q] = f32x4{dwv[0], dwv[1], dwv[2], dwv[3]};
-                *(f32x2 *)&s_dw[wid][i][16 + 2 * q] = f32x2{dwv[4], dwv[5]};
+                *(f32x4 *)&s_dw[wid][i][4 * q] = f32x4{(float)(T)dwv[0], (float)(T)dwv[1], (float)(T)dwv[2], (float)(T)dwv[3]};
+                *(f32x2 *)&s_dw[wid][i][16 + 2 * q] = f32x2{(float)(T)dwv[4], (float)(T)dwv[5]};
             } else {
-                if (ch_ok) s_dw[wid][i][cb] = dwv[0];
+                if (ch_ok) s_dw[wid][i][cb] = (float)(T)dwv[0];
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
