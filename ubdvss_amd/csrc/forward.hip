@@ -100,6 +100,31 @@ __device__ __forceinline__ void store_tile_relu(float *__restrict__ y, size_t ro
     }
 }
 
+// Epilogue for products issued as D = W^T . X^T (A operand = weights, B operand = activations): the D layout then is
+// col = lane & 15 = PIXEL of the 16-pixel tile, row = 4*(lane>>4) + reg = OUTPUT CHANNEL, so every lane holds four
+// consecutive channels of its pixel and the tile leaves as two 16-byte buffer stores per lane (channels 4q..4q+3, and
+// 16+4q..19+4q from the lanes q < 2) instead of eight scattered dword stores.  bA / bB: the matching bias vectors.
+__device__ __forceinline__ void store_tile_relu_t(float *__restrict__ y, size_t row_base_elems, int x0, int ow,
+                                                  int lane, f32x4 acc0, f32x4 acc1, f32x4 bA, f32x4 bB)
+{
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned long long rp = (unsigned long long)(y + (row_base_elems + (size_t)x0) * UBD_C);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
+    float *rowp = (float *)(((unsigned long long)rhi << 32) | rlo);
+    int npx = ow - x0 < 16 ? ow - x0 : 16;                                    // valid pixels in this tile
+    npx = npx < 0 ? 0 : npx;
+    const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, (int)bytes, 0x00020000);
+    const unsigned base = (unsigned)i * (UBD_C * 4u) + 16u * (unsigned)q;     // beyond `bytes` for pixels >= npx
+    const unsigned base1 = q < 2 ? base + 64u : 0x40000000u;
+    f32x4 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(acc0[r] + bA[r], 0.f); o1[r] = fmaxf(acc1[r] + bB[r], 0.f); }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs, (int)base, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs, (int)base1, 0, 0);
+}
+
 // Backward epilogue: no bias; multiply by the ReLU mask of the layer below (its saved output > 0).
 __device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const float (&mk)[8],
                                                   size_t row_base_elems, int x0, int ow, int lane, f32x4 acc0, f32x4 acc1)
@@ -173,7 +198,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
         pwf[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
         pwf[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
     }
-    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
+    const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int cb = (q < CIN) ? q : 0;                                  // 1/3 channels
 
     auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
@@ -294,10 +320,10 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
             // This tile's DMA must have landed.  vmcnt counts stores too (CDNA4) and __syncthreads() would drain
             // them all (~2 us of store latency per tile): every wave issues exactly NSTORE buffer stores per tile
             // AFTER the next tile's DMA, so "all but the NSTORE youngest" retires the DMA and nothing else.
-            constexpr int NSTORE = (C::TH / 4) * 8;
+            constexpr int NSTORE = (C::TH / 4) * 2;
             if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (NSTORE == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();    // + everyone left the other buffer
             if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_FLOATS);
             const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
@@ -364,11 +390,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
             }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < CPL; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dwv[s], pwf[s][1], acc1, 0, 0, 0);
+            for (int s = 0; s < CPL; ++s) {              // weights as the A operand: D = [channel][pixel] (see store_tile_relu_t)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[s][0], dwv[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[s][1], dwv[s], acc1, 0, 0, 0);
             }
-            store_tile_relu(y, ((size_t)img * OH + oy) * OW, ox0, oy < OH ? OW : 0, lane, acc0, acc1, b0, b1);
+            store_tile_relu_t(y, ((size_t)img * OH + oy) * OW, ox0, oy < OH ? OW : 0, lane, acc0, acc1, bA, bB);
         }
         if (!has_next) break;
         tile = nxt;
