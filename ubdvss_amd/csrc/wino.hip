@@ -15,8 +15,9 @@
 //   * the 16 transform-domain products are 16 small GEMMs [16 tiles x 24 ci] x [24 ci x 24 co] on the
 //     MFMA pipe (6 k-steps x 2 N-tiles each; N = 24 padded to 32), B operands (the pre-transformed
 //     weights U = G g G^T, packed per lane) streamed from LDS with ds_read_b64;
-//   * the MFMA result layout (lane = output channel, registers = tiles) makes the output transform
-//     A^T M A lane-local too; rows of the transform domain are processed one at a time so that only
+//   * the products are issued with the weights as the A operand, so the MFMA result layout is lane = tile,
+//     registers = 4 consecutive output channels: the output transform A^T M A is lane-local too and every output
+//     pixel leaves as 16-byte stores; rows of the transform domain are processed one at a time so that only
 //     4 of the 16 products are live (<= 256 VGPRs, two waves per SIMD);
 //   * epilogue: bias + ReLU (forward) or ReLU mask of the layer below (data gradient, run with the
 //     spatially flipped / channel-transposed kernel).
@@ -93,8 +94,13 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
     for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
-    float b0 = 0.f, b1 = 0.f;
-    if constexpr (EPI == 0) { b0 = ((const float *)aux_)[i]; b1 = (i < 8) ? ((const float *)aux_)[16 + i] : 0.f; }
+    // products are issued as D = U^T . V^T (A operand = weights): D col = lane & 15 = tile, row = 4q + reg = channel, so
+    // a lane ends up with four consecutive channels (4q.. of N-tile 0, 16+4q.. of N-tile 1 for q < 2) of its own tile
+    f32x4 bA = {0.f, 0.f, 0.f, 0.f}, bB = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == 0) {
+        bA = *(const f32x4 *)((const float *)aux_ + 4 * q);
+        if (q < 2) bB = *(const f32x4 *)((const float *)aux_ + 16 + 4 * q);
+    }
     __syncthreads();
 
     const int dm1 = d - 1;
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
     const int stride = nblk_x * 4;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)in_bytes, 0x00020000);   // output: same shape
     const unsigned oob = in_bytes;
 
     // wave-uniform group index kept in SGPRs
@@ -193,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const float av = j < 4 ? V4[b][j] : V2[b][j - 4];
-                    m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ucur[j][0], m0, 0, 0, 0);
-                    m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ucur[j][1], m1, 0, 0, 0);
+                    m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ucur[j][0], av, m0, 0, 0, 0);
+                    m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ucur[j][1], av, m1, 0, 0, 0);
                 }
                 M[b][0] = m0; M[b][1] = m1;
 #pragma unroll
@@ -213,35 +220,44 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
             }
         }
 
-        // ---- epilogue: lane = (co = i, q); register r <-> tile 4q + r of the group
+        // ---- epilogue: lane = (tile i of the group, channel quarter q); registers = 4 consecutive channels
         {
             const int gx = (int)((unsigned)g % (unsigned)groups_x);
             const int rs = (int)((unsigned)g / (unsigned)groups_x);
             const int s = (int)((unsigned)rs % (unsigned)half_rows);
             const int img = (int)((unsigned)rs / (unsigned)half_rows);
             const int y0 = ((s >> log2d) << (log2d + 1)) + (s & dm1);
-            const int co = i;
+            const int tc = gx * 16 + i;
+            const int xo0 = ((tc >> log2d) << (log2d + 1)) + (tc & dm1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tc = gx * 16 + 4 * q + r;
-                const int xo0 = ((tc >> log2d) << (log2d + 1)) + (tc & dm1);
+            for (int rr = 0; rr < 2; ++rr) {
+                const int yo = y0 + rr * d;
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int yo = y0 + rr * d;
+                for (int c = 0; c < 2; ++c) {
+                    const int xo = xo0 + c * d;
+                    const bool ok = yo < h && xo < w;
+                    const unsigned e = ((unsigned)(img * h + yo) * (unsigned)w + (unsigned)xo) * (unsigned)UBD_C + 4u * (unsigned)q;   // element index
+                    const unsigned o0 = ok ? e * 4u : oob;
+                    const unsigned o1 = (ok && q < 2) ? (e + 16u) * 4u : oob;
+                    f32x4 v0, v1;
+                    if constexpr (EPI == 0) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int xo = xo0 + c * d;
-                        if (yo < h && xo < w) {
-                            const size_t e = ((size_t)(img * h + yo) * w + xo) * UBD_C;
-                            if constexpr (EPI == 0) {
-                                y[e + co] = fmaxf(Y[rr][c][0][r] + b0, 0.f);
-                                if (co < 8) y[e + 16 + co] = fmaxf(Y[rr][c][1][r] + b1, 0.f);
-                            } else {
-                                y[e + co] = (float)aux[e + co] > 0.f ? Y[rr][c][0][r] : 0.f;
-                                if (co < 8) y[e + 16 + co] = (float)aux[e + 16 + co] > 0.f ? Y[rr][c][1][r] : 0.f;
+                        for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(Y[rr][c][0][r] + bA[r], 0.f); v1[r] = fmaxf(Y[rr][c][1][r] + bB[r], 0.f); }
+                    } else {
+                        float mk0[4] = {0.f, 0.f, 0.f, 0.f}, mk1[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (ok) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mk0[r] = (float)aux[e + r];
+                            if (q < 2) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) mk1[r] = (float)aux[e + 16 + r];
                             }
                         }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v0[r] = mk0[r] > 0.f ? Y[rr][c][0][r] : 0.f; v1[r] = mk1[r] > 0.f ? Y[rr][c][1][r] : 0.f; }
                     }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)o0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)o1, 0, 0);
                 }
             }
         }
