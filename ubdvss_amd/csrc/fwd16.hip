@@ -88,78 +88,41 @@ __global__ void pack16_kernel(const float *__restrict__ params, unsigned *__rest
 }
 
 // ------------------------------------------------------------------------------------ shared epilogue
-// D layout: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).  y = relu(acc + bias), narrowed to T and
-// written through this wave's 768-byte LDS tile so that the 16 pixels x 48 B leave as 16-byte stores.
+// All products are issued with the weights as the MFMA A operand (D = W^T . X^T): D col = lane & 15 = pixel of the
+// 16-pixel tile, row = 4*(lane>>4) + reg = output channel, i.e. every lane holds channels 4q..4q+3 (N-tile 0) and
+// 16+4q..19+4q (N-tile 1, lanes q < 2) of ITS pixel: the tile leaves as two 8-byte buffer stores per lane, no LDS
+// transpose.  EPI 0: y = relu(acc + bias); EPI 1: y = acc * (mask > 0) with the 16-bit mask words m0 / m1 of the same
+// bytes.  Exactly two unconditional stores per call (callers count them for s_waitcnt vmcnt).
 template <typename T, int EPI>
-__device__ __forceinline__ void store_tile16(unsigned short *__restrict__ y, size_t first_pixel, int npx, int lane,
-                                             unsigned short *__restrict__ stile, f32x4 acc0, f32x4 acc1, float b0, float b1, u32x4 m)
+__device__ __forceinline__ void store_tile16_t(unsigned short *__restrict__ y, size_t first_pixel, int npx, int lane,
+                                               f32x4 acc0, f32x4 acc1, f32x4 bA, f32x4 bB, u32x2 m0, u32x2 m1)
 {
-    const int co = lane & 15, q = lane >> 4;
+    const int i = lane & 15, q = lane >> 4;
+    u32x2 o0, o1;
+    if constexpr (EPI == 0) {
+        o0[0] = pack2<T>(fmaxf(acc0[0] + bA[0], 0.f), fmaxf(acc0[1] + bA[1], 0.f));
+        o0[1] = pack2<T>(fmaxf(acc0[2] + bA[2], 0.f), fmaxf(acc0[3] + bA[3], 0.f));
+        o1[0] = pack2<T>(fmaxf(acc1[0] + bB[0], 0.f), fmaxf(acc1[1] + bB[1], 0.f));
+        o1[1] = pack2<T>(fmaxf(acc1[2] + bB[2], 0.f), fmaxf(acc1[3] + bB[3], 0.f));
+    } else {
+        // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
+        o0[0] = pack2<T>(acc0[0], acc0[1]); o0[1] = pack2<T>(acc0[2], acc0[3]);
+        o1[0] = pack2<T>(acc1[0], acc1[1]); o1[1] = pack2<T>(acc1[2], acc1[3]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if constexpr (EPI == 0) {
-            stile[(4 * q + r) * UBD_C + co] = to_bits<T>(fmaxf(acc0[r] + b0, 0.f));
-            if (co < 8) stile[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(fmaxf(acc1[r] + b1, 0.f));
-        } else {
-            stile[(4 * q + r) * UBD_C + co] = to_bits<T>(acc0[r]);
-            if (co < 8) stile[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(acc1[r]);
+        for (int e = 0; e < 2; ++e) {
+            o0[e] &= (((short)(m0[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)m0[e] >> 16) > 0) ? 0xFFFF0000u : 0u);
+            o1[e] &= (((short)(m1[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)m1[e] >> 16) > 0) ? 0xFFFF0000u : 0u);
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    u32x4 v = *(const u32x4 *)((const char *)stile + (lane < 48 ? lane : 0) * 16);
-    if constexpr (EPI == 1) {                        // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned lo = ((short)(m[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u;
-            const unsigned hi = ((int)m[e] >> 16) > 0 ? 0xFFFF0000u : 0u;
-            v[e] &= (lo | hi);
-        }
-    }
-    // ONE unconditional buffer store per tile (callers count them for s_waitcnt vmcnt): the record count clips the
-    // lanes beyond the valid pixels; the descriptor is made provably wave-uniform (no waterfall loop)
     const unsigned long long rp = (unsigned long long)(y + first_pixel * UBD_C);
     const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
     const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
     npx = npx < 0 ? 0 : npx;
     const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 2);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)rhi << 32) | rlo), 0, (int)bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 0);
-    __builtin_amdgcn_wave_barrier();
-}
-
-// NR row tiles of one wave at once: one LDS round trip (and one pair of waits) for all of them.  `stile` holds NR tiles.
-template <typename T, int NR>
-__device__ __forceinline__ void store_tiles16(unsigned short *__restrict__ y, const size_t (&first_pixel)[NR], const int (&npx)[NR],
-                                              int lane, unsigned short *__restrict__ stile, const f32x4 (&acc0)[NR],
-                                              const f32x4 (&acc1)[NR], float b0, float b1)
-{
-    const int co = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        unsigned short *t = stile + k * 16 * UBD_C;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            t[(4 * q + r) * UBD_C + co] = to_bits<T>(fmaxf(acc0[k][r] + b0, 0.f));
-            if (co < 8) t[(4 * q + r) * UBD_C + 16 + co] = to_bits<T>(fmaxf(acc1[k][r] + b1, 0.f));
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    u32x4 v[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) v[k] = *(const u32x4 *)((const char *)stile + k * 16 * UBD_C * 2 + (lane < 48 ? lane : 0) * 16);
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const unsigned long long rp = (unsigned long long)(y + first_pixel[k] * UBD_C);
-        const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
-        const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
-        const int np = npx[k] < 0 ? 0 : npx[k];
-        const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(np * UBD_C * 2);
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)rhi << 32) | rlo), 0, (int)bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, lane * 16, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
+    const unsigned base = (unsigned)i * (UBD_C * 2u) + 8u * (unsigned)q;       // beyond `bytes` for pixels >= npx
+    __builtin_amdgcn_raw_buffer_store_b64(o0, rs, (int)base, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(o1, rs, (int)(q < 2 ? base + 32u : 0x40000000u), 0, 0);
 }
 
 // ------------------------------------------------------------------------------------ separable layers
@@ -179,7 +142,7 @@ template <int CIN, int STRIDE> struct sep16_cfg {
     static constexpr int ELEMS = PH * PW * CIN;
     static constexpr int BUF_BYTES = (CIN == UBD_C) ? ROUNDS * 256 * 16 : (ELEMS + 3) / 4 * 16;
     static constexpr int STAGE_REGS = (CIN == UBD_C) ? 1 : (ELEMS + 255) / 256;
-    static constexpr int NSTORE = TH / 4;                                     // buffer stores per wave per tile
+    static constexpr int NSTORE = TH / 2;                                     // buffer stores per wave per tile (2 per row tile)
 };
 
 template <int CIN, int STRIDE, int IN_MODE, typename T>
@@ -192,10 +155,7 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
     constexpr int NBUF = (CIN == UBD_C) ? 2 : 1;
     constexpr int NR = C::TH / 4;                                           // row tiles per wave per block tile
     // ONE LDS object: with a second __shared__ array hipcc orders every LDS read behind the LDS-DMA in flight (s_waitcnt vmcnt(0))
-    constexpr int TILE_HALVES = NR * 16 * UBD_C;
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * C::BUF_BYTES + 4 * TILE_HALVES * 2];
-    char *patch_mem = smem;
-    unsigned short *s_tile_base = (unsigned short *)(smem + NBUF * C::BUF_BYTES);
+    __shared__ __attribute__((aligned(16))) char patch_mem[NBUF * C::BUF_BYTES];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *pwfrag = frag, *dwlane = frag + UBD_SEP_FRAG_FLOATS;
@@ -231,7 +191,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
         pwf[0][0] = round16<T>(pwfrag[0 * 64 + lane]);
         pwf[0][1] = round16<T>(pwfrag[1 * 64 + lane]);
     }
-    const float b0 = bias[i], b1 = (i < 8) ? bias[16 + i] : 0.f;
+    const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
+    const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int cb = (q < CIN) ? q : 0;                                       // CIN < 24: this lane's channel (weights are 0 beyond)
 
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
@@ -341,8 +302,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
         if constexpr (CIN == UBD_C) {
             // counted wait as in forward.hip: exactly NSTORE buffer stores per wave follow each tile's DMA
             if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (C::NSTORE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (C::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_BYTES);
             const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
@@ -375,9 +336,6 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             if (has_next) load_regs(nxt, stage);
         }
 
-        f32x4 acc0[NR], acc1[NR];
-        size_t fpx[NR];
-        int npxs[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int r = wid + 4 * k;
@@ -403,28 +361,28 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
                     }
                 }
             }
-            acc0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (CIN == UBD_C) {
                 const u32x4 av = {pack2<T>(dwv[0], dwv[1]), pack2<T>(dwv[2], dwv[3]), pack2<T>(dwv[4], dwv[5]), 0u};
-                acc0[k] = h16<T>::mfma(av, pwb[0], acc0[k]);
-                acc1[k] = h16<T>::mfma(av, pwb[1], acc1[k]);
+                acc0 = h16<T>::mfma(pwb[0], av, acc0);               // weights as the A operand: D = [channel][pixel]
+                acc1 = h16<T>::mfma(pwb[1], av, acc1);
             } else {
                 const float dr = round16<T>(dwv[0]);
-                acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, pwf[0][0], acc0[k], 0, 0, 0);
-                acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr, pwf[0][1], acc1[k], 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][0], dr, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][1], dr, acc1, 0, 0, 0);
             }
-            const int npx = OW - ox0 < 16 ? OW - ox0 : 16;
-            npxs[k] = (oy < OH) ? npx : 0;
-            fpx[k] = ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0;
+            int npx = OW - ox0 < 16 ? OW - ox0 : 16;
+            npx = (oy < OH) ? npx : 0;
+            const u32x2 nomask = {0u, 0u};
+            store_tile16_t<T, 0>(y, ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
         }
-        store_tiles16<T, NR>(y, fpx, npxs, lane, s_tile_base + wid * TILE_HALVES, acc0, acc1, b0, b1);
         if (!has_next) break;
         tile = nxt;
     }
 }
 
 // ------------------------------------------------------------------------------------ dilated layers
-struct a16_frags { u32x4 v[7]; u32x4 m; };
+struct a16_frags { u32x4 v[7]; u32x2 m0, m1; };
 
 // EPI 0: y = relu(conv + bias).  EPI 1 (data gradient of the 16-bit train step): y = conv * (mask > 0), no bias; `wfrag`
 // then holds the flipped / transposed kernel and `mask` the saved output of the layer below (same shape as y).
@@ -434,13 +392,16 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
                                                         const unsigned short *__restrict__ mask, int n, int h,
                                                         int w, int d, unsigned in_bytes)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short s_tile[4][16 * UBD_C];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     u32x4 wr[7][2];
 #pragma unroll
     for (int c = 0; c < 7; ++c) { wr[c][0] = wfrag[(c * 2 + 0) * 64 + lane]; wr[c][1] = wfrag[(c * 2 + 1) * 64 + lane]; }
-    const float b0 = EPI == 0 ? bias[i] : 0.f, b1 = (EPI == 0 && i < 8) ? bias[16 + i] : 0.f;
+    f32x4 bA = {0.f, 0.f, 0.f, 0.f}, bB = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == 0) {
+        bA = *(const f32x4 *)(bias + 4 * q);
+        if (q < 2) bB = *(const f32x4 *)(bias + 16 + 4 * q);
+    }
     // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c+q)/3, channel group ((4c+q)%3)*8
     int dyc[7], dxc[7], cic[7];
 #pragma unroll
@@ -476,24 +437,27 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
             const unsigned off = ((unsigned)(rowid + dyc[c]) * (unsigned)w + (unsigned)ix) * (unsigned)(UBD_C * 2) + (unsigned)cic[c];
             a.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : oob), 0, 0);
         }
-        if constexpr (EPI == 1) {                    // the 16 bytes of the mask this lane will need in the store phase
-            const unsigned moff = ((unsigned)rowid * (unsigned)w + (unsigned)(xt * 16)) * (unsigned)(UBD_C * 2) + (unsigned)lane * 16u;
+        if constexpr (EPI == 1) {                    // the mask words of the bytes this lane will store
             const int npx = w - xt * 16 < 16 ? w - xt * 16 : 16;
-            a.m = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (int)(lane * 16 < npx * UBD_C * 2 ? moff : oob), 0, 0);
+            const unsigned moff = ((unsigned)rowid * (unsigned)w + (unsigned)px) * (unsigned)(UBD_C * 2) + 8u * (unsigned)q;
+            a.m0 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (int)(i < npx ? moff : oob), 0, 0);
+            a.m1 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (int)((i < npx && q < 2) ? moff + 32u : oob), 0, 0);
         }
     };
     auto compute_store = [&](const a16_frags &a, int tl) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-            acc0 = h16<T>::mfma(a.v[c], wr[c][0], acc0);
-            acc1 = h16<T>::mfma(a.v[c], wr[c][1], acc1);
+            acc0 = h16<T>::mfma(wr[c][0], a.v[c], acc0);          // weights as the A operand: D = [channel][pixel]
+            acc1 = h16<T>::mfma(wr[c][1], a.v[c], acc1);
         }
         const int xt = (int)((unsigned)tl % (unsigned)tiles_x);
         const int rowid = (int)((unsigned)tl / (unsigned)tiles_x);
         const int x0 = xt * 16;
         const int npx = w - x0 < 16 ? w - x0 : 16;
-        store_tile16<T, EPI>(y, (size_t)rowid * w + x0, npx, lane, s_tile[wid], acc0, acc1, b0, b1, a.m);
+        u32x2 m0 = {0u, 0u}, m1 = {0u, 0u};
+        if constexpr (EPI == 1) { m0 = a.m0; m1 = a.m1; }
+        store_tile16_t<T, EPI>(y, (size_t)rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
     };
     a16_frags A0, A1;
     const int t_last = t_end - 1;
