@@ -54,7 +54,10 @@ template <> __device__ __forceinline__ float dot2_16<_Float16>(unsigned a, unsig
 }
 template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi)
 {
-    return (unsigned)to_bits<T>(lo) | ((unsigned)to_bits<T>(hi) << 16);
+    // one v_cvt_pk_bf16_f32 (bf16) / two v_cvt_f16_f32 + pack (fp16); round to nearest even like the scalar casts
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
 }
 template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
 
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
 {
     using C = sep16_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
-    constexpr int NBUF = (CIN == UBD_C) ? 2 : 1;
+    // 24 channels: ring of LDS patch buffers.  Stride 1 (16 KiB patches) prefetches TWO tiles ahead: one tile's compute
+    // phase (~1 us) is shorter than the DMA latency under load; stride 2 (28 KiB patches) keeps the double buffer.
+    constexpr int NBUF = (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 1;
     constexpr int NR = C::TH / 4;                                           // row tiles per wave per block tile
     // ONE LDS object: with a second __shared__ array hipcc orders every LDS read behind the LDS-DMA in flight (s_waitcnt vmcnt(0))
     __shared__ __attribute__((aligned(16))) char patch_mem[NBUF * C::BUF_BYTES];
@@ -290,22 +295,40 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
     int tile = blockIdx.x;
     if (tile >= total) return;
     unsigned stage[C::STAGE_REGS];      // raw loaded bits (fp32 pattern or zero-extended byte): nothing consumes them before the LDS write
-    if constexpr (CIN == UBD_C) dma_tile(tile, patch_mem);
-    else load_regs(tile, stage);
+    constexpr int AHEAD = NBUF - 1;                                   // tiles in flight ahead of the one being computed
+    if constexpr (CIN == UBD_C) {
+        dma_tile(tile, patch_mem);
+        if (AHEAD == 2 && tile + (int)gridDim.x < total) dma_tile(tile + gridDim.x, patch_mem + C::BUF_BYTES);
+    } else {
+        load_regs(tile, stage);
+    }
 
     for (int it = 0;; ++it) {
-        char *patch = patch_mem + ((CIN == UBD_C) ? (it & 1) * C::BUF_BYTES : 0);
+        char *patch = patch_mem + ((CIN == UBD_C) ? (it % NBUF) * C::BUF_BYTES : 0);
         int img, oy0, ox0;
         tile_coords(tile, img, oy0, ox0);
         const int nxt = tile + gridDim.x;
         const bool has_next = (CIN == UBD_C) && nxt < total;         // block-uniform; 1/3-channel tiles: one per block (see launch)
         if constexpr (CIN == UBD_C) {
-            // counted wait as in forward.hip: exactly NSTORE buffer stores per wave follow each tile's DMA
-            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (C::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // Counted wait (vmcnt counts stores too and retires in order): this tile's DMA must have landed, everything
+            // issued after it may stay in flight.  After DMA(it) each wave issued: [AHEAD == 2: the stores of tile it-2,]
+            // the DMA of tile it+AHEAD-1... i.e. per later tile C::ROUNDS DMA instructions (if that tile exists) and per
+            // computed tile C::NSTORE buffer stores.
+            if constexpr (AHEAD == 1) {
+                if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (C::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                static_assert(AHEAD == 1 || (C::NSTORE == 8 && C::ROUNDS == 4), "vmcnt immediates below assume 8 stores / 4 DMA instructions per tile");
+                if (it == 0) { if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                else if (it == 1) { if (has_next) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                else { if (has_next) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            }
             __builtin_amdgcn_s_barrier();
-            if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_BYTES);
+            {
+                const int ahead_tile = tile + AHEAD * (int)gridDim.x;
+                if (ahead_tile < total) dma_tile(ahead_tile, patch_mem + ((it + AHEAD) % NBUF) * C::BUF_BYTES);
+            }
             const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
             const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
             if (border) {                                            // block-uniform
@@ -548,7 +571,7 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
 {
     using C = sep16_cfg<CIN, STRIDE>;
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
-    const int per_cu = (CIN == UBD_C) ? (STRIDE == 2 ? 2 : 4) : 5;                 // LDS-limited residency
+    const int per_cu = (CIN == UBD_C) ? (STRIDE == 2 ? 2 : 3) : 5;                 // LDS-limited residency
     long grid = (long)h->num_cus * per_cu;
     if (grid > tiles || CIN != UBD_C) grid = tiles;      // 1/3 channels: one tile per block
     hipLaunchKernelGGL((sepconv16_kernel<CIN, STRIDE, IN_MODE, T>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sub, div);
