@@ -5,6 +5,7 @@ The reference runs ``model.predict`` on the device, then thresholds with numpy a
 threshold, the component labelling and the box fitting all run on the MI355X; only the final
 (count, quads, classes) lists cross PCIe.
 """
+import os
 import numpy as np
 import torch
 
@@ -51,7 +52,9 @@ class ModelRunner:
         self._step += 1
         main = torch.cuda.current_stream(model.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=model.device)
+            # high priority: the short, latency-bound postprocess kernels take their few CUs at once instead of queueing
+            # behind the next forward pass (+2 % end to end)
+            self._side = torch.cuda.Stream(device=model.device, priority=-1)
         slot = self._slots.get(key)
         if slot is None:
             slot = {"logits": torch.empty((n, hh // 4, ww // 4, model.k_out), dtype=torch.float32, device=model.device),
