@@ -60,8 +60,9 @@ def test_bf16_full_batch_property_and_postprocess():
 
 
 @pytest.mark.parametrize("dtype,tol64", [("bfloat16", 4e-2), ("float16", 3e-2)])
-@pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 2, 64, 64), (1, 2, 2, 64, 96)])
-def test_train_step_16bit(dtype, tol64, cin, ncls, n, hh, ww):
+@pytest.mark.parametrize("cin,ncls,fml,n,hh,ww", [(3, 0, True, 2, 64, 64), (1, 2, True, 2, 64, 96), (3, 2, False, 1, 128, 64),
+                                                   (3, 0, True, 3, 72, 104)])
+def test_train_step_16bit(dtype, tol64, cin, ncls, fml, n, hh, ww):
     """configs[2] (bf16 train step) on small shapes: 16-bit activations, kernels and depthwise intermediates, 16-bit
     MFMA forward, fp32 accumulation / weight gradients / master weights; bf16 mode also keeps the gradient tensors
     between L3..L9 and the depthwise-output gradients of L2/L3 in bf16 (fp16 mode keeps them fp32).
@@ -72,7 +73,7 @@ def test_train_step_16bit(dtype, tol64, cin, ncls, n, hh, ww):
       * against the oracle evaluated in fp64: within `tol64` (the fp32-vs-fp64 oracle spread itself reaches 2e-2)."""
     from oracle import net_torch as otorch
     from ubdvss_amd import Trainer, Adam
-    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml)
     model = Model(cfg, dtype=dtype, seed=0)
     w = onet.init_weights(90 + cin, cin, ncls, bias_scale=0.2)
     w[-2] = (w[-2] * 4).astype(np.float32)
@@ -85,7 +86,7 @@ def test_train_step_16bit(dtype, tol64, cin, ncls, n, hh, ww):
     g = tr.grads.cpu().numpy().astype(np.float64)
     gdt = "bfloat16" if dtype == "bfloat16" else None
     for odt, tol in ((torch.float32, 5e-3), (torch.float64, tol64)):
-        loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, True, dtype=odt, act_dtype=dtype,
+        loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, fml, dtype=odt, act_dtype=dtype,
                                                           grad_dtype=gdt)
         assert abs(l[0] - loss_ref) <= tol * abs(loss_ref), (l[0], loss_ref)
         off = 0
@@ -97,3 +98,26 @@ def test_train_step_16bit(dtype, tol64, cin, ncls, n, hh, ww):
     # and the optimiser step runs on the fp32 master weights
     tr.apply_gradients()
     assert torch.isfinite(model.params).all()
+
+
+def test_bf16_train_uint8_input_and_loss_goes_down():
+    """bf16 train step on a larger batch (several tiles per block in every backward kernel), fed with uint8 images
+    (mobilenet preprocessing fused into L1 forward and backward): gradients equal those of the same step fed with the
+    preprocessed fp32 images, and Adam steps on the fixed batch reduce the objective."""
+    from ubdvss_amd import Trainer, Adam
+    from ubdvss_amd.net import PreprocessingType
+    cfg = NetConfig(grey=False, preprocessing=PreprocessingType.MOBILENET_LIKE)
+    n, side = 6, 256
+    labels = synthetic.rectangle_maps(7, n, side // 4, side // 4)
+    img8 = synthetic.textured_images(8, labels, 4, 3).astype(np.uint8)
+    y = torch.from_numpy(labels).cuda()
+    ma, mb = Model(cfg, dtype="bfloat16", seed=2), Model(cfg, dtype="bfloat16", seed=2)
+    ta, tb = Trainer(ma, Adam(lr=2e-3)), Trainer(mb, Adam(lr=2e-3))
+    ta.backward_on_device(torch.from_numpy(img8).cuda(), y)
+    tb.backward_on_device(torch.from_numpy((img8.astype(np.float32) - 127.5) / 127.5).cuda(), y)
+    ga, gb = ta.grads.cpu().numpy(), tb.grads.cpu().numpy()
+    assert np.linalg.norm(ga - gb) <= 1e-5 * np.linalg.norm(gb)
+    first = float(ta.loss[0])
+    for _ in range(25):
+        ta.train_step_on_device(torch.from_numpy(img8).cuda(), y)
+    assert np.isfinite(float(ta.loss[0])) and float(ta.loss[0]) < first
