@@ -138,3 +138,17 @@ def test_packed_fragments_follow_the_parameters():
     tr.train_step_on_device(x, y)                            # parameters move through the C-ABI
     ref2 = Model(cfg, seed=3); ref2.params.copy_(m.params)
     assert torch.equal(m.predict_on_device(x), ref2.predict_on_device(x))
+
+
+def test_load_keras_weights_export(tmp_path):
+    """The migration path for trained reference models: np.savez(path, *keras_model.get_weights())."""
+    cfg = NetConfig(class_names=["a", "b"], grey=True)
+    w = onet.init_weights(11, 1, 2, bias_scale=0.1)
+    path = str(tmp_path / "keras_weights.npz")
+    np.savez(path, *w)
+    m = Model(cfg, seed=0)
+    m.load_keras_weights(path)
+    for a, b in zip(m.get_weights(), w):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        Model(NetConfig(grey=False), seed=0).load_keras_weights(path)      # wrong architecture

@@ -219,6 +219,16 @@ class Model:
             raise ValueError("weight file was saved for a different architecture")
         self.params.copy_(torch.from_numpy(d["params"]))
 
+    def load_keras_weights(self, path):
+        """Weights exported from the reference's Keras model (net.py:418-494 keeps them in HDF5, which needs h5py):
+        run ``np.savez(path, *model.get_weights())`` once in the Keras environment; the arrays arrive as arr_0, arr_1,
+        ... in ``get_weights()`` order, which is this model's flat parameter order."""
+        d = np.load(path)
+        names = sorted((k for k in d.files if k.startswith("arr_")), key=lambda k: int(k[4:]))
+        if not names:
+            raise ValueError("no arr_<i> entries: export with np.savez(path, *model.get_weights())")
+        self.set_weights([d[k] for k in names])
+
     # ---------------------------------------------------------------- forward
     def _workspace(self, attr, nbytes):
         ws = getattr(self, attr)
