@@ -409,11 +409,17 @@ struct a16_frags { u32x4 v[7]; u32x2 m0, m1; };
 
 // EPI 0: y = relu(conv + bias).  EPI 1 (data gradient of the 16-bit train step): y = conv * (mask > 0), no bias; `wfrag`
 // then holds the flipped / transposed kernel and `mask` the saved output of the layer below (same shape as y).
+// n / d for the (wave-uniform) tile bookkeeping: m = ceil(2^32 / d) computed on the host, exact while n * d < 2^32
+// (checked by the launcher); d == 1 has no 32-bit magic number.
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned d, unsigned m) { return d == 1u ? n : __umulhi(n, m); }
+
+struct dil16_tile { int xt, rowid, yy, img; };
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                         const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                                                         const unsigned short *__restrict__ mask, int n, int h,
-                                                        int w, int d, unsigned in_bytes)
+                                                        int w, int d, unsigned mg_tx, unsigned mg_h)
 {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
@@ -425,17 +431,20 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         bA = *(const f32x4 *)(bias + 4 * q);
         if (q < 2) bB = *(const f32x4 *)(bias + 16 + 4 * q);
     }
-    // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c+q)/3, channel group ((4c+q)%3)*8
-    int dyc[7], dxc[7], cic[7];
+    // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c+q)/3, channel group ((4c+q)%3)*8.
+    // delta[c]: byte offset of that tap / channel group relative to the centre pixel inside ONE image (the loads go through
+    // a per-image buffer descriptor, so rows above / below the image fall out of range by themselves and read zeros =
+    // the 'same' padding); dxc[c]: column shift, checked per lane.  Chunk 6, q = 3 lies beyond K: always out of range.
+    int delta[7], dxc[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
         const int g = 4 * c + q, t = g / 3;
-        cic[c] = (g - 3 * t) * 16;                   // byte offset of the 8-channel group inside the 48-byte pixel
-        dyc[c] = t < 9 ? (t / 3 - 1) * d : (1 << 28);  // chunk 6, q = 3: beyond K -> always out of range
-        dxc[c] = (t % 3 - 1) * d;
+        const int dy = (t / 3 - 1) * d, dx = (t % 3 - 1) * d;
+        delta[c] = t < 9 ? (dy * w + dx) * (UBD_C * 2) + (g - 3 * t) * 16 : (1 << 30);
+        dxc[c] = t < 9 ? dx : 0;
     }
-    const int tiles_x = (w + 15) >> 4;
-    const int total = n * h * tiles_x;
+    const unsigned tiles_x = (unsigned)(w + 15) >> 4;
+    const int total = n * h * (int)tiles_x;
     const int xcd = blockIdx.x & 7;
     const int nblk_x = (gridDim.x + 7 - xcd) >> 3;
     const int chunk = (total + 7) >> 3;
@@ -444,56 +453,54 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
     const int stride = nblk_x * 4;
     int tile = t_begin + (int)(blockIdx.x >> 3) * 4 + wid;
     if (tile >= t_end) return;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(EPI == 1 ? mask : x), 0, (int)in_bytes, 0x00020000);
-    const unsigned oob = in_bytes;
+    const unsigned img_bytes = (unsigned)h * (unsigned)w * (unsigned)(UBD_C * 2);
 
-    auto load = [&](a16_frags &a, int tl) {
-        const int xt = (int)((unsigned)tl % (unsigned)tiles_x);
-        const int rowid = (int)((unsigned)tl / (unsigned)tiles_x);
-        const int yy = (int)((unsigned)rowid % (unsigned)h);
-        const int px = xt * 16 + i;
+    auto load = [&](a16_frags &a, dil16_tile &tc, int tl) {
+        tc.rowid = (int)udiv_magic((unsigned)tl, tiles_x, mg_tx);
+        tc.xt = tl - tc.rowid * (int)tiles_x;
+        tc.img = (int)udiv_magic((unsigned)tc.rowid, (unsigned)h, mg_h);
+        tc.yy = tc.rowid - tc.img * h;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)tc.img * h * w * UBD_C), 0, (int)img_bytes, 0x00020000);
+        const int px = tc.xt * 16 + i;
+        const int base = (tc.yy * w + px) * (UBD_C * 2);
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
-            const int iy = yy + dyc[c], ix = px + dxc[c];
-            const bool ok = (iy >= 0) && (iy < h) && (ix >= 0) && (ix < w);
-            const unsigned off = ((unsigned)(rowid + dyc[c]) * (unsigned)w + (unsigned)ix) * (unsigned)(UBD_C * 2) + (unsigned)cic[c];
-            a.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? off : oob), 0, 0);
+            const bool xok = (unsigned)(px + dxc[c]) < (unsigned)w;
+            a.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xok ? base + delta[c] : (1 << 30), 0, 0);
         }
         if constexpr (EPI == 1) {                    // the mask words of the bytes this lane will store
-            const int npx = w - xt * 16 < 16 ? w - xt * 16 : 16;
-            const unsigned moff = ((unsigned)rowid * (unsigned)w + (unsigned)px) * (unsigned)(UBD_C * 2) + 8u * (unsigned)q;
-            a.m0 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (int)(i < npx ? moff : oob), 0, 0);
-            a.m1 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, (int)((i < npx && q < 2) ? moff + 32u : oob), 0, 0);
+            __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(mask + (size_t)tc.img * h * w * UBD_C), 0, (int)img_bytes, 0x00020000);
+            const int moff = px < w ? base + 8 * q : (1 << 30);
+            a.m0 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, moff, 0, 0);
+            a.m1 = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, q < 2 ? moff + 32 : (1 << 30), 0, 0);
         }
     };
-    auto compute_store = [&](const a16_frags &a, int tl) {
+    auto compute_store = [&](const a16_frags &a, const dil16_tile &tc) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
             acc0 = h16<T>::mfma(wr[c][0], a.v[c], acc0);          // weights as the A operand: D = [channel][pixel]
             acc1 = h16<T>::mfma(wr[c][1], a.v[c], acc1);
         }
-        const int xt = (int)((unsigned)tl % (unsigned)tiles_x);
-        const int rowid = (int)((unsigned)tl / (unsigned)tiles_x);
-        const int x0 = xt * 16;
+        const int x0 = tc.xt * 16;
         const int npx = w - x0 < 16 ? w - x0 : 16;
         u32x2 m0 = {0u, 0u}, m1 = {0u, 0u};
         if constexpr (EPI == 1) { m0 = a.m0; m1 = a.m1; }
-        store_tile16_t<T, EPI>(y, (size_t)rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
+        store_tile16_t<T, EPI>(y, (size_t)tc.rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
     };
     a16_frags A0, A1;
+    dil16_tile T0, T1;
     const int t_last = t_end - 1;
-    load(A0, tile);
+    load(A0, T0, tile);
     for (;;) {
         int nxt = tile + stride;
-        load(A1, nxt < t_last ? nxt : t_last);
-        compute_store(A0, tile);
+        load(A1, T1, nxt < t_last ? nxt : t_last);
+        compute_store(A0, T0);
         tile = nxt;
         if (tile >= t_end) break;
         nxt = tile + stride;
-        load(A0, nxt < t_last ? nxt : t_last);
-        compute_store(A1, tile);
+        load(A0, T0, nxt < t_last ? nxt : t_last);
+        compute_store(A1, T1);
         tile = nxt;
         if (tile >= t_end) break;
     }
@@ -577,20 +584,23 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
     hipLaunchKernelGGL((sepconv16_kernel<CIN, STRIDE, IN_MODE, T>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sub, div);
 }
 
+static unsigned magic_u32(unsigned d) { return d <= 1u ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+
 template <typename T>
 static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
                          const void *in, void *out, int n, int H4, int W4, hipStream_t st)
 {
-    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 2);
-    const long tiles = (long)n * H4 * ((W4 + 15) / 16);
+    const unsigned tiles_x = (unsigned)(W4 + 15) / 16;
+    const long tiles = (long)n * H4 * tiles_x;
     int grid = ubd_grid_for(tiles, h->num_cus, 4, 4);
     grid = (grid + 7) / 8 * 8;
+    const unsigned mg_tx = magic_u32(tiles_x), mg_h = magic_u32((unsigned)H4);
     if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, in_bytes);
+                           (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h);
     else
         hipLaunchKernelGGL((dilconv16_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, in_bytes);
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h);
 }
 
 // 16-bit dense dilated layer (epi 0: forward, epi 1: data gradient with ReLU mask); element type from the handle
@@ -657,6 +667,10 @@ int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images,
                          int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
 {
     UBD_REQUIRE((size_t)n * (H / 4) * (W / 4) * UBD_C * 2 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
+    // dilconv16_kernel: per-image 30-bit byte offsets and magic-number division of the tile index
+    UBD_REQUIRE((size_t)(H / 4) * (W / 4) * UBD_C * 2 < (1ull << 30), "ubd_forward: image too large for the 16-bit path (%d x %d)", H, W);
+    UBD_REQUIRE((unsigned long long)n * (H / 4) * ((W / 4 + 15) / 16) * ((W / 4 + 15) / 16) < (1ull << 32) &&
+                (unsigned long long)n * (H / 4) * (H / 4) < (1ull << 32), "ubd_forward: batch too large for the 16-bit path; split the batch");
     if (h->cfg.dtype == UBD_BF16) return forward16_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
     return forward16_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
 }
