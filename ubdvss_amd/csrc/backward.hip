@@ -113,6 +113,7 @@ __global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restr
     }
 }
 
+#define RP_COLS 16          // elements per block of reduce_partials_kernel
 // ------------------------------------------------------------------------------------ partial sums
 // Weight gradients are accumulated per block and written as one row of a [blocks][count] partial-sum matrix;
 // reduce_partials_kernel adds the rows in a fixed order (deterministic, and no same-address atomics: a few
@@ -121,23 +122,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
                                                               float *__restrict__ out0, int n0, float *__restrict__ out1, int n1,
                                                               float *__restrict__ out2)
 {
-    // block = 64 consecutive elements x 4 row groups; 8 independent loads in flight per thread
-    __shared__ float s[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + tx;
+    // block = RP_COLS consecutive elements x (256 / RP_COLS) row groups; 8 independent loads in flight per thread.
+    // 16 columns per block: 5208-element rows give 326 blocks (one per CU and more) instead of 82.
+    constexpr int G = 256 / RP_COLS;
+    __shared__ float s[G][RP_COLS];
+    const int tx = threadIdx.x % RP_COLS, ty = threadIdx.x / RP_COLS;
+    const int e = blockIdx.x * RP_COLS + tx;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < count) {
         int b = ty;
-        for (; b + 28 < nblocks; b += 32) {
+        for (; b + 7 * G < nblocks; b += 8 * G) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(b + 4 * u) * count + e];
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(b + G * u) * count + e];
         }
-        for (; b < nblocks; b += 4) acc[0] += part[(size_t)b * count + e];
+        for (; b < nblocks; b += G) acc[0] += part[(size_t)b * count + e];
     }
     s[ty][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (ty == 0 && e < count) {
-        const float v = (s[0][tx] + s[1][tx]) + (s[2][tx] + s[3][tx]);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) v += s[g][tx];           // fixed order: deterministic
         if (e < n0) out0[e] = v;
         else if (e < n0 + n1) out1[e - n0] = v;
         else out2[e - n0 - n1] = v;
@@ -804,7 +809,7 @@ static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const 
     else
         hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + 63) / 64), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
 template <int CIN, int STRIDE, int GSRC, typename T>
@@ -821,7 +826,7 @@ static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const u
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
     else
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + 63) / 64), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 
 template <typename TX>
@@ -832,7 +837,7 @@ static void launch_head_wgrad(const ubd_handle *h, const void *a9, const float *
         long g1 = (npix + 255) / 256;
         if (g1 > h->num_cus * 4) g1 = h->num_cus * 4;
         hipLaunchKernelGGL((head_wgrad1_kernel<TX>), dim3((int)g1), dim3(256), 0, st, a9, dlogits, partials, npix);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partials, (int)g1, UBD_C + 1, grads + h->off_head_k, UBD_C,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((UBD_C + 1 + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, (int)g1, UBD_C + 1, grads + h->off_head_k, UBD_C,
                            grads + h->off_head_b, 1, (float *)nullptr);
         return;
     }
@@ -884,7 +889,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             int gw = h->num_cus * 3;
             if (gw > items) gw = (int)items;
             hipLaunchKernelGGL((dil_wgrad16_kernel<TX>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + 63) / 64), dim3(256), 0, st, partials, gw, 217 * UBD_C,
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
                                grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
@@ -922,7 +927,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             int gw = h->num_cus * 2;
             if (gw > items) gw = (int)items;
             hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + 63) / 64), dim3(256), 0, st, partials, gw, 217 * UBD_C,
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
                                grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
         }
         if (h->use_wino)
