@@ -15,14 +15,14 @@
 #include "common.h"
 
 #define LOSS_BLOCK 256
-#define LOSS_MAX_BLOCKS 1024
+#define LOSS_MAX_BLOCKS 256      // one block per CU: every block ends with ~50 same-address global atomics (header sums, non-empty bins)
 
 struct loss_hdr {
     double sum_pos, sum_neg, sum_hard, sum_cls;   // 0..31
     int n_pos;                                    // 32
     unsigned k;                                   // top-k size
-    unsigned prefix;                              // radix-select prefix so far
-    unsigned k_rem;                               // rank still to resolve inside the prefix bin
+    unsigned prefix_l[2];                         // radix-select prefix after level 0 / level 1
+    unsigned k_rem_l[2];                          // rank still to resolve inside that prefix bin
     unsigned T;                                   // final threshold bits (k-th largest value)
     unsigned need_eq;                             // how many elements == T are selected
     // per-batch pixel metrics (keras_metrics.py:110-172): detection confusion matrix with pred = logit0 > 0,
@@ -120,58 +120,80 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stats_kernel(const float *__r
 }
 
 // ---- radix-select scan: pick the bin that holds the k_rem-th largest element -----------------
-// level 0: bins = bits >> 21 (2048), level 1: (bits >> 10) & 2047, level 2: bits & 1023
-__global__ __launch_bounds__(256) void loss_select_kernel(loss_hdr *hdr, const unsigned *__restrict__ hist, int level,
-                                                          long npix)
+// level 0: bins = bits >> 21 (2048), level 1: (bits >> 10) & 2047, level 2: bits & 1023.
+// Runs at the head of the kernel that consumes its result (three single-block launches of ~10 us each saved): every
+// block recomputes the same selection from the finished histogram of the previous kernel; block 0 records it in the
+// header for the later kernels (each level has its own header fields, so late blocks never read a value block 0 has
+// already replaced).
+struct loss_sel { unsigned prefix, k_rem, k; };
+
+__device__ __forceinline__ loss_sel loss_select_block(loss_hdr *hdr, const unsigned *__restrict__ hist, int level, long npix,
+                                                      unsigned *s_part /* 256 */, loss_sel *s_out)
 {
-    __shared__ unsigned s_part[256];
     const int nbins = level == 2 ? 1024 : 2048;
     const int per = nbins / 256;
-    // thread t sums bins [nbins - (t+1)*per, nbins - t*per)  (descending order)
-    unsigned s = 0;
-    for (int j = 0; j < per; ++j) s += hist[nbins - 1 - (threadIdx.x * per + j)];
-    s_part[threadIdx.x] = s;
+    // thread t sums bins [nbins - (t+1)*per, nbins - t*per)  (descending order); inclusive prefix over the 256 segment
+    // sums (Hillis-Steele in LDS); the one thread whose segment holds the k_rem-th largest element finishes the scan
+    unsigned mine = 0;
+    for (int j = 0; j < per; ++j) mine += hist[nbins - 1 - (threadIdx.x * per + j)];
+    s_part[threadIdx.x] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned k_rem;
-        if (level == 0) {
-            const long n_pos = hdr->n_pos;
-            const long n_neg = npix - n_pos;
-            const long a = n_pos > 1 ? n_pos : 1, b = n_neg > 1 ? n_neg : 1;
-            const unsigned k = (unsigned)(a < b ? a : b);       // losses.py:110
-            hdr->k = k;
-            k_rem = k;
-        } else {
-            k_rem = hdr->k_rem;
-        }
-        unsigned acc = 0;
-        int seg = 0;
-        for (; seg < 255; ++seg) {
-            if (acc + s_part[seg] >= k_rem) break;
-            acc += s_part[seg];
-        }
-        int bin = nbins - 1 - seg * per;
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned v = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned k_rem, k, prev_prefix = 0;
+    if (level == 0) {
+        const long n_pos = hdr->n_pos;
+        const long n_neg = npix - n_pos;
+        const long a = n_pos > 1 ? n_pos : 1, b = n_neg > 1 ? n_neg : 1;
+        k = (unsigned)(a < b ? a : b);       // losses.py:110
+        k_rem = k;
+    } else {
+        k = hdr->k;
+        k_rem = hdr->k_rem_l[level - 1];
+        prev_prefix = hdr->prefix_l[level - 1];
+    }
+    const unsigned incl = s_part[threadIdx.x], excl = incl - mine;
+    // k_rem <= total count holds by construction (k <= number of masked negatives incl. zeros); the last segment takes
+    // any remainder like the serial scan did
+    const bool winner = (excl < k_rem && k_rem <= incl) || (threadIdx.x == 255 && incl < k_rem);
+    if (winner) {
+        unsigned acc = excl;
+        int bin = nbins - 1 - (int)threadIdx.x * per;
         for (int j = 0; j < per - 1; ++j, --bin) {
             const unsigned c = hist[bin];
             if (acc + c >= k_rem) break;
             acc += c;
         }
         // `bin` holds the k_rem-th largest; `acc` elements are strictly above it
-        k_rem -= acc;
-        if (level == 0) hdr->prefix = (unsigned)bin;
-        else if (level == 1) hdr->prefix = (hdr->prefix << 11) | (unsigned)bin;
-        else { hdr->T = (hdr->prefix << 10) | (unsigned)bin; hdr->need_eq = k_rem; }
-        hdr->k_rem = k_rem;
+        const unsigned rem = k_rem - acc;
+        loss_sel r;
+        r.k = k; r.k_rem = rem;
+        r.prefix = level == 0 ? (unsigned)bin : (level == 1 ? ((prev_prefix << 11) | (unsigned)bin) : ((prev_prefix << 10) | (unsigned)bin));
+        *s_out = r;
+        if (blockIdx.x == 0) {
+            if (level == 0) hdr->k = k;
+            if (level < 2) { hdr->prefix_l[level] = r.prefix; hdr->k_rem_l[level] = rem; }
+            else { hdr->T = r.prefix; hdr->need_eq = rem; }
+        }
     }
+    __syncthreads();
+    return *s_out;
 }
 
+// histogram of level `level` (1 or 2) over the elements inside the bin selected at level - 1 (prev_hist)
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__restrict__ ce_buf, long npix,
-                                                               const loss_hdr *hdr, unsigned *__restrict__ hist, int level)
+                                                               loss_hdr *hdr, const unsigned *__restrict__ prev_hist,
+                                                               unsigned *__restrict__ hist, int level)
 {
     __shared__ unsigned s_hist[2048];
+    __shared__ unsigned s_part[256];
+    __shared__ loss_sel s_sel;
     for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
-    __syncthreads();
-    const unsigned prefix = hdr->prefix;
+    const unsigned prefix = loss_select_block(hdr, prev_hist, level - 1, npix, s_part, &s_sel).prefix;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         const unsigned b = __float_as_uint(ce_buf[p]);
         if (level == 1) {
@@ -187,10 +209,13 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__re
 
 // ---- ties: per-chunk count of elements == T (chunks are contiguous index ranges) --------------
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *__restrict__ ce_buf, long npix, long chunk,
-                                                                   const loss_hdr *hdr, unsigned *__restrict__ blockties)
+                                                                   loss_hdr *hdr, const unsigned *__restrict__ hist2,
+                                                                   unsigned *__restrict__ blockties)
 {
     __shared__ double s_red[LOSS_BLOCK / 64];
-    const unsigned T = hdr->T;
+    __shared__ unsigned s_part[256];
+    __shared__ loss_sel s_sel;
+    const unsigned T = loss_select_block(hdr, hist2, 2, npix, s_part, &s_sel).prefix;    // final threshold bits
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
     int c = 0;
     for (long p = lo + threadIdx.x; p < hi; p += blockDim.x) c += (__float_as_uint(ce_buf[p]) == T);
@@ -344,12 +369,9 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     chunk = (chunk + LOSS_BLOCK - 1) / LOSS_BLOCK * LOSS_BLOCK;
     const int cgrid = (int)((npix + chunk - 1) / chunk);
     hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce);
-    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist, 0, npix);
-    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, 1);
-    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist + 2048, 1, npix);
-    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 4096, 2);
-    hipLaunchKernelGGL(loss_select_kernel, dim3(1), dim3(256), 0, st, hdr, hist + 4096, 2, npix);
-    hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, blockties);
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist, hist + 2048, 1);
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, hist + 4096, 2);
+    hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, hist + 4096, blockties);
     hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix, k_out - 1, loss);
