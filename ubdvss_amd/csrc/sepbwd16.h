@@ -45,10 +45,23 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int OFF_SDW = OFF_G + GPIX * UBD_C * 4;           // per-wave transpose tiles
     static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // channels per pixel of the transpose tiles
     static constexpr int OFF_WT = OFF_SDW + NW * 16 * SDW_W * 4;        // own depthwise taps [9][24] fp32 (24-channel layers)
-    static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24] fp32 (kx = 3: zeros)
+    static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
     static constexpr int LDS_BYTES = OFF_UT + 12 * UBD_C * 4;
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
 };
+
+// acc + a.lo * b.lo + a.hi * b.hi, 16-bit inputs, fp32 accumulation (v_dot2c_f32_{bf16,f16})
+template <typename T> __device__ __forceinline__ float dot2b(unsigned a, unsigned b, float acc);
+template <> __device__ __forceinline__ float dot2b<__bf16>(unsigned a, unsigned b, float acc)
+{
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), acc, false);
+}
+template <> __device__ __forceinline__ float dot2b<_Float16>(unsigned a, unsigned b, float acc)
+{
+    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), acc, false);
+}
 
 template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float &lo, float &hi)
 {
@@ -106,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     const char *mraw = dma + C::OFF_M;
     float *gtile = (float *)(lds + C::OFF_G);
     float (*s_dw)[16][C::SDW_W] = (float (*)[16][C::SDW_W])(lds + C::OFF_SDW);
-    float *wt = (float *)(lds + C::OFF_WT), *ut = (float *)(lds + C::OFF_UT);
+    float *wt = (float *)(lds + C::OFF_WT);
+    unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
@@ -116,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     if constexpr (GSRC != 0)
         for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
-            ut[t] = kx < 3 ? (float)(T)dw_up[(ky * 3 + kx) * UBD_C + ch] : 0.f;
+            // 16-bit tap in the half of the dword that matches the channel's position in its pair: ONE v_dot2c then
+            // multiplies the raw activation pair from LDS (the other product is x * 0)
+            const unsigned wb = kx < 3 ? (unsigned)__builtin_bit_cast(unsigned short, (T)dw_up[(ky * 3 + kx) * UBD_C + ch]) : 0u;
+            utp[t] = (ch & 1) ? (wb << 16) : wb;
         }
     float dwk1[9];                                                               // 1/3-channel layers: this lane's taps
     if constexpr (CIN != UBD_C) {
@@ -315,14 +332,12 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                         const char *pd = draw + (dr * C::DCOLS + dc) * 48;
                         const u32x2 a = *(const u32x2 *)(pd + 8 * q);
                         const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
-                        const float *pu = ut + (ky * 4 + kx) * UBD_C;
-                        const f32x4 w4 = *(const f32x4 *)(pu + 4 * q);
-                        const f32x2 w2 = *(const f32x2 *)(pu + 16 + 2 * q);
-                        float v[6];
-                        widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
-                        acc[0] = fmaf(v[0], w4[0], acc[0]); acc[1] = fmaf(v[1], w4[1], acc[1]);
-                        acc[2] = fmaf(v[2], w4[2], acc[2]); acc[3] = fmaf(v[3], w4[3], acc[3]);
-                        acc[4] = fmaf(v[4], w2[0], acc[4]); acc[5] = fmaf(v[5], w2[1], acc[5]);
+                        const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
+                        const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
+                        const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
+                        acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
+                        acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
+                        acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
                     }
                 }
                 const char *pm = mraw + (r * 16 + i) * 48;
