@@ -885,10 +885,14 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];
-            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH - 1) / W16_TH) * (((W4 + dd - 1) / dd + W16_TW - 1) / W16_TW);
+            const int sw = (W4 + dd - 1) / dd, tw = sw <= 8 ? 8 : 16;              // narrow sub-grids: 8-wide tiles
+            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH - 1) / W16_TH) * ((sw + tw - 1) / tw);
             int gw = h->num_cus * 3;
             if (gw > items) gw = (int)items;
-            hipLaunchKernelGGL((dil_wgrad16_kernel<TX>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
+            if (tw == 8)
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
+            else
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
                                grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);

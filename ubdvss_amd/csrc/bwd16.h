@@ -63,21 +63,27 @@ __global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict_
 // pixel, ci = rho0 % 24 the channel (24 = 6 x 4: a segment never straddles a tap).  rho = 216 is the all-ones column
 // (bias gradient), 217.. are zero: those segments read 8-byte constants kept behind the tile buffers.
 #define W16_TH 8
-#define W16_TW 16
-#define W16_XW (W16_TW + 2)
-#define W16_XPIX ((W16_TH + 2) * W16_XW)              // 180
-#define W16_GPIX (W16_TH * W16_TW)                    // 128
-#define W16_XBYTES (W16_XPIX * UBD_C * 2)             // 8640
-#define W16_CHUNKS ((W16_XPIX + W16_GPIX) * 3)        // 924
-#define W16_ROUNDS ((W16_CHUNKS + 255) / 256)         // 4
-#define W16_BUF_BYTES (W16_ROUNDS * 256 * 16)         // 16 KiB
+// TW = 16 (default) or 8 (sub-grids at most 8 columns wide, i.e. dilation 16 on 128-wide maps: half of a 16-wide tile
+// would be padding).  k-block = 32 sub-pixels = 2 rows x 16 or 4 rows x 8.
+template <int TW> struct w16_cfg {
+    static constexpr int XW = TW + 2;
+    static constexpr int XPIX = (W16_TH + 2) * XW;           // 180 / 100
+    static constexpr int GPIX = W16_TH * TW;                 // 128 / 64
+    static constexpr int XBYTES = XPIX * UBD_C * 2;
+    static constexpr int CHUNKS = (XPIX + GPIX) * 3;
+    static constexpr int ROUNDS = (CHUNKS + 255) / 256;
+    static constexpr int BUF_BYTES = ROUNDS * 256 * 16;      // 16 KiB / 8 KiB
+    static constexpr int KROWS = 32 / TW;                    // tile rows per k-block
+};
+#define W16_BUF_BYTES_MAX (w16_cfg<16>::BUF_BYTES)
 
-template <typename T>
+template <typename T, int TW>
 __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d)
 {
-    constexpr int CONST_OFF = 2 * W16_BUF_BYTES;                          // [0,8): {1,0,0,0}   [8,16): zeros
-    __shared__ __attribute__((aligned(16))) char smem[2 * W16_BUF_BYTES + 64];   // ONE LDS object (see fwd16.hip)
+    using C = w16_cfg<TW>;
+    constexpr int CONST_OFF = 2 * W16_BUF_BYTES_MAX;                          // [0,8): {1,0,0,0}   [8,16): zeros
+    __shared__ __attribute__((aligned(16))) char smem[2 * W16_BUF_BYTES_MAX + 64];   // ONE LDS object (see fwd16.hip)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
@@ -90,25 +96,25 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
     for (int mt = 0; mt < 14; ++mt) {
         const int rho0 = 16 * mt + 4 * p;
         const int t = rho0 / UBD_C, ci = rho0 - t * UBD_C;
-        aoff[mt] = ((t / 3) * W16_XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below)
+        aoff[mt] = ((t / 3) * C::XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below)
     }
-    // pixel of this lane inside a k-block (2 tile rows x 16 columns): k = 8 grp + 4 j + qq, j = 0, 1
-    const int krow = grp >> 1, kcol = 8 * (grp & 1) + qq;
+    // pixel of this lane inside a k-block (2 tile rows x 16 columns or 4 x 8): k = 8 grp + 4 j + qq, j = 0, 1
+    const int krow = TW == 16 ? grp >> 1 : grp, kcol = TW == 16 ? 8 * (grp & 1) + qq : qq;
 
     // DMA chunk -> (tile row, tile column, 16-byte part, X or G) of this lane, per round
-    int cinfo[W16_ROUNDS];
+    int cinfo[C::ROUNDS];
 #pragma unroll
-    for (int rd = 0; rd < W16_ROUNDS; ++rd) {
+    for (int rd = 0; rd < C::ROUNDS; ++rd) {
         int c = rd * 256 + wid * 64 + lane;
-        c = c < W16_CHUNKS ? c : W16_CHUNKS - 1;
+        c = c < C::CHUNKS ? c : C::CHUNKS - 1;
         int sy, sx, part, isx;
-        if (c < W16_XPIX * 3) { const int pix = c / 3; part = c - pix * 3; sy = pix / W16_XW; sx = pix - sy * W16_XW; isx = 1; }   // sy, sx include the +1 halo shift
-        else { const int cg = c - W16_XPIX * 3; const int gp = cg / 3; part = cg - gp * 3; sy = gp / W16_TW + 1; sx = gp % W16_TW + 1; isx = 0; }
+        if (c < C::XPIX * 3) { const int pix = c / 3; part = c - pix * 3; sy = pix / C::XW; sx = pix - sy * C::XW; isx = 1; }   // sy, sx include the +1 halo shift
+        else { const int cg = c - C::XPIX * 3; const int gp = cg / 3; part = cg - gp * 3; sy = gp / TW + 1; sx = gp % TW + 1; isx = 0; }
         cinfo[rd] = sy | (sx << 8) | (part << 16) | (isx << 24);
     }
 
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
-    const int tiles_y = (sh + W16_TH - 1) / W16_TH, tiles_x = (sw + W16_TW - 1) / W16_TW;
+    const int tiles_y = (sh + W16_TH - 1) / W16_TH, tiles_x = (sw + TW - 1) / TW;
     const int items = n * d * d * tiles_y * tiles_x;
     struct item_t { int img, ry, rx, sy0, sx0; };
     auto decode = [&](int it) {
@@ -118,13 +124,13 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
         r.rx = (int)((unsigned)it % (unsigned)d); it = (int)((unsigned)it / (unsigned)d);
         r.ry = (int)((unsigned)it % (unsigned)d);
         r.img = (int)((unsigned)it / (unsigned)d);
-        r.sy0 = ty * W16_TH; r.sx0 = tx * W16_TW;
+        r.sy0 = ty * W16_TH; r.sx0 = tx * TW;
         return r;
     };
     auto dma_item = [&](int it, char *buf) {
         const item_t I = decode(it);
 #pragma unroll
-        for (int rd = 0; rd < W16_ROUNDS; ++rd) {
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int ci = cinfo[rd];
             int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;
             int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
@@ -137,21 +143,29 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
         }
     };
 
+    // XCD-aware item ranges: blocks b, b + 8, ... share an XCD (and its L2) and walk one contiguous eighth of the item
+    // list (image-major), so the d x d phases of an image -- which interleave inside the same cache lines -- are fetched
+    // through ONE L2 instead of up to eight (d = 8: 65 -> 37 us)
+    const int xcd = blockIdx.x & 7;
+    const int nblk_x = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int chunk = (items + 7) >> 3;
+    const int it_begin = xcd * chunk;
+    const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
     f32x4 acc[14][2] = {};
-    int it = blockIdx.x;
-    if (it < items) dma_item(it, smem);
-    for (int iter = 0; it < items; ++iter, it += gridDim.x) {
-        char *buf = smem + (iter & 1) * W16_BUF_BYTES;
+    int it = it_begin + (int)(blockIdx.x >> 3);
+    if (it < it_end) dma_item(it, smem);
+    for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
+        char *buf = smem + (iter & 1) * C::BUF_BYTES;
         const item_t I = decode(it);
         __syncthreads();                              // this item's DMA landed; everyone left the other buffer
-        if (it + (int)gridDim.x < items) dma_item(it + gridDim.x, smem + ((iter + 1) & 1) * W16_BUF_BYTES);
+        if (it + nblk_x < it_end) dma_item(it + nblk_x, smem + ((iter + 1) & 1) * C::BUF_BYTES);
         const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
-                            (I.ry + (I.sy0 + W16_TH) * d >= h) || (I.rx + (I.sx0 + W16_TW) * d >= w);   // block-uniform
+                            (I.ry + (I.sy0 + W16_TH) * d >= h) || (I.rx + (I.sx0 + TW) * d >= w);   // block-uniform
         if (ragged) {
-            for (int pix = threadIdx.x; pix < W16_XPIX + W16_GPIX; pix += 256) {
+            for (int pix = threadIdx.x; pix < C::XPIX + C::GPIX; pix += 256) {
                 int sy, sx;
-                if (pix < W16_XPIX) { sy = pix / W16_XW - 1; sx = pix % W16_XW - 1; }
-                else { sy = (pix - W16_XPIX) / W16_TW; sx = (pix - W16_XPIX) % W16_TW; }
+                if (pix < C::XPIX) { sy = pix / C::XW - 1; sx = pix % C::XW - 1; }
+                else { sy = (pix - C::XPIX) / TW; sx = (pix - C::XPIX) % TW; }
                 const int gy = I.ry + (I.sy0 + sy) * d, gx = I.rx + (I.sx0 + sx) * d;
                 if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
                     u32x4 *z = (u32x4 *)(buf + pix * (UBD_C * 2));
@@ -163,10 +177,10 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
             __builtin_amdgcn_s_barrier();             // raw barrier: the next item's DMA stays in flight
         }
         const int rows_eff = min(W16_TH, sh - I.sy0);
-        if (2 * wid < rows_eff) {                     // wave-uniform: this wave's two tile rows hold real sub-pixels
-            const int py = 2 * wid + krow;
-            const char *xb = buf + (py * W16_XW + kcol) * (UBD_C * 2);
-            const char *gb = buf + W16_XBYTES + (py * W16_TW + kcol) * (UBD_C * 2);
+        if (C::KROWS * wid < rows_eff) {              // wave-uniform: this wave's tile rows hold real sub-pixels
+            const int py = C::KROWS * wid + krow;
+            const char *xb = buf + (py * C::XW + kcol) * (UBD_C * 2);
+            const char *gb = buf + C::XBYTES + (py * TW + kcol) * (UBD_C * 2);
             // B operand: segments of the two N tiles (co 0..15, 16..23 + zero padding)
             u32x4 b[2];
             {
