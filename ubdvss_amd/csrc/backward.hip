@@ -397,14 +397,20 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
         }
     };
 
+    // XCD-aware item ranges (see dil_wgrad16_kernel): the phases of one image go through ONE L2
+    const int xcd = blockIdx.x & 7;
+    const int nblk_x = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int chunk = (items + 7) >> 3;
+    const int it_begin = xcd * chunk;
+    const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
     f32x4 acc[14][2] = {};
-    int it = blockIdx.x;
-    if (it < items) dma_item(it, smem);
-    for (int iter = 0; it < items; ++iter, it += gridDim.x) {
+    int it = it_begin + (int)(blockIdx.x >> 3);
+    if (it < it_end) dma_item(it, smem);
+    for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         float *buf = smem + (iter & 1) * WG_BUF_FLOATS;
         const item_t I = decode(it);
         __syncthreads();                              // this item's DMA landed; everyone left the other buffer
-        if (it + (int)gridDim.x < items) dma_item(it + gridDim.x, smem + ((iter + 1) & 1) * WG_BUF_FLOATS);
+        if (it + nblk_x < it_end) dma_item(it + nblk_x, smem + ((iter + 1) & 1) * WG_BUF_FLOATS);
         // zero the pixels that lie outside the image (halo / ragged sub-grid edge)
         const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
                             (I.ry + (I.sy0 + WG_TH) * d >= h) || (I.rx + (I.sx0 + WG_TW) * d >= w);   // block-uniform
