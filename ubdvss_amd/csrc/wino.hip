@@ -84,7 +84,7 @@ struct wsamples {
 
 // TAUX: element type of the ReLU-mask source (EPI 1): fp32 or a 16-bit activation type
 template <int EPI, typename TAUX>
-__global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
+__global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               const float *__restrict__ ufrag,
                                                               const void *__restrict__ aux_, int n, int h, int w, int d,
                                                               int log2d, unsigned in_bytes)
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
     if (g >= g_end) return;
     const int g_last = g_end - 1;
 
-    auto load_group = [&](wsamples &D, int gg) {
+    // one row (a) of the 4 x 4 sample array of group gg: 4 samples x (4 + 2) channel registers
+    auto load_row = [&](wsamples &D, int gg, int a) {
         const int gx = (int)((unsigned)gg % (unsigned)groups_x);
         const int rs = (int)((unsigned)gg / (unsigned)groups_x);
         const int s = (int)((unsigned)rs % (unsigned)half_rows);
@@ -134,25 +135,26 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
         const int y0 = ((s >> log2d) << (log2d + 1)) + (s & dm1);
         const int tcol = gx * 16 + i;
         const int xj = ((tcol >> log2d) << (log2d + 1)) + (tcol & dm1);   // this lane's tile column
+        const int iy = y0 + (a - 1) * d;
+        const bool rok = (iy >= 0) && (iy < h);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int iy = y0 + (a - 1) * d;
-            const bool rok = (iy >= 0) && (iy < h);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int ix = xj + (b - 1) * d;
-                const bool ok = rok && (ix >= 0) && (ix < w);
-                const unsigned byte_off = (unsigned)((img * h + iy) * w + ix) * (unsigned)(UBD_C * 4);
-                u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? byte_off + 16u * q : oob), 0, 0);
-                u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(ok ? byte_off + 64u + 8u * q : oob), 0, 0);
-                D.v4[a][b] = __builtin_bit_cast(f32x4, r4);
-                D.v2[a][b] = __builtin_bit_cast(f32x2, r2);
-            }
+        for (int b = 0; b < 4; ++b) {
+            const int ix = xj + (b - 1) * d;
+            const bool ok = rok && (ix >= 0) && (ix < w);
+            const unsigned byte_off = (unsigned)((img * h + iy) * w + ix) * (unsigned)(UBD_C * 4);
+            u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? byte_off + 16u * q : oob), 0, 0);
+            u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(ok ? byte_off + 64u + 8u * q : oob), 0, 0);
+            D.v4[a][b] = __builtin_bit_cast(f32x4, r4);
+            D.v2[a][b] = __builtin_bit_cast(f32x2, r2);
         }
     };
 
+    // Sample rows are fetched just in time so that at most three of the four are live (72 instead of 96 VGPRs ->
+    // three waves per SIMD): rows 0 and 2 arrive before the group starts (issued under the previous group's last 48
+    // MFMAs), row 1 is fetched under the MFMAs of transform row 0, row 3 under those of transform row 2.
     wsamples D;
-    load_group(D, g);
+    load_row(D, g, 0);
+    load_row(D, g, 2);
     for (;;) {
         // ---- transform-domain rows a = 0..3
         f32x4 Y[2][2][2];      // [output row rr][output col c][nt]
@@ -181,12 +183,15 @@ __global__ __launch_bounds__(256, 2) void dilconv_wino_kernel(const float *__res
                 V4[0] = T4[0] - T4[2]; V4[1] = T4[1] + T4[2]; V4[2] = T4[2] - T4[1]; V4[3] = T4[1] - T4[3];
                 V2[0] = T2[0] - T2[2]; V2[1] = T2[1] + T2[2]; V2[2] = T2[2] - T2[1]; V2[3] = T2[1] - T2[3];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (a == 0) load_row(D, g, 1);                   // sample row 0 is dead
+            if (a == 2) load_row(D, g, 3);                   // sample row 2 is dead
             if (a == 3) {
-                // D is dead from here on: prefetch the next group's samples under the last 48 MFMAs + epilogue.
+                // all sample rows are dead: rows 0 and 2 of the next group under the last 48 MFMAs + epilogue.
                 // Unconditional (clamped) so that hipcc counts the outstanding loads exactly.
-                __builtin_amdgcn_sched_barrier(0);
                 const int gn = g + stride;
-                load_group(D, gn < g_last ? gn : g_last);
+                load_row(D, gn < g_last ? gn : g_last, 0);
+                load_row(D, gn < g_last ? gn : g_last, 2);
             }
             f32x4 M[4][2];
 #pragma unroll
@@ -277,7 +282,7 @@ void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, co
     const int d = dilation;
     const long half_rows = ((H4 + 2 * d - 1) / (2 * d)) * d, half_cols = ((W4 + 2 * d - 1) / (2 * d)) * d;
     const long groups = (long)n * half_rows * ((half_cols + 15) / 16);
-    int grid = ubd_grid_for(groups, h->num_cus, 4, 2);
+    int grid = ubd_grid_for(groups, h->num_cus, 4, epi == 0 ? 3 : 2);     // forward: 150 VGPRs, three waves per SIMD
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
         hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
