@@ -153,7 +153,7 @@ __device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const f
 // ds_read_b64 of 16 neighbouring pixels conflict-free), CIN dwords for 1/3 channels.
 // ------------------------------------------------------------------------------------
 template <int CIN, int STRIDE> struct sep_cfg {
-    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int TH = (CIN == UBD_C) ? (STRIDE == 2 ? 4 : 8) : 16;   // 24 channels: 9 x 33 (stride 2) / 10 x 18 (stride 1) pixel patches
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int PS = CIN;                                   // LDS pixel stride in dwords
@@ -167,7 +167,7 @@ template <int CIN, int STRIDE> struct sep_cfg {
 // tile t is computed (24 channels: LDS-DMA into the other half of a double buffer; 1/3 channels: loads held
 // in registers across the compute phase, written to LDS afterwards).  Per-lane weights are loaded once.
 template <int CIN, int STRIDE, int IN_U8>
-__global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
+__global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) void sepconv_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                       const float *__restrict__ frag,  // pwfrag then dwlane
                                                       const float *__restrict__ bias, int n, int H, int W, int OH,
                                                       int OW, int pad_lo, float pre_sub, float pre_div)
@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv_kernel(co
             constexpr int NSTORE = (C::TH / 4) * 2;
             if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NSTORE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else { static_assert(NSTORE == 2, "counted vmcnt"); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();    // + everyone left the other buffer
             if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_FLOATS);
             const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
@@ -605,7 +606,7 @@ static void launch_sep(const ubd_handle *h, const void *x, int in_u8, float *y, 
 {
     const int th = sep_cfg<CIN, STRIDE>::TH;
     const int tiles = n * ((OH + th - 1) / th) * ((OW + 15) / 16);
-    const int per_cu = (CIN == UBD_C) ? ((sep_cfg<CIN, STRIDE>::BUF_FLOATS * 8 > 80 * 1024) ? 1 : 2) : 5;   // LDS-limited residency
+    const int per_cu = (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5;   // register / LDS-limited residency
     int grid = h->num_cus * per_cu;
     if (grid > tiles || CIN != UBD_C) grid = tiles;      // 1/3 channels: one tile per block, residency (not a register prefetch) hides the load latency
     if (in_u8)
