@@ -137,7 +137,7 @@ __device__ __forceinline__ void store_tile16_t(unsigned short *__restrict__ y, s
 // and 16+2q, 17+2q (one ds_read_b32 at byte 32+4q); pixel stride 48 B = 12 banks keeps 16 neighbouring pixels
 // conflict-free at stride 1.  The per-lane depthwise / pointwise weights are re-gathered to that split.
 template <int CIN, int STRIDE> struct sep16_cfg {
-    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 4 : 16;         // stride 2: 9 x 33 pixel patches (14 KiB)
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int CHUNKS = (CIN == UBD_C) ? PH * PW * 3 : 0;           // 16-byte chunks of the 16-bit patch
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
 {
     using C = sep16_cfg<CIN, STRIDE>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
-    // 24 channels: ring of LDS patch buffers.  Stride 1 (16 KiB patches) prefetches TWO tiles ahead: one tile's compute
-    // phase (~1 us) is shorter than the DMA latency under load; stride 2 (28 KiB patches) keeps the double buffer.
-    constexpr int NBUF = (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 1;
+    // 24 channels: ring of three LDS patch buffers (16 / 14 KiB each), i.e. the DMA runs TWO tiles ahead: one tile's
+    // compute phase (~1 us) is shorter than the DMA latency under load.
+    constexpr int NBUF = (CIN == UBD_C) ? 3 : 1;
     constexpr int NR = C::TH / 4;                                           // row tiles per wave per block tile
     // ONE LDS object: with a second __shared__ array hipcc orders every LDS read behind the LDS-DMA in flight (s_waitcnt vmcnt(0))
     __shared__ __attribute__((aligned(16))) char patch_mem[NBUF * C::BUF_BYTES];
@@ -314,16 +314,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             // issued after it may stay in flight.  After DMA(it) each wave issued: [AHEAD == 2: the stores of tile it-2,]
             // the DMA of tile it+AHEAD-1... i.e. per later tile C::ROUNDS DMA instructions (if that tile exists) and per
             // computed tile C::NSTORE buffer stores.
-            if constexpr (AHEAD == 1) {
-                if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if constexpr (C::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                static_assert(AHEAD == 1 || (C::NSTORE == 8 && C::ROUNDS == 4), "vmcnt immediates below assume 8 stores / 4 DMA instructions per tile");
-                if (it == 0) { if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                else if (it == 1) { if (has_next) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-                else { if (has_next) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-            }
+            static_assert(CIN != UBD_C || AHEAD == 2, "ring of three");
+            constexpr int R = C::ROUNDS, S = C::NSTORE;
+            if (it == 0) { if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else if (it == 1) { if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + R) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory"); }
+            else { if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S + R) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S) : "memory"); }
             __builtin_amdgcn_s_barrier();
             {
                 const int ahead_tile = tile + AHEAD * (int)gridDim.x;
@@ -578,7 +573,7 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
 {
     using C = sep16_cfg<CIN, STRIDE>;
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
-    const int per_cu = (CIN == UBD_C) ? (STRIDE == 2 ? 2 : 3) : 5;                 // LDS-limited residency
+    const int per_cu = (CIN == UBD_C) ? 3 : 5;                 // LDS-limited residency
     long grid = (long)h->num_cus * per_cu;
     if (grid > tiles || CIN != UBD_C) grid = tiles;      // 1/3 channels: one tile per block
     hipLaunchKernelGGL((sepconv16_kernel<CIN, STRIDE, IN_MODE, T>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sub, div);
