@@ -140,6 +140,20 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
 #pragma unroll
         for (int t = 0; t < 9; ++t) dwk1[t] = q < CIN ? (float)(T)dw_own[t * CIN + q] : 0.f;
     }
+    // the 1/3-channel kernel has registers to spare: it keeps the packed taps of the layer above (stride 1: no parity
+    // selection) in 54 VGPRs instead of re-reading the table for every tap
+    constexpr bool UREG = (CIN != UBD_C) && (GSRC == 1);
+    unsigned ureg[UREG ? 9 : 1][6];
+    if constexpr (UREG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+                const unsigned wb = (unsigned)__builtin_bit_cast(unsigned short, (T)dw_up[t * UBD_C + ch]);
+                ureg[t][s] = (ch & 1) ? (wb << 16) : wb;
+            }
+    }
     // A operand of the dDW product: A[rho = i][k = q] of step s = pw[ch(rho, tile)][co = chs_q(s)]; the result rows
     // 4q + r then are this lane's own channels: tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r
     float apw[6][NT_A];
@@ -332,12 +346,19 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                         const char *pd = draw + (dr * C::DCOLS + dc) * 48;
                         const u32x2 a = *(const u32x2 *)(pd + 8 * q);
                         const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
-                        const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
-                        const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
-                        const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
-                        acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
-                        acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
-                        acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
+                        if constexpr (UREG) {
+                            const int t = ky * 3 + j;
+                            acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
+                            acc[2] = dot2b<T>(a[1], ureg[t][2], acc[2]); acc[3] = dot2b<T>(a[1], ureg[t][3], acc[3]);
+                            acc[4] = dot2b<T>(b, ureg[t][4], acc[4]);    acc[5] = dot2b<T>(b, ureg[t][5], acc[5]);
+                        } else {
+                            const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
+                            const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
+                            const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
+                            acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
+                            acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
+                            acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
+                        }
                     }
                 }
                 const char *pm = mraw + (r * 16 + i) * 48;
