@@ -84,13 +84,13 @@ def forward(x_nhwc, tw, fml_compatible=True, act_dtype=None, grad_dtype=None):
     act_dtype "bfloat16"/"float16": hidden activations (including the depthwise output of a separable layer) and all
     3x3 / depthwise / pointwise kernels are rounded to that type (straight-through in the backward pass) --
     BASELINE.json configs[2..4].
-    grad_dtype: the gradient tensors the bf16 train step stores in bf16 are rounded to that type: the gradient w.r.t.
-    the pre-activation of L3 and of the six dilated layers, and w.r.t. the depthwise output of L2 and L3 (the
-    gradients w.r.t. the pre-activations of L1 and L2 only ever exist tile-wise in fp32)."""
+    grad_dtype: the gradient tensors of the bf16 train step are rounded to that type: the gradient w.r.t. every
+    pre-activation (L1..L9; those of L1 and L2 only ever exist tile-wise in LDS) and w.r.t. the depthwise output of
+    L2 and L3."""
     x = x_nhwc.permute(0, 3, 1, 2)
     i = 0
     for li, stride in enumerate((2, 1, 2)):
-        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype if li == 2 else None,
+        x = _ste_round(_sep(x, tw[i], tw[i + 1], tw[i + 2], stride, fml_compatible, grad_dtype,
                             grad_dtype if li >= 1 else None, act_dtype), act_dtype)
         i += 3
     for d in DILATIONS:

@@ -12,9 +12,13 @@
 //
 // Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers), of the raw bf16 D tile
 // (G3 tile, or dDW-above tile with halo) and of the mask tile; clamped addresses, out-of-map pixels zero-fixed.
-// Phase 1: fp32 G tile [pixel][24] from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q, 17+2q}).
-// Phase 2: as sep_bwd_kernel: depthwise recompute, dDW = G pw^T (MFMA, lands in the depthwise lane layout),
-// ddw (VALU), dpw / db (MFMA through an LDS transpose), dDW stored as bf16.
+// Phase 1 (L1, L2): the G tile [pixel][24] in T from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q,
+// 17+2q}); every G tensor of the bf16 train step is a bf16 tensor, these two just never leave LDS.
+// Phase 2, two row tiles (= 32 pixels = one k-block of the 16-bit MFMA) per step: dDW = G pw^T as ONE
+// v_mfma_f32_16x16x32 per tile of channels (K = output channel, B operand = 16 bytes of a G row; the result lands in
+// the depthwise lane layout), one pass over the taps (depthwise recompute + ddw on the VALU), the depthwise output
+// rounded to T into a per-wave [32 pixels][channels] LDS image, then dpw / db = DW^T G with K = pixel: both operands
+// read with ds_read_b64_tr_b16 (as dil_wgrad16_kernel), an all-ones column gives the bias gradient.
 #pragma once
 
 // NW = waves per block: the 1/3-channel layer needs few registers, so 6 waves share one tile's LDS (3 waves per SIMD at two
@@ -41,12 +45,14 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int XREGS = (CIN == UBD_C) ? 1 : (XPIX * CIN + NT - 1) / NT;                           // staged input elements per thread
     static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
     static constexpr int OFF_DMA = XF32_BYTES;
-    static constexpr int OFF_G = OFF_DMA + DMA_BYTES;                  // fp32 G tile
-    static constexpr int OFF_SDW = OFF_G + GPIX * UBD_C * 4;           // per-wave transpose tiles
-    static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // channels per pixel of the transpose tiles
-    static constexpr int OFF_WT = OFF_SDW + NW * 16 * SDW_W * 4;        // own depthwise taps [9][24] fp32 (24-channel layers)
+    static constexpr int OFF_G = OFF_DMA + DMA_BYTES;                  // G tile in T (GSRC 0: the D tile itself)
+    static constexpr int OFF_SDW = OFF_G + (GSRC == 0 ? 0 : GPIX * UBD_C * 2);   // per-wave depthwise-output images
+    static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // columns per pixel ([ch.., 1, 0..] for 1/3 channels)
+    static constexpr int SDW_BYTES = 32 * SDW_W * 2;                   // two row tiles per wave
+    static constexpr int OFF_WT = OFF_SDW + NW * SDW_BYTES;        // own depthwise taps [9][24] fp32 (24-channel layers)
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
-    static constexpr int LDS_BYTES = OFF_UT + 12 * UBD_C * 4;
+    static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,16): zeros
+    static constexpr int LDS_BYTES = OFF_CONST + 16;
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
 };
 
@@ -61,6 +67,13 @@ template <> __device__ __forceinline__ float dot2b<_Float16>(unsigned a, unsigne
 {
     typedef _Float16 v2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), acc, false);
+}
+
+template <typename T> __device__ __forceinline__ unsigned pack2b(float lo, float hi)
+{
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
 }
 
 template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float &lo, float &hi)
@@ -117,8 +130,16 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
     const char *xraw = dma;                                                      // 24-channel patch (bf16)
     const char *draw = dma + C::OFF_D;
     const char *mraw = dma + C::OFF_M;
-    float *gtile = (float *)(lds + C::OFF_G);
-    float (*s_dw)[16][C::SDW_W] = (float (*)[16][C::SDW_W])(lds + C::OFF_SDW);
+    char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
+    char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
+    const char *c_ones = lds + C::OFF_CONST, *c_zero = lds + C::OFF_CONST + 8;
+    if (threadIdx.x < 4) ((unsigned *)(lds + C::OFF_CONST))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
+    if constexpr (CIN != UBD_C) {                                           // [ch.., 1, 0..] rows: the constant columns are written once
+        for (int t = lane; t < 32 * C::SDW_W; t += 64) {
+            const int col = t % C::SDW_W;
+            ((unsigned short *)sdw)[t] = col == CIN ? __builtin_bit_cast(unsigned short, (T)1.0f) : (unsigned short)0;
+        }
+    }
     float *wt = (float *)(lds + C::OFF_WT);
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
@@ -154,18 +175,19 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                 ureg[t][s] = (ch & 1) ? (wb << 16) : wb;
             }
     }
-    // A operand of the dDW product: A[rho = i][k = q] of step s = pw[ch(rho, tile)][co = chs_q(s)]; the result rows
-    // 4q + r then are this lane's own channels: tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r
-    float apw[6][NT_A];
+    // A operand of the dDW product (K = output channel co, 24 padded to 32): lane (m = i, kg = q) holds
+    // pw[ch(m, tile)][8q .. 8q+7] in T (zero for q = 3); the result rows 4q + r then are this lane's own channels:
+    // tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r; 1/3 channels: tile 0 only, row 4q -> channel q
+    u32x4 apwb[NT_A];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int co = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
-        if constexpr (CIN == UBD_C) {
-            apw[s][0] = (float)(T)pw_own[i * UBD_C + co];
-            apw[s][1] = (i & 3) < 2 ? (float)(T)pw_own[(16 + 2 * (i >> 2) + (i & 3)) * UBD_C + co] : 0.f;
-        } else {
-            apw[s][0] = ((i & 3) == 0 && (i >> 2) < CIN) ? (float)(T)pw_own[(i >> 2) * UBD_C + co] : 0.f;
-        }
+    for (int tl = 0; tl < NT_A; ++tl) {
+        int ch;
+        if constexpr (CIN == UBD_C) ch = tl == 0 ? i : ((i & 3) < 2 ? 16 + 2 * (i >> 2) + (i & 3) : -1);
+        else ch = ((i & 3) == 0 && (i >> 2) < CIN) ? (i >> 2) : -1;
+        float w8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w8[e] = (ch >= 0 && q < 3) ? pw_own[ch * UBD_C + 8 * q + e] : 0.f;
+        apwb[tl] = u32x4{pack2b<T>(w8[0], w8[1]), pack2b<T>(w8[2], w8[3]), pack2b<T>(w8[4], w8[5]), pack2b<T>(w8[6], w8[7])};
     }
     const bool ch_ok = (CIN == UBD_C) || (q < CIN);
     const int cb = (q < CIN) ? q : 0;                                            // 1/3 channels
@@ -320,57 +342,55 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                 __syncthreads();
             }
         }
-        // ---- phase 1: fp32 G tile
+        // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
+        if constexpr (GSRC != 0) {
 #pragma unroll 1
         for (int r = wid; r < C::TH; r += C::NW) {
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if constexpr (GSRC == 0) {
-                const char *pd = draw + (r * 16 + i) * 48;
-                const u32x2 a = *(const u32x2 *)(pd + 8 * q);
-                const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
-                widen2b<T>(a[0], acc[0], acc[1]); widen2b<T>(a[1], acc[2], acc[3]); widen2b<T>(b, acc[4], acc[5]);
-            } else {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    int dr;
-                    if constexpr (GSRC == 1) dr = r + 2 - ky;
-                    else {
-                        if (((r + pad_up - ky) & 1) != 0) continue;     // wave-uniform: row parity (oy0 is even)
-                        dr = ((r + pad_up - ky) >> 1) + 1;
-                    }
+            for (int ky = 0; ky < 3; ++ky) {
+                int dr;
+                if constexpr (GSRC == 1) dr = r + 2 - ky;
+                else {
+                    if (((r + pad_up - ky) & 1) != 0) continue;     // wave-uniform: row parity (oy0 is even)
+                    dr = ((r + pad_up - ky) >> 1) + 1;
+                }
 #pragma unroll
-                    for (int j = 0; j < (GSRC == 1 ? 3 : 2); ++j) {
-                        int kx, dc;
-                        if constexpr (GSRC == 1) { kx = j; dc = i + 2 - j; }
-                        else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
-                        const char *pd = draw + (dr * C::DCOLS + dc) * 48;
-                        const u32x2 a = *(const u32x2 *)(pd + 8 * q);
-                        const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
-                        if constexpr (UREG) {
-                            const int t = ky * 3 + j;
-                            acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
-                            acc[2] = dot2b<T>(a[1], ureg[t][2], acc[2]); acc[3] = dot2b<T>(a[1], ureg[t][3], acc[3]);
-                            acc[4] = dot2b<T>(b, ureg[t][4], acc[4]);    acc[5] = dot2b<T>(b, ureg[t][5], acc[5]);
-                        } else {
-                            const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
-                            const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
-                            const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
-                            acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
-                            acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
-                            acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
-                        }
+                for (int j = 0; j < (GSRC == 1 ? 3 : 2); ++j) {
+                    int kx, dc;
+                    if constexpr (GSRC == 1) { kx = j; dc = i + 2 - j; }
+                    else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
+                    const char *pd = draw + (dr * C::DCOLS + dc) * 48;
+                    const u32x2 a = *(const u32x2 *)(pd + 8 * q);
+                    const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
+                    if constexpr (UREG) {
+                        const int t = ky * 3 + j;
+                        acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
+                        acc[2] = dot2b<T>(a[1], ureg[t][2], acc[2]); acc[3] = dot2b<T>(a[1], ureg[t][3], acc[3]);
+                        acc[4] = dot2b<T>(b, ureg[t][4], acc[4]);    acc[5] = dot2b<T>(b, ureg[t][5], acc[5]);
+                    } else {
+                        const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
+                        const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
+                        const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
+                        acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
+                        acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
+                        acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
                     }
                 }
-                const char *pm = mraw + (r * 16 + i) * 48;
-                const u32x2 ma = *(const u32x2 *)(pm + 8 * q);
-                const unsigned mb = *(const unsigned *)(pm + 32 + 4 * q);
-                acc[0] = (short)(ma[0] & 0xFFFFu) > 0 ? acc[0] : 0.f; acc[1] = ((int)ma[0] >> 16) > 0 ? acc[1] : 0.f;
-                acc[2] = (short)(ma[1] & 0xFFFFu) > 0 ? acc[2] : 0.f; acc[3] = ((int)ma[1] >> 16) > 0 ? acc[3] : 0.f;
-                acc[4] = (short)(mb & 0xFFFFu) > 0 ? acc[4] : 0.f;    acc[5] = ((int)mb >> 16) > 0 ? acc[5] : 0.f;
             }
-            float *pg = gtile + (r * 16 + i) * UBD_C;
-            *(f32x4 *)(pg + 4 * q) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            *(f32x2 *)(pg + 16 + 2 * q) = f32x2{acc[4], acc[5]};
+            const char *pm = mraw + (r * 16 + i) * 48;
+            const u32x2 ma = *(const u32x2 *)(pm + 8 * q);
+            const unsigned mb = *(const unsigned *)(pm + 32 + 4 * q);
+            u32x2 g4 = {pack2b<T>(acc[0], acc[1]), pack2b<T>(acc[2], acc[3])};
+            unsigned g2 = pack2b<T>(acc[4], acc[5]);
+            // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
+            g4[0] &= (((short)(ma[0] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)ma[0] >> 16) > 0) ? 0xFFFF0000u : 0u);
+            g4[1] &= (((short)(ma[1] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)ma[1] >> 16) > 0) ? 0xFFFF0000u : 0u);
+            g2 &= (((short)(mb & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)mb >> 16) > 0) ? 0xFFFF0000u : 0u);
+            char *pg = g16 + (r * 16 + i) * 48;
+            *(u32x2 *)(pg + 8 * q) = g4;
+            *(unsigned *)(pg + 32 + 4 * q) = g2;
+        }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
@@ -379,104 +399,107 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
             if constexpr (CIN != UBD_C) load_x(gn);
         }
 
-        // ---- phase 2 (per row tile, as sep_bwd_kernel)
+        // ---- phase 2: two row tiles (one k-block of 32 pixels) per step
+        const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;   // roles in the transposed reads (bwd16.h)
 #pragma unroll 1
-        for (int r = wid; r < C::TH; r += C::NW) {
-            const int oy = oy0 + r;
-            if (oy >= OH) break;
-            const int ox = ox0 + i;
-            const bool pvalid = ox < OW;
-            // G of this pixel in the k-split {4q..4q+3, 16+2q, 17+2q} and dDW[i][ch] = sum_co G[i][co] pw[ch][co] first
-            // (rows = this lane's channels, cols = pixels), then ONE pass over the taps feeds both the depthwise
-            // recompute (for dpw) and the depthwise kernel gradient
-            float g6[6];
-            {
-                const float *pg = gtile + (r * 16 + i) * UBD_C;
-                const f32x4 g4 = *(const f32x4 *)(pg + 4 * q);
-                const f32x2 g2 = *(const f32x2 *)(pg + 16 + 2 * q);
-                g6[0] = g4[0]; g6[1] = g4[1]; g6[2] = g4[2]; g6[3] = g4[3]; g6[4] = g2[0]; g6[5] = g2[1];
-            }
-            f32x4 dA = {0.f, 0.f, 0.f, 0.f}, dB = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                dA = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][0], g6[s], dA, 0, 0, 0);
-                if constexpr (NT_A == 2) dB = __builtin_amdgcn_mfma_f32_16x16x4f32(apw[s][1], g6[s], dB, 0, 0, 0);
-            }
-            float ddwv[CPL];
-            if constexpr (CIN == UBD_C) {
-                ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
-            } else {
-                ddwv[0] = dA[0];
-            }
-            float dwv[CPL];
-#pragma unroll
-            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int t = ky * 3 + kx;
-                    const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
-                    if constexpr (CIN == UBD_C) {
-                        const char *px = xraw + pix * 48;
-                        const u32x2 a = *(const u32x2 *)(px + 8 * q);
-                        const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
-                        const f32x4 w4 = *(const f32x4 *)(wt + t * UBD_C + 4 * q);
-                        const f32x2 w2 = *(const f32x2 *)(wt + t * UBD_C + 16 + 2 * q);
-                        float v[6];
-                        widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
-                        dwv[0] = fmaf(v[0], w4[0], dwv[0]); dwv[1] = fmaf(v[1], w4[1], dwv[1]);
-                        dwv[2] = fmaf(v[2], w4[2], dwv[2]); dwv[3] = fmaf(v[3], w4[3], dwv[3]);
-                        dwv[4] = fmaf(v[4], w2[0], dwv[4]); dwv[5] = fmaf(v[5], w2[1], dwv[5]);
-#pragma unroll
-                        for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
-                    } else {
-                        const float v = xf32[pix * CIN + cb];
-                        dwv[0] = fmaf(v, dwk1[t], dwv[0]);              // dwk1 is zero for lanes without a channel
-                        ddw[t][0] = fmaf(v, ddwv[0], ddw[t][0]);
-                    }
+        for (int rp = 0; rp < C::TH / (2 * C::NW); ++rp) {
+            const int r0 = wid + C::NW * (2 * rp), r1 = r0 + C::NW;
+#pragma unroll 1
+            for (int hr = 0; hr < 2; ++hr) {
+                const int r = hr ? r1 : r0;
+                const int oy = oy0 + r, ox = ox0 + i;
+                // dDW[pixel i][ch] = sum_co G[i][co] pw[ch][co] first (rows = this lane's channels), then ONE pass over the
+                // taps feeds both the depthwise recompute (for dpw) and the depthwise kernel gradient
+                u32x4 gb = *(const u32x4 *)(g16 + (r * 16 + i) * 48 + 16 * (q < 3 ? q : 0));
+                if (q == 3) gb = u32x4{0u, 0u, 0u, 0u};
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 dA = mfma16<T>(apwb[0], gb, z4);
+                float ddwv[CPL];
+                if constexpr (CIN == UBD_C) {
+                    const f32x4 dB = mfma16<T>(apwb[1], gb, z4);
+                    ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
+                } else {
+                    ddwv[0] = dA[0];
                 }
-            // DW transposed through this wave's LDS tile for the dpw / db product (A = [channel][pixel])
-            // (the forward pass stores the depthwise output in T before the pointwise product)
-            if constexpr (CIN == UBD_C) {
-                *(f32x4 *)&s_dw[wid][i][4 * q] = f32x4{(float)(T)dwv[0], (float)(T)dwv[1], (float)(T)dwv[2], (float)(T)dwv[3]};
-                *(f32x2 *)&s_dw[wid][i][16 + 2 * q] = f32x2{(float)(T)dwv[4], (float)(T)dwv[5]};
-            } else {
-                if (ch_ok) s_dw[wid][i][cb] = (float)(T)dwv[0];
+                float dwv[CPL];
+#pragma unroll
+                for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int t = ky * 3 + kx;
+                        const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
+                        if constexpr (CIN == UBD_C) {
+                            const char *px = xraw + pix * 48;
+                            const u32x2 a = *(const u32x2 *)(px + 8 * q);
+                            const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
+                            const f32x4 w4 = *(const f32x4 *)(wt + t * UBD_C + 4 * q);
+                            const f32x2 w2 = *(const f32x2 *)(wt + t * UBD_C + 16 + 2 * q);
+                            float v[6];
+                            widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
+                            dwv[0] = fmaf(v[0], w4[0], dwv[0]); dwv[1] = fmaf(v[1], w4[1], dwv[1]);
+                            dwv[2] = fmaf(v[2], w4[2], dwv[2]); dwv[3] = fmaf(v[3], w4[3], dwv[3]);
+                            dwv[4] = fmaf(v[4], w2[0], dwv[4]); dwv[5] = fmaf(v[5], w2[1], dwv[5]);
+#pragma unroll
+                            for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
+                        } else {
+                            const float v = xf32[pix * CIN + cb];
+                            dwv[0] = fmaf(v, dwk1[t], dwv[0]);          // dwk1 is zero for lanes without a channel
+                            ddw[t][0] = fmaf(v, ddwv[0], ddw[t][0]);
+                        }
+                    }
+                // depthwise output in T (as the forward pass stored it) into this wave's [32 pixels][channels] image
+                if constexpr (CIN == UBD_C) {
+                    char *ps = sdw + (hr * 16 + i) * 48;
+                    *(u32x2 *)(ps + 8 * q) = u32x2{pack2b<T>(dwv[0], dwv[1]), pack2b<T>(dwv[2], dwv[3])};
+                    *(unsigned *)(ps + 32 + 4 * q) = pack2b<T>(dwv[4], dwv[5]);
+                    if (dDW != nullptr && oy < OH && ox < OW) {        // 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
+                        char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
+                        *(u32x2 *)(pd + 8 * q) = u32x2{pack2b<T>(ddwv[0], ddwv[1]), pack2b<T>(ddwv[2], ddwv[3])};
+                        *(unsigned *)(pd + 32 + 4 * q) = pack2b<T>(ddwv[4], ddwv[5]);
+                    }
+                } else {
+                    if (ch_ok) ((unsigned short *)sdw)[(hr * 16 + i) * C::SDW_W + cb] = __builtin_bit_cast(unsigned short, (T)dwv[0]);
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
+            // dpw[ch][co] += sum over the 32 pixels DW[pixel][ch] G[pixel][co]; an all-ones column of the A operand gives db.
+            // Transposed reads: lane 4qq+pp of group grp supplies the address of pixel k = 8 grp + 4 j + qq, segment pp.
+            {
+                u32x4 am[MT_PW], bn[2];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int pr = 4 * g4 + q;
-                const float *gp = gtile + (r * 16 + pr) * UBD_C;
-                const float b0 = gp[i];
-                const float b1 = i < 8 ? gp[16 + i] : 0.f;
-                float a0, a1 = 0.f;
-                if constexpr (CIN == UBD_C) {
-                    a0 = s_dw[wid][pr][i];
-                    a1 = i < 8 ? s_dw[wid][pr][16 + i] : (i == 8 ? 1.f : 0.f);
-                } else {
-                    a0 = i < CIN ? s_dw[wid][pr][i] : (i == CIN ? 1.f : 0.f);
+                for (int mt = 0; mt < MT_PW; ++mt) {
+                    s16x4 h[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = 8 * grp + 4 * j + qq;
+                        const char *pa;
+                        if constexpr (CIN == UBD_C) pa = mt == 0 ? sdw + k * 48 + 8 * pp : (pp < 2 ? sdw + k * 48 + 32 + 8 * pp : (pp == 2 ? c_ones : c_zero));
+                        else pa = pp == 0 ? sdw + k * (C::SDW_W * 2) : c_zero;
+                        h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pa);
+                    }
+                    am[mt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
                 }
-                accpw[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accpw[0][0], 0, 0, 0);
-                accpw[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accpw[0][1], 0, 0, 0);
-                if constexpr (MT_PW == 2) {
-                    accpw[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accpw[1][0], 0, 0, 0);
-                    accpw[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accpw[1][1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    s16x4 h[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = 8 * grp + 4 * j + qq;
+                        const char *pg = g16 + (((k < 16 ? r0 : r1) * 16 + (k & 15)) * 48);
+                        const char *pb = nt == 0 ? pg + 8 * pp : (pp < 2 ? pg + 32 + 8 * pp : c_zero);
+                        h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
+                    }
+                    bn[nt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT_PW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) accpw[mt][nt] = mfma16<T>(am[mt], bn[nt], accpw[mt][nt]);
             }
             __builtin_amdgcn_wave_barrier();
-            if constexpr (CIN == UBD_C) {
-                if (dDW != nullptr && pvalid) {                        // bf16: 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
-                    char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
-                    u32x2 o;
-                    o[0] = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[1]) << 16);
-                    o[1] = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[3]) << 16);
-                    *(u32x2 *)(pd + 8 * q) = o;
-                    *(unsigned *)(pd + 32 + 4 * q) = (unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[4]) | ((unsigned)__builtin_bit_cast(unsigned short, (T)ddwv[5]) << 16);
-                }
-            }
         }
     }
     // ---- flush: wave-sequential reduction of the per-lane sums into this block's row of the partial-sum matrix
