@@ -358,6 +358,58 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
             if (has_next) load_regs(nxt, stage);                     // in flight during the compute phase
         }
 
+        if constexpr (CIN == UBD_C && STRIDE == 1) {
+            // ---- compute, stride 1: wave `wid` owns RW consecutive rows and slides over RW + 2 patch rows: every
+            //      patch row is read from LDS once (3 x (b128 + b64)) and feeds up to three output rows
+            constexpr int RW = C::TH / 4;
+            const int rb = wid * RW;
+            float dwv[RW][6];
+#pragma unroll
+            for (int o = 0; o < RW; ++o)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) dwv[o][s] = 0.f;
+#pragma unroll
+            for (int yy = 0; yy < RW + 2; ++yy) {
+                f32x4 v4[3];
+                f32x2 v2[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int pcol = i + kx;
+                    const float *p = patch + ((rb + yy) * C::PW + pcol) * C::PS;
+                    // 16-byte chunk c of the pixel sits in slot (c + 3f) % 6, f = (patch column >> 3) & 1
+                    const int rot = 3 * ((pcol >> 3) & 1);
+                    int s4 = q + rot, s2 = 4 + (q >> 1) + rot;
+                    s4 = s4 >= 6 ? s4 - 6 : s4; s2 = s2 >= 6 ? s2 - 6 : s2;
+                    v4[kx] = *(const f32x4 *)(p + 4 * s4);
+                    v2[kx] = *(const f32x2 *)(p + 4 * s2 + 2 * (q & 1));
+                }
+#pragma unroll
+                for (int o = 0; o < RW; ++o) {
+                    const int ky = yy - o;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int t = ky * 3 + kx;
+                        dwv[o][0] = fmaf(v4[kx][0], dwk[t][0], dwv[o][0]);
+                        dwv[o][1] = fmaf(v4[kx][1], dwk[t][1], dwv[o][1]);
+                        dwv[o][2] = fmaf(v4[kx][2], dwk[t][2], dwv[o][2]);
+                        dwv[o][3] = fmaf(v4[kx][3], dwk[t][3], dwv[o][3]);
+                        dwv[o][4] = fmaf(v2[kx][0], dwk[t][4], dwv[o][4]);
+                        dwv[o][5] = fmaf(v2[kx][1], dwk[t][5], dwv[o][5]);
+                    }
+                }
+                if (yy >= 2) {                               // output row yy - 2 is complete
+                    const int o = yy - 2, oy = oy0 + rb + o;
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) {            // weights as the A operand: D = [channel][pixel] (see store_tile_relu_t)
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[s][0], dwv[o][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[s][1], dwv[o][s], acc1, 0, 0, 0);
+                    }
+                    store_tile_relu_t(y, ((size_t)img * OH + oy) * OW, ox0, oy < OH ? OW : 0, lane, acc0, acc1, bA, bB);
+                }
+            }
+        } else {
         // ---- compute: wave `wid` owns rows wid, wid+4, ...
         for (int r = wid; r < C::TH; r += 4) {                       // fixed trip count: rows past the image only mask their stores
             const int oy = oy0 + r;
@@ -396,6 +448,7 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[s][1], dwv[s], acc1, 0, 0, 0);
             }
             store_tile_relu_t(y, ((size_t)img * OH + oy) * OW, ox0, oy < OH ? OW : 0, lane, acc0, acc1, bA, bB);
+        }
         }
         if (!has_next) break;
         tile = nxt;
