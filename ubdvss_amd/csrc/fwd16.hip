@@ -354,6 +354,50 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             if (has_next) load_regs(nxt, stage);
         }
 
+        if constexpr (CIN == UBD_C && STRIDE == 1) {
+            // stride 1: wave `wid` owns NR consecutive rows and slides over NR + 2 patch rows: every patch row is read
+            // from LDS once (3 x (b64 + b32)) and feeds up to three output rows
+            const int rb = wid * NR;
+            float dwv[NR][6];
+#pragma unroll
+            for (int o = 0; o < NR; ++o)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) dwv[o][s] = 0.f;
+#pragma unroll
+            for (int yy = 0; yy < NR + 2; ++yy) {
+                u32x2 a[3];
+                unsigned b[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const char *p = patch + ((rb + yy) * C::PW + i + kx) * (UBD_C * 2);
+                    a[kx] = *(const u32x2 *)(p + 8 * q);
+                    b[kx] = *(const unsigned *)(p + 32 + 4 * q);
+                }
+#pragma unroll
+                for (int o = 0; o < NR; ++o) {
+                    const int ky = yy - o;
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int t = ky * 3 + kx;
+                        dwv[o][0] = dot2_16<T>(a[kx][0], dwp[t][0], dwv[o][0]); dwv[o][1] = dot2_16<T>(a[kx][0], dwp[t][1], dwv[o][1]);
+                        dwv[o][2] = dot2_16<T>(a[kx][1], dwp[t][2], dwv[o][2]); dwv[o][3] = dot2_16<T>(a[kx][1], dwp[t][3], dwv[o][3]);
+                        dwv[o][4] = dot2_16<T>(b[kx], dwp[t][4], dwv[o][4]);    dwv[o][5] = dot2_16<T>(b[kx], dwp[t][5], dwv[o][5]);
+                    }
+                }
+                if (yy >= 2) {                               // output row yy - 2 is complete
+                    const int o = yy - 2, oy = oy0 + rb + o;
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const u32x4 av = {pack2<T>(dwv[o][0], dwv[o][1]), pack2<T>(dwv[o][2], dwv[o][3]), pack2<T>(dwv[o][4], dwv[o][5]), 0u};
+                    const f32x4 acc0 = h16<T>::mfma(pwb[0], av, z4);     // weights as the A operand: D = [channel][pixel]
+                    const f32x4 acc1 = h16<T>::mfma(pwb[1], av, z4);
+                    int npx = OW - ox0 < 16 ? OW - ox0 : 16;
+                    npx = (oy < OH) ? npx : 0;
+                    const u32x2 nomask = {0u, 0u};
+                    store_tile16_t<T, 0>(y, ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int r = wid + 4 * k;
@@ -393,6 +437,7 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             npx = (oy < OH) ? npx : 0;
             const u32x2 nomask = {0u, 0u};
             store_tile16_t<T, 0>(y, ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
+        }
         }
         if (!has_next) break;
         tile = nxt;
