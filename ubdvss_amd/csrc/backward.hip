@@ -826,7 +826,7 @@ static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const u
 {
     using C = sepb16_cfg<CIN, STRIDE, GSRC>;
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
-    int grid = h->num_cus * (C::LDS_BYTES > 78 * 1024 ? 1 : (C::LDS_BYTES > 52 * 1024 || CIN != UBD_C ? 2 : 3));
+    int grid = h->num_cus * C::BLOCKS_PER_CU;
     if (grid > tiles) grid = (int)tiles;
     if (in_u8)
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);

@@ -53,6 +53,9 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
     static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,16): zeros
     static constexpr int LDS_BYTES = OFF_CONST + 16;
+    // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
+    // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : 2);
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
 };
 
@@ -111,7 +114,7 @@ __device__ __forceinline__ void sepb16_stage(const char *__restrict__ tensor, in
 }
 
 template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
-__global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
+__global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU == 3) ? 3 : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
                                                         const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
@@ -140,14 +143,17 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
             ((unsigned short *)sdw)[t] = col == CIN ? __builtin_bit_cast(unsigned short, (T)1.0f) : (unsigned short)0;
         }
     }
-    float *wt = (float *)(lds + C::OFF_WT);
+    unsigned *wtp = (unsigned *)(lds + C::OFF_WT);                          // own taps [9][24], packed like utp
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
     // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
     if constexpr (CIN == UBD_C)
-        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) wt[t] = (float)(T)dw_own[t];      // Keras (3,3,C,1): [tap][ch]; 16-bit mode uses the kernels in T
+        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) {                               // Keras (3,3,C,1): [tap][ch]; kernels are used in T
+            const unsigned wb = (unsigned)__builtin_bit_cast(unsigned short, (T)dw_own[t]);
+            wtp[t] = ((t % UBD_C) & 1) ? (wb << 16) : wb;
+        }
     if constexpr (GSRC != 0)
         for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
@@ -421,6 +427,15 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                 } else {
                     ddwv[0] = dA[0];
                 }
+                // dDW in T (what is stored and what the depthwise-kernel gradient multiplies, as in the oracle), one value per
+                // dword in the half that matches the channel's position in its pair
+                unsigned dp[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                if constexpr (CIN == UBD_C) {
+                    const unsigned p01 = pack2b<T>(ddwv[0], ddwv[1]), p23 = pack2b<T>(ddwv[2], ddwv[3]), p45 = pack2b<T>(ddwv[4], ddwv[5]);
+                    dp[0] = p01 & 0xFFFFu; dp[1] = p01 & 0xFFFF0000u;
+                    dp[2] = p23 & 0xFFFFu; dp[3] = p23 & 0xFFFF0000u;
+                    dp[4] = p45 & 0xFFFFu; dp[5] = p45 & 0xFFFF0000u;
+                }
                 float dwv[CPL];
 #pragma unroll
                 for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
@@ -431,18 +446,18 @@ __global__ __launch_bounds__(256, 2) void sepb16_kernel(const void *__restrict__
                         const int t = ky * 3 + kx;
                         const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
                         if constexpr (CIN == UBD_C) {
+                            // raw 16-bit activation pairs x packed taps -> depthwise output; x packed dDW pairs -> ddw
                             const char *px = xraw + pix * 48;
                             const u32x2 a = *(const u32x2 *)(px + 8 * q);
                             const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
-                            const f32x4 w4 = *(const f32x4 *)(wt + t * UBD_C + 4 * q);
-                            const f32x2 w2 = *(const f32x2 *)(wt + t * UBD_C + 16 + 2 * q);
-                            float v[6];
-                            widen2b<T>(a[0], v[0], v[1]); widen2b<T>(a[1], v[2], v[3]); widen2b<T>(b, v[4], v[5]);
-                            dwv[0] = fmaf(v[0], w4[0], dwv[0]); dwv[1] = fmaf(v[1], w4[1], dwv[1]);
-                            dwv[2] = fmaf(v[2], w4[2], dwv[2]); dwv[3] = fmaf(v[3], w4[3], dwv[3]);
-                            dwv[4] = fmaf(v[4], w2[0], dwv[4]); dwv[5] = fmaf(v[5], w2[1], dwv[5]);
-#pragma unroll
-                            for (int s = 0; s < 6; ++s) ddw[t][s] = fmaf(v[s], ddwv[s], ddw[t][s]);
+                            const u32x4 w4 = *(const u32x4 *)(wtp + t * UBD_C + 4 * q);
+                            const u32x2 w2 = *(const u32x2 *)(wtp + t * UBD_C + 16 + 2 * q);
+                            dwv[0] = dot2b<T>(a[0], w4[0], dwv[0]); dwv[1] = dot2b<T>(a[0], w4[1], dwv[1]);
+                            dwv[2] = dot2b<T>(a[1], w4[2], dwv[2]); dwv[3] = dot2b<T>(a[1], w4[3], dwv[3]);
+                            dwv[4] = dot2b<T>(b, w2[0], dwv[4]);    dwv[5] = dot2b<T>(b, w2[1], dwv[5]);
+                            ddw[t][0] = dot2b<T>(a[0], dp[0], ddw[t][0]); ddw[t][1] = dot2b<T>(a[0], dp[1], ddw[t][1]);
+                            ddw[t][2] = dot2b<T>(a[1], dp[2], ddw[t][2]); ddw[t][3] = dot2b<T>(a[1], dp[3], ddw[t][3]);
+                            ddw[t][4] = dot2b<T>(b, dp[4], ddw[t][4]);    ddw[t][5] = dot2b<T>(b, dp[5], ddw[t][5]);
                         } else {
                             const float v = xf32[pix * CIN + cb];
                             dwv[0] = fmaf(v, dwk1[t], dwv[0]);          // dwk1 is zero for lanes without a channel
