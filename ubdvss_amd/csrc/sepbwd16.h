@@ -10,8 +10,9 @@
 //   GSRC 1  (L1)  G = dwT(dDW of L2; stride 1, pad 1)            * (a1 > 0)
 //   GSRC 2  (L2)  G = dwT(dDW of L3; stride 2, pad_up top/left)  * (a2 > 0)
 //
-// Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers), of the raw bf16 D tile
-// (G3 tile, or dDW-above tile with halo) and of the mask tile; clamped addresses, out-of-map pixels zero-fixed.
+// Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers) and of the raw bf16 D tile
+// (G3 tile, or dDW-above tile with halo); clamped addresses, out-of-map pixels zero-fixed.  The ReLU mask (used once per
+// pixel) is not staged: every lane fetches the words of its own pixels while the DMA is in flight.
 // Phase 1 (L1, L2): the G tile [pixel][24] in T from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q,
 // 17+2q}); every G tensor of the bf16 train step is a bf16 tensor, these two just never leave LDS.
 // Phase 2, two row tiles (= 32 pixels = one k-block of the 16-bit MFMA) per step: dDW = G pw^T as ONE
@@ -34,14 +35,13 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int DROWS = GSRC == 0 ? TH : (GSRC == 1 ? TH + 2 : TH / 2 + 2);
     static constexpr int DCOLS = GSRC == 0 ? 16 : (GSRC == 1 ? 18 : 10);
     static constexpr int DPIX = DROWS * DCOLS;
-    static constexpr int MPIX = GSRC == 0 ? 0 : GPIX;
     // DMA regions (16-byte chunks, 3 per bf16 pixel; each region is a whole number of 1 KiB wave-instructions):
-    // [X patch (24 ch only)] [D tile] [mask tile]
+    // [X patch (24 ch only)] [D tile]
     static constexpr int XCHUNKS = (CIN == UBD_C) ? XPIX * 3 : 0;
-    static constexpr int XI = (XCHUNKS + 63) / 64, DI = (DPIX * 3 + 63) / 64, MI = (MPIX * 3 + 63) / 64;   // wave-instructions
-    static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW, MK = (MI + NW - 1) / NW;         // per wave
-    static constexpr int OFF_D = XI * 1024, OFF_M = OFF_D + DI * 1024;     // byte offsets inside the DMA area
-    static constexpr int DMA_BYTES = (XI + DI + MI) * 1024;
+    static constexpr int XI = (XCHUNKS + 63) / 64, DI = (DPIX * 3 + 63) / 64;        // wave-instructions
+    static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW;           // per wave
+    static constexpr int OFF_D = XI * 1024;                                         // byte offset of the D tile inside the DMA area
+    static constexpr int DMA_BYTES = (XI + DI) * 1024;
     static constexpr int XREGS = (CIN == UBD_C) ? 1 : (XPIX * CIN + NT - 1) / NT;                           // staged input elements per thread
     static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
     static constexpr int OFF_DMA = XF32_BYTES;
@@ -132,7 +132,6 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     char *dma = lds + C::OFF_DMA;
     const char *xraw = dma;                                                      // 24-channel patch (bf16)
     const char *draw = dma + C::OFF_D;
-    const char *mraw = dma + C::OFF_M;
     char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
     char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
     const char *c_ones = lds + C::OFF_CONST, *c_zero = lds + C::OFF_CONST + 8;
@@ -211,12 +210,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     };
     // (the 24-channel kernels have no registers to spare for them and always take the clamped path)
     constexpr bool PRE = (CIN != UBD_C);
-    int xrel[C::XK > 0 ? C::XK : 1], drel[C::DK], mrel[C::MK > 0 ? C::MK : 1];
+    int xrel[C::XK > 0 ? C::XK : 1], drel[C::DK];
     if constexpr (PRE) {
 #pragma unroll
         for (int k = 0; k < C::DK; ++k) drel[k] = chunk_rel(k * C::NW + wid, C::DPIX * 3, C::DCOLS, DW_);
-#pragma unroll
-        for (int k = 0; k < C::MK; ++k) mrel[k] = chunk_rel(k * C::NW + wid, C::MPIX * 3, 16, OW);
     }
     int ld_rel[C::XREGS];                                                       // 1/3 channels: element offsets
     if constexpr (CIN != UBD_C) {
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // Tile geometry and the staging steps.  Pipeline per tile: [X patch DMA (24 ch)] -> wait -> phase 1 (D, mask -> G tile)
     // -> D / mask DMA of the NEXT tile (their LDS regions are free again) and, for 1/3 channels, the next tile's input
     // loads into registers -> phase 2.  Only the 24-channel X patch (single-buffered) is fetched with exposed latency.
-    struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder, mborder; };
+    struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder; };
     auto tile_geom = [&](int tile) {
         geom g;
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
@@ -255,13 +252,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         g.dx0 = GSRC == 0 ? g.ox0 : (GSRC == 1 ? g.ox0 - 1 : (g.ox0 >> 1) - 1);
         g.xborder = (g.iy0 < 0) || (g.ix0 < 0) || (g.iy0 + C::PH > H) || (g.ix0 + C::PW > W);
         g.dborder = (g.dy0 < 0) || (g.dx0 < 0) || (g.dy0 + C::DROWS > DH) || (g.dx0 + C::DCOLS > DW_);
-        g.mborder = (GSRC != 0) && ((g.oy0 + C::TH > OH) || (g.ox0 + 16 > OW));
         return g;
     };
     auto stage_dm = [&](const geom &g) {
         sepb16_stage<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW, (PRE ? C::DK : 1)>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, drel, g.dborder || !PRE, dma + C::OFF_D, lane, wid);
-        if constexpr (GSRC != 0)
-            sepb16_stage<C::MK, C::MI, C::MPIX * 3, 16, C::NW, (PRE ? C::MK : 1)>((const char *)maskact, g.img, OH, OW, g.oy0, g.ox0, mrel, g.mborder || !PRE, dma + C::OFF_M, lane, wid);
     };
     // 1/3-channel input: raw bits (fp32 pattern or zero-extended byte; 0x100 / pre_sub bits = "outside", exactly 0 after the
     // preprocessing) held in registers across phase 2
@@ -303,7 +297,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     for (; tile < total; tile += gridDim.x) {
         const geom g = tile_geom(tile);
         const int img = g.img, oy0 = g.oy0, ox0 = g.ox0, ix0 = g.ix0, iy0 = g.iy0, dy0 = g.dy0, dx0 = g.dx0;
-        const bool xborder = g.xborder, dborder = g.dborder, mborder = g.mborder;
+        const bool xborder = g.xborder, dborder = g.dborder;
         __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
         if constexpr (CIN == UBD_C)
             sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
@@ -317,9 +311,26 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                 }
             }
         }
+        // ReLU mask (this layer's saved output) of this wave's G rows, straight from memory; the 24-channel kernels issue
+        // the loads here so that they arrive under the DMA wait (outside the map: 0 -> G = 0)
+        constexpr bool MPRE = (CIN == UBD_C);
+        u32x2 mka[C::TH / C::NW];
+        unsigned mkb[C::TH / C::NW];
+        if constexpr (GSRC != 0 && MPRE) {
+#pragma unroll
+            for (int kr = 0; kr < C::TH / C::NW; ++kr) {
+                const int my = oy0 + wid + C::NW * kr, mx = ox0 + i;
+                mka[kr] = u32x2{0u, 0u}; mkb[kr] = 0u;
+                if (my < OH && mx < OW) {
+                    const char *pm = (const char *)maskact + (((size_t)img * OH + my) * OW + mx) * (UBD_C * 2);
+                    mka[kr] = *(const u32x2 *)(pm + 8 * q);
+                    mkb[kr] = *(const unsigned *)(pm + 32 + 4 * q);
+                }
+            }
+        }
         __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
         {
-            if ((CIN == UBD_C && xborder) || dborder || mborder) {     // block-uniform
+            if ((CIN == UBD_C && xborder) || dborder) {                // block-uniform
                 const u32x4 zero = {0u, 0u, 0u, 0u};
                 if (CIN == UBD_C && xborder)
                     for (int pix = threadIdx.x; pix < C::XPIX; pix += C::NT) {
@@ -339,20 +350,24 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                             z[0] = zero; z[1] = zero; z[2] = zero;
                         }
                     }
-                if (mborder)
-                    for (int pix = threadIdx.x; pix < C::MPIX; pix += C::NT)
-                        if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
-                            u32x4 *z = (u32x4 *)(dma + C::OFF_M + pix * 48);
-                            z[0] = zero; z[1] = zero; z[2] = zero;
-                        }
                 __syncthreads();
             }
         }
         // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
         if constexpr (GSRC != 0) {
-#pragma unroll 1
-        for (int r = wid; r < C::TH; r += C::NW) {
+        constexpr int P1_UNROLL = MPRE ? C::TH / C::NW : 1;
+#pragma unroll P1_UNROLL
+        for (int kr = 0; kr < C::TH / C::NW; ++kr) {
+            const int r = wid + C::NW * kr;
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            u32x2 ma = {0u, 0u};
+            unsigned mb = 0u;
+            if constexpr (MPRE) { ma = mka[kr]; mb = mkb[kr]; }
+            else if (oy0 + r < OH && ox0 + i < OW) {                 // register-bound 1/3-channel kernel: fetched in place
+                const char *pm = (const char *)maskact + (((size_t)img * OH + oy0 + r) * OW + ox0 + i) * (UBD_C * 2);
+                ma = *(const u32x2 *)(pm + 8 * q);
+                mb = *(const unsigned *)(pm + 32 + 4 * q);
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 int dr;
@@ -384,9 +399,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     }
                 }
             }
-            const char *pm = mraw + (r * 16 + i) * 48;
-            const u32x2 ma = *(const u32x2 *)(pm + 8 * q);
-            const unsigned mb = *(const unsigned *)(pm + 32 + 4 * q);
+
             u32x2 g4 = {pack2b<T>(acc[0], acc[1]), pack2b<T>(acc[2], acc[3])};
             unsigned g2 = pack2b<T>(acc[4], acc[5]);
             // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
