@@ -39,6 +39,10 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     {
         const char *e = getenv("UBD_DILCONV");
         h->use_wino = !(e && strcmp(e, "direct") == 0);
+        // test hook: pretend the device has fewer CUs, so that every persistent kernel walks many tiles per block even
+        // on the small shapes the CPU oracle can check (tests/test_gpu_persistent.py)
+        const char *c = getenv("UBD_TEST_NUM_CUS");
+        if (c && atoi(c) > 0) h->num_cus = atoi(c);
     }
     // Keras model.get_weights() order
     size_t off = 0;

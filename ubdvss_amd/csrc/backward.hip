@@ -787,7 +787,7 @@ static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train
     T->off_gb[0] = off;   off += big;
     T->off_gb[1] = off;   off += big;
     T->off_loss = off;    off += ubd_align_up(ubd_loss_workspace_bytes(h, n, H / 4, W / 4), 256);
-    T->off_partials = off; off += ubd_align_up((size_t)4 * h->num_cus * (217 * UBD_C) * sizeof(float), 256);
+    T->off_partials = off; off += ubd_align_up(((size_t)4 * h->num_cus + 8) * (217 * UBD_C) * sizeof(float), 256);
     T->total = off;
 }
 
@@ -895,6 +895,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH - 1) / W16_TH) * ((sw + tw - 1) / tw);
             int gw = h->num_cus * 3;
             if (gw > items) gw = (int)items;
+            gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             if (tw == 8)
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
             else
@@ -936,6 +937,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + WG_TH - 1) / WG_TH) * (((W4 + dd - 1) / dd + WG_TW - 1) / WG_TW);
             int gw = h->num_cus * 2;
             if (gw > items) gw = (int)items;
+            gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
                                grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);

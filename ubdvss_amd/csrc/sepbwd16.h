@@ -288,10 +288,13 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
     };
 
+    // GSRC 0 reads its G tile (= the staged D tile) throughout phase 2, so there the D tile cannot be prefetched under
+    // phase 2: it is fetched together with the X patch at the top of the tile
+    constexpr bool D_AHEAD = (GSRC != 0);
     int tile = blockIdx.x;
     if (tile < total) {
         const geom g0 = tile_geom(tile);
-        stage_dm(g0);
+        if constexpr (D_AHEAD) stage_dm(g0);
         if constexpr (CIN != UBD_C) load_x(g0);
     }
     for (; tile < total; tile += gridDim.x) {
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         const int img = g.img, oy0 = g.oy0, ox0 = g.ox0, ix0 = g.ix0, iy0 = g.iy0, dy0 = g.dy0, dx0 = g.dx0;
         const bool xborder = g.xborder, dborder = g.dborder;
         __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
+        if constexpr (!D_AHEAD) stage_dm(g);
         if constexpr (CIN == UBD_C)
             sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
         else {
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         __syncthreads();
         if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
             const geom gn = tile_geom(tile + gridDim.x);
-            stage_dm(gn);
+            if constexpr (D_AHEAD) stage_dm(gn);
             if constexpr (CIN != UBD_C) load_x(gn);
         }
 
