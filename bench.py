@@ -37,8 +37,8 @@ PEAK_HBM = 8000.0                         # GB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-train", action="store_true", help="skip the extra train-step measurement")
@@ -187,7 +187,7 @@ def main():
             m5.predict_on_device(x5)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps5 = max(5, min(args.steps, 20))
+        reps5 = max(5, min(args.steps, 200))
         e0.record()
         for _ in range(reps5):
             m5.predict_on_device(x5)
@@ -219,7 +219,7 @@ def main():
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        reps = max(5, min(args.steps, 20))
+        reps = max(5, min(args.steps, 200))
         net_ms = timed(lambda: model.predict_on_device(x), reps)
         logits = model.predict_on_device(x)
         post_ms = timed(lambda: model.postprocess_on_device(logits, runner.logit_threshold, 4, 5, cap=1024), reps)

@@ -91,7 +91,6 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
 {
     const TAUX *__restrict__ aux = (const TAUX *)aux_;
     __shared__ __attribute__((aligned(16))) float s_u[UBD_WINO_FRAG_FLOATS];       // 48 KiB
-    for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
     // products are issued as D = U^T . V^T (A operand = weights): D col = lane & 15 = tile, row = 4q + reg = channel, so
@@ -101,8 +100,6 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
         bA = *(const f32x4 *)((const float *)aux_ + 4 * q);
         if (q < 2) bB = *(const f32x4 *)((const float *)aux_ + 16 + 4 * q);
     }
-    __syncthreads();
-
     const int dm1 = d - 1;
     const int half_rows = ((h + 2 * d - 1) / (2 * d)) * d;       // rows y that pair with y + d
     const int half_cols = ((w + 2 * d - 1) / (2 * d)) * d;
@@ -123,7 +120,6 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
     // wave-uniform group index kept in SGPRs
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int g = g_begin + (int)(blockIdx.x >> 3) * 4 + wave_in_block;
-    if (g >= g_end) return;
     const int g_last = g_end - 1;
 
     // one row (a) of the 4 x 4 sample array of group gg: 4 samples x (4 + 2) channel registers
@@ -152,9 +148,13 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
     // Sample rows are fetched just in time so that at most three of the four are live (72 instead of 96 VGPRs ->
     // three waves per SIMD): rows 0 and 2 arrive before the group starts (issued under the previous group's last 48
     // MFMAs), row 1 is fetched under the MFMAs of transform row 0, row 3 under those of transform row 2.
+    // The first samples are requested before the block copies U into LDS: their latency hides behind the copy.
     wsamples D;
-    load_row(D, g, 0);
-    load_row(D, g, 2);
+    load_row(D, g < g_last ? g : g_last, 0);
+    load_row(D, g < g_last ? g : g_last, 2);
+    for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
+    __syncthreads();
+    if (g >= g_end) return;
     for (;;) {
         // ---- transform-domain rows a = 0..3
         f32x4 Y[2][2][2];      // [output row rr][output col c][nt]
