@@ -14,6 +14,17 @@ from ubdvss_amd import NetConfig, Model, ModelRunner, SegmapManager, synthetic
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["lds", "global"], autouse=True)
+def front_end(request, monkeypatch):
+    """Every case runs through both front ends: the one-launch LDS kernel (maps of <= 16384 pixels) and the multi-launch
+    global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    if request.param == "global":
+        monkeypatch.setenv("UBD_PP_GLOBAL", "1")
+    else:
+        monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
+    return request.param
+
+
 def _model(ncls=0, cin=3):
     cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1))
     return Model(cfg, seed=0)

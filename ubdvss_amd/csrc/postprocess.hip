@@ -342,7 +342,10 @@ __device__ __forceinline__ long long cross3(ipt o, ipt a, ipt b)
 // cv::minAreaRect + cv::boxPoints on a strictly convex polygon `hp` (n >= 3) ordered like
 // cv::convexHull(clockwise=true) -- same float32/float64 operation order as OpenCV 3.4
 // rotatingCalipers (rotcalipers.cpp), minAreaRect (rotcalipers.cpp) and RotatedRect::points.
-__device__ void min_area_box(const ipt *hp, int n, float *box8)
+// `etab` (optional): per-edge table [3][n] = (vx, vy, 1/length) of edge i -> i+1 computed beforehand with exactly the
+// arithmetic of `vec` below (the wave-cooperative kernel fills it one edge per lane, which takes the double-precision
+// square roots and divisions out of the serial calipers loop).
+__device__ void min_area_box(const ipt *hp, int n, float *box8, const float *etab = nullptr)
 {
     float cxr = 0.f, cyr = 0.f, bw = 0.f, bh = 0.f, angle = 0.f;
     if (n > 2) {
@@ -361,6 +364,7 @@ __device__ void min_area_box(const ipt *hp, int n, float *box8)
             if (py < bottom_y) bottom_y = py, bottom = i;
         }
         auto vec = [&](int i, float &vx, float &vy, float &inv) {
+            if (etab) { vx = etab[i]; vy = etab[n + i]; inv = etab[2 * n + i]; return; }
             const int j = (i + 1 < n) ? i + 1 : 0;
             const double dx = (float)hp[j].x - (float)hp[i].x;
             const double dy = (float)hp[j].y - (float)hp[i].y;
@@ -588,14 +592,15 @@ __device__ __forceinline__ void hull_finish(ipt *P, int nl, int nr, int &n_out)
     n_out = n;
 }
 
-__global__ __launch_bounds__(256) void pp_boxes_wave_kernel(int n, int h, int w, const int *__restrict__ nkept,
+__global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w, const int *__restrict__ nkept,
                                                             int *__restrict__ stage, const int *__restrict__ ymax,
                                                             const int *__restrict__ rows_ws, int cap, int scale)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int *rws = smem + wid * (6 * h + 4);
+    int *rws = smem + wid * (12 * h + 4);
     ipt *pts = (ipt *)(rws + 2 * h);
+    float *etab = (float *)(rws + 6 * h);                   // edge table of the hull: 3 x (<= 2h) floats
     for (int img = blockIdx.x; img < n; img += gridDim.x) {
         const int nk = min(nkept[img], cap);
         for (int k = wid; k < nk; k += nw) {
@@ -648,11 +653,23 @@ __global__ __launch_bounds__(256) void pp_boxes_wave_kernel(int n, int h, int w,
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
+            int nh = 0;
+            if (lane == 0) hull_finish(pts, cnt[0], cnt[1], nh);
+            nh = __builtin_amdgcn_readfirstlane(nh);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < nh; e += 64) {           // one hull edge per lane (same arithmetic as min_area_box::vec)
+                const int j = (e + 1 < nh) ? e + 1 : 0;
+                const double dx = (float)pts[j].x - (float)pts[e].x;
+                const double dy = (float)pts[j].y - (float)pts[e].y;
+                etab[e] = (float)dx; etab[nh + e] = (float)dy;
+                etab[2 * nh + e] = (float)(1. / sqrt(dx * dx + dy * dy));
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
-                int nh = 0;
-                hull_finish(pts, cnt[0], cnt[1], nh);
                 float box[8];
-                min_area_box(pts, nh, box);
+                min_area_box(pts, nh, box, etab);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
                 st[9] = 0;
@@ -716,6 +733,245 @@ __global__ __launch_bounds__(256) void pp_emit_kernel(int n, const int *__restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------ fused front end (LDS)
+// Maps of at most PP_LDS_MAX_HW pixels (128 x 128: the 512 x 512 input of the headline configuration): init, merge,
+// flatten, roots, owner, area, keep and extents of ONE image run in ONE block with the union-find forest, the
+// foreground bits and the owner map in LDS -- one launch instead of nine, no global atomics on the forest.  Every phase
+// is the corresponding kernel above restated on LDS arrays (same links, same external rule, same bit-quad area), so
+// the results are identical; the phases are separated by block barriers instead of kernel boundaries.
+#define PP_LDS_MAX_HW 16384
+#define PP_LDS_THREADS 1024
+
+// find with intermediate pointer jumping (as in ECL-CC): every node visited is re-pointed at its grandparent.  Parents
+// only ever move to smaller ancestors of the same tree, so concurrent finds and hooks stay correct and the final roots
+// (minimum node of each region) do not depend on the interleaving.
+__device__ __forceinline__ int uf_find_wg(int *lab, int a)
+{
+    int curr = __hip_atomic_load(&lab[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (curr != a) {
+        int prev = a, next;
+        while (curr > (next = __hip_atomic_load(&lab[curr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+            __hip_atomic_store(&lab[prev], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = curr;
+            curr = next;
+        }
+    }
+    return curr;
+}
+
+__device__ __forceinline__ void uf_union_wg(int *lab, int a, int b)
+{
+    for (;;) {
+        a = uf_find_wg(lab, a);
+        b = uf_find_wg(lab, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        const int old = __hip_atomic_fetch_min(&lab[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// LDS layout (bytes): label int32 [hw + 1] | owner int16 [hw] | rootslot int16 [hw] | fg uint8 [hw] | 2 counters.
+// After the owner phase the label array is dead and is reused as area2 [root_cap] | kept [root_cap].
+static size_t pp_front_lds_bytes(int hw)
+{
+    const size_t lab_ints = (size_t)hw + 1 > 2 * ((size_t)hw / 4 + 2) ? (size_t)hw + 1 : 2 * ((size_t)hw / 4 + 2);
+    return ubd_align_up(lab_ints * 4, 16) + (size_t)hw * 2 * 2 + ubd_align_up(hw, 16) + 16;
+}
+
+__global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
+    const float *__restrict__ logits, int k_out, float thr, int h, int w, float min_area, int cap, int n_cls, int root_cap,
+    int *__restrict__ binary_map, int *__restrict__ g_nroots, int *__restrict__ g_nkept, int *__restrict__ g_owner,
+    int *__restrict__ g_roots, int *__restrict__ g_kept, int *__restrict__ stage, int *__restrict__ ymax,
+    int *__restrict__ rows, float *__restrict__ vote)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int hw = h * w;
+    int *lab = smem;
+    const int lab_ints = hw + 1 > 2 * root_cap ? hw + 1 : 2 * root_cap;
+    short *own16 = (short *)((char *)smem + (((size_t)lab_ints * 4 + 15) & ~(size_t)15));
+    short *rs16 = own16 + hw;
+    unsigned char *m = (unsigned char *)(rs16 + hw);
+    int *ctr = (int *)(m + ((hw + 15) & ~15));               // [0] roots, [1] kept
+    int *area2 = lab, *kept = lab + root_cap;                  // aliases, valid after the owner phase
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const size_t pbase = (size_t)img * hw;
+    const int hw64 = (hw + 63) & ~63;
+
+    // ---- init (pp_init_kernel); the thread's logits are requested up front, PP_LDS_MAX_HW / PP_LDS_THREADS at most
+    if (tid < 2) ctr[tid] = 0;
+    constexpr int PER_THREAD = PP_LDS_MAX_HW / PP_LDS_THREADS;
+    float lg[PER_THREAD];
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; ++it) {
+        const int loc = tid + it * PP_LDS_THREADS;
+        lg[it] = loc < hw ? logits[(pbase + loc) * k_out] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; ++it) {
+        const int loc = tid + it * PP_LDS_THREADS;
+        if (loc - lane >= hw64) break;                                              // wave-uniform
+        const bool valid = loc < hw;
+        int f = 0, x = 0;
+        if (valid) {
+            x = loc % w;
+            f = lg[it] > thr ? 1 : 0;                                               // strict >, model_runner.py:124
+            m[loc] = (unsigned char)f;
+            if (binary_map) binary_map[pbase + loc] = f;
+        }
+        int fl = __shfl_up(f, 1, 64);
+        if (lane == 0 && valid && x > 0) fl = logits[(pbase + loc - 1) * k_out] > thr ? 1 : 0;
+        const bool same_left = valid && x > 0 && fl == f;
+        const unsigned long long breaks = __ballot(!same_left);
+        if (valid) {
+            const unsigned long long below = breaks & ((2ull << lane) - 1ull);
+            const int start_off = below ? lane - (63 - __clzll(below)) : lane + 1;
+            lab[loc + 1] = loc + 1 - start_off;
+            if (loc == 0) lab[0] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- merge (pp_merge_kernel)
+    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        const int y = loc / w, x = loc - y * w;
+        const int me = loc + 1;
+        const int c = m[loc];
+        const bool W = x > 0 && m[loc - 1] == c;
+        if (c) {
+            if (y > 0) {
+                const bool N = m[loc - w];
+                const bool NW = x > 0 && m[loc - w - 1];
+                if (N) {
+                    if (!(W && NW)) uf_union_wg(lab, me, me - w);
+                } else {
+                    if (NW && !W) uf_union_wg(lab, me, me - w - 1);
+                    const bool NE = x < w - 1 && m[loc - w + 1];
+                    const bool E = x < w - 1 && m[loc + 1];
+                    if (NE && !E) uf_union_wg(lab, me, me - w + 1);
+                }
+            }
+        } else {
+            if (y > 0 && !m[loc - w]) {
+                const bool NW = x > 0 && !m[loc - w - 1];
+                if (!(W && NW)) uf_union_wg(lab, me, me - w);
+            }
+            const bool row_edge = (y == 0 || y == h - 1) && !W;
+            if (row_edge || x == 0 || x == w - 1) uf_union_wg(lab, me, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- flatten (pp_flatten_kernel)
+    for (int node = tid; node <= hw; node += PP_LDS_THREADS) {
+        const int r = uf_find_wg(lab, node);
+        __hip_atomic_store(&lab[node], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+
+    // ---- roots (pp_roots_kernel)
+    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        if (!m[loc] || lab[loc + 1] != loc + 1) continue;
+        const bool external = (loc < w) || (lab[loc + 1 - w] == 0);
+        if (!external) continue;
+        const int idx = atomicAdd(&ctr[0], 1);
+        g_roots[(size_t)img * root_cap + idx] = loc;
+        rs16[loc] = (short)idx;
+    }
+    __syncthreads();
+
+    // ---- owner (pp_owner_kernel)
+    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        int node = lab[loc + 1];
+        int own = -1;
+        for (int guard = 0; guard < 4096; ++guard) {
+            if (node == 0) break;
+            const int r = node - 1;
+            if (r < w) { if (m[r]) own = rs16[r]; break; }
+            const int up = lab[r - w + 1];
+            if (m[r] && up == 0) { own = rs16[r]; break; }
+            node = up;
+        }
+        own16[loc] = (short)own;
+        if (g_owner) g_owner[pbase + loc] = own;
+    }
+    __syncthreads();
+    const int nroots = ctr[0];
+    for (int s = tid; s < nroots; s += PP_LDS_THREADS) area2[s] = 0;       // the forest is dead from here on
+    __syncthreads();
+
+    // ---- area (pp_area_kernel)
+    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        int key = -1, val = 0;
+        if (loc < hw) {
+            const int y = loc / w, x = loc - y * w;
+            if (x < w - 1 && y < h - 1) {
+                const int o0 = own16[loc], o1 = own16[loc + 1], o2 = own16[loc + w], o3 = own16[loc + w + 1];
+                const int o = max(max(o0, o1), max(o2, o3));
+                if (o >= 0) {
+                    const int cnt = (o0 == o) + (o1 == o) + (o2 == o) + (o3 == o);
+                    val = cnt == 4 ? 2 : (cnt == 3 ? 1 : 0);
+                    key = o;
+                }
+            }
+        }
+        if (val != 0) atomicAdd(&area2[key], val);                                  // LDS atomic
+    }
+    __syncthreads();
+
+    // ---- keep (pp_keep_kernel)
+    for (int s = tid; s < nroots; s += PP_LDS_THREADS) {
+        const double area = (double)area2[s] * 0.5;
+        int k = -1;
+        if (area > (double)min_area) {                                        // utils.py:55 (strict >)
+            k = atomicAdd(&ctr[1], 1);
+            if (k < cap) {
+                int *st = stage + ((size_t)img * cap + k) * STAGE_INTS;
+                st[0] = g_roots[(size_t)img * root_cap + s];
+                ymax[(size_t)img * cap + k] = 0;
+                if (n_cls > 0) {
+                    float *v = vote + ((size_t)img * cap + k) * (n_cls + 1);
+                    for (int c = 0; c <= n_cls; ++c) v[c] = 0.f;
+                }
+            } else {
+                k = -1;
+            }
+        }
+        kept[s] = k;
+        if (g_kept) g_kept[(size_t)img * root_cap + s] = k;
+    }
+    __syncthreads();
+    {
+        const int nk = min(ctr[1], cap);                                          // row extents of the kept objects: (+inf, -1)
+        int2 *r = (int2 *)(rows + (size_t)img * cap * (size_t)(6 * h));
+        for (int e = tid; e < nk * h; e += PP_LDS_THREADS) {
+            const int k = e / h, y = e - k * h;
+            r[(size_t)k * (3 * h) + y] = make_int2(0x7fffffff, -1);
+        }
+    }
+    __syncthreads();
+
+    // ---- extents (pp_extents_kernel)
+    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        const int o = own16[loc];
+        if (o < 0) continue;
+        const int y = loc / w, x = loc - y * w;
+        const bool left_end = (x == 0) || own16[loc - 1] != o;
+        const bool right_end = (x == w - 1) || own16[loc + 1] != o;
+        const bool bottom = (y == h - 1) || own16[loc + w] != o;
+        if (!(left_end || right_end || bottom)) continue;
+        const int k = kept[o];
+        if (k < 0) continue;
+        int *r = rows + ((size_t)img * cap + k) * (size_t)(6 * h);
+        if (left_end) atomicMin(&r[2 * y], x);
+        if (right_end) atomicMax(&r[2 * y + 1], x);
+        if (bottom) atomicMax(&ymax[(size_t)img * cap + k], y);
+    }
+    if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1]; }
+}
+
 // ------------------------------------------------------------------------------------ host
 extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int map_h, int map_w,
                                float logit_threshold, int scale, float min_area, int32_t *binary_map,
@@ -741,10 +997,21 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     float *vote = (float *)(ws + L.off_vote);
     const int hw = map_h * map_w;
     const long npix = (long)n * hw;
-    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));          // the two per-image counters
     int grid = (int)((npix + 255) / 256);
     const int gmax = hd->num_cus * 8;
     if (grid > gmax) grid = gmax;
+    const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;         // test hook: exercise the multi-launch front end
+    if (hw <= PP_LDS_MAX_HW && !force_global) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw), st, logits, hd->k_out, logit_threshold,
+                           map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
+                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote);
+    } else {
+    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));          // the two per-image counters
     hipLaunchKernelGGL(pp_init_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, logit_threshold, npix, hw, map_w, fg, label, binary_map);
     hipLaunchKernelGGL(pp_merge_kernel, dim3(grid), dim3(256), 0, st, fg, label, npix, map_h, map_w);
     hipLaunchKernelGGL(pp_flatten_kernel, dim3(grid), dim3(256), 0, st, label, n, hw);
@@ -753,10 +1020,14 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     hipLaunchKernelGGL(pp_area_kernel, dim3(grid), dim3(256), 0, st, owner, npix, map_h, map_w, area2, L.root_cap);
     hipLaunchKernelGGL(pp_keep_kernel, dim3(n), dim3(256), 0, st, n, map_h, nroots, roots, area2, L.root_cap, min_area, nkept, kept, stage, ymax, rows, cap, vote, n_cls);
     hipLaunchKernelGGL(pp_extents_kernel, dim3(grid), dim3(256), 0, st, owner, kept, npix, map_h, map_w, L.root_cap, cap, rows, ymax);
+    }
     {
-        const size_t lds = (size_t)4 * (6 * map_h + 4) * sizeof(int);
+        // one wave per kept object; 8 waves per image block, fewer while their LDS does not fit
+        int waves = 8;
+        size_t lds = (size_t)waves * (12 * map_h + 4) * sizeof(int);
+        while (lds > 64 * 1024 && waves > 1) { waves /= 2; lds /= 2; }
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(256), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(64 * waves), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
         } else {                                       // very tall maps: serial per-object fallback in global memory
             const long total = (long)n * cap;
             int bgrid = (int)((total + 63) / 64);

@@ -60,8 +60,9 @@ class ModelRunner:
             slot = {"logits": torch.empty((n, hh // 4, ww // 4, model.k_out), dtype=torch.float32, device=model.device),
                     "out": model.alloc_postprocess_outputs(n, hh // 4, ww // 4, self._cap), "done": None}
             self._slots[key] = slot
-        if slot["done"] is not None:
+        if slot["done"] is not None and not slot["done"].query():
             main.wait_event(slot["done"])               # the previous postprocess of this slot still reads its logits
+                                                        # (normally long finished: no barrier packet in the forward stream)
         logits = model.predict_on_device(images, out=slot["logits"])
         fwd_done = torch.cuda.Event()
         fwd_done.record(main)
