@@ -11,6 +11,8 @@ for f in api forward fwd16 wino postprocess loss backward train; do
   extra=""
   # OpenCV-exact float geometry: no FMA contraction in postprocess
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
+  # no SLP packing of adjacent fp32 adds into v_pk_add_f32: beside MFMAs the packed form issues slower than two scalar adds
+  [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
   stale=0
   for dep in $f.hip *.h ../../include/ubd.h; do [ "$dep" -nt _obj/$f.o ] && stale=1; done
   if [ ! -f _obj/$f.o ] || [ $stale = 1 ]; then
