@@ -65,7 +65,7 @@ struct ubd_fwd_layout {
 // ---- cross-file internals ------------------------------------------------------------------
 void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L);
 int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
-                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st);
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference = false);
 void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
                         const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu);
@@ -74,7 +74,7 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
 extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,
-                             const float *in, float *out, int n, int H4, int W4, hipStream_t st);
+                             const float *in, float *out, int n, int H4, int W4, hipStream_t st, const float *head = nullptr);
 void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st);
 size_t ubd_forward16_workspace_bytes(int n, int H, int W);
 int ubd_pack16_workspace(ubd_handle *h, const float *params, char *ws, size_t ws_bytes, hipStream_t st);

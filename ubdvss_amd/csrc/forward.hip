@@ -740,7 +740,7 @@ extern "C" int ubd_dilated_layer(ubd_handle *h, const float *params, int layer, 
 
 // Runs L1..L9 + head.  acts[0..8] receive the hidden activations (L1..L9 outputs).
 int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
-                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st)
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference)
 {
     UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_forward: only UBD_F32 activations are implemented in this build");
     const bool prepacked = (in_dtype & UBD_IN_PREPACKED) != 0;
@@ -770,8 +770,16 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     float *cur = (float *)(ws + L.off_acts[0]);
     launch_sep<UBD_C, 2>(h, a2, 0, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
 
+    // inference with a single output channel: the head rides in the epilogue of L9 and L9's activation is never written
+    const bool fuse_head = inference && h->use_wino && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
         float *nxt = (float *)(ws + L.off_acts[k + 1]);
+        if (fuse_head && k == UBD_NUM_DIL - 1) {
+            ubd_launch_dilconv_wino(h, 2, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k], UBD_F32,
+                                    UBD_DILATIONS[k], cur, logits, n, H4, W4, st, params + h->off_head_k);
+            UBD_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         launch_dil(h, params, wfrag, k, cur, nxt, n, H4, W4, st);
         cur = nxt;
     }
@@ -796,5 +804,5 @@ extern "C" int ubd_forward(ubd_handle *h, const float *params, const void *image
     ubd_fwd_layout L;
     ubd_fwd_layout_compute(h, n, height, width, 0, &L);
     UBD_REQUIRE(workspace_bytes >= L.total, "ubd_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
-    return ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, L, (hipStream_t)stream);
+    return ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, L, (hipStream_t)stream, true);
 }

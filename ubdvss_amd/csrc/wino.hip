@@ -94,10 +94,10 @@ struct wsamples {
 
 // TAUX: element type of the ReLU-mask source (EPI 1): fp32 or a 16-bit activation type
 template <int EPI, typename TAUX>
-__global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
+__global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               const float *__restrict__ ufrag,
                                                               const void *__restrict__ aux_, int n, int h, int w, int d,
-                                                              int log2d, unsigned in_bytes)
+                                                              int log2d, unsigned in_bytes, const float *__restrict__ head)
 {
     const TAUX *__restrict__ aux = (const TAUX *)aux_;
     __shared__ __attribute__((aligned(16))) float s_u[UBD_WINO_FRAG_FLOATS];       // 48 KiB
@@ -106,9 +106,18 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
     // products are issued as D = U^T . V^T (A operand = weights): D col = lane & 15 = tile, row = 4q + reg = channel, so
     // a lane ends up with four consecutive channels (4q.. of N-tile 0, 16+4q.. of N-tile 1 for q < 2) of its own tile
     f32x4 bA = {0.f, 0.f, 0.f, 0.f}, bB = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == 0) {
+    if constexpr (EPI != 1) {
         bA = *(const f32x4 *)((const float *)aux_ + 4 * q);
         if (q < 2) bB = *(const f32x4 *)((const float *)aux_ + 16 + 4 * q);
+    }
+    // EPI 2 (last hidden layer of an inference pass with one output channel): the 1x1 head (net.py:308-311) is applied
+    // to the lane's channels in the epilogue and the activation itself is never written; head = 24 weights + bias
+    f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if constexpr (EPI == 2) {
+        hA = *(const f32x4 *)(head + 4 * q);
+        if (q < 2) hB = *(const f32x4 *)(head + 16 + 4 * q);
+        hbias = head[UBD_C];
     }
     const int dm1 = d - 1;
     const int half_rows = ((h + 2 * d - 1) / (2 * d)) * d;       // rows y that pair with y + d
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
     const int stride = nblk_x * 4;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)in_bytes, 0x00020000);   // output: same shape
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)(EPI == 2 ? in_bytes / UBD_C : in_bytes), 0x00020000);   // output: same shape (EPI 2: one logit per pixel)
     const unsigned oob = in_bytes;
 
     // wave-uniform group index kept in SGPRs
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
                     const unsigned o0 = ok ? e * 4u : oob;
                     const unsigned o1 = (ok && q < 2) ? (e + 16u) * 4u : oob;
                     f32x4 v0, v1;
-                    if constexpr (EPI == 0) {
+                    if constexpr (EPI != 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(Y[rr][c][0][r] + bA[r], 0.f); v1[r] = fmaxf(Y[rr][c][1][r] + bB[r], 0.f); }
                     } else {
@@ -267,8 +276,20 @@ __global__ __launch_bounds__(256, (EPI == 0) ? 3 : 2) void dilconv_wino_kernel(c
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v0[r] = mk0[r] > 0.f ? Y[rr][c][0][r] : 0.f; v1[r] = mk1[r] > 0.f ? Y[rr][c][1][r] : 0.f; }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)o0, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)o1, 0, 0);
+                    if constexpr (EPI == 2) {
+                        float part = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part = fmaf(v0[r], hA[r], part);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part = fmaf(v1[r], hB[r], part);      // hB = 0 for q >= 2
+                        part += __shfl_xor(part, 16, 64);                                   // sum over the four channel quarters
+                        part += __shfl_xor(part, 32, 64);
+                        const unsigned pix = (unsigned)(img * h + yo) * (unsigned)w + (unsigned)xo;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part + hbias), yrsrc, (int)((ok && q == 0) ? pix * 4u : oob), 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)o0, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)o1, 0, 0);
+                    }
                 }
             }
         }
@@ -282,20 +303,22 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // frag: this layer's UBD_WINO_FRAG_FLOATS packed floats; aux: bias (epi 0) or mask source (epi 1)
 // aux_dtype: element type of `aux` for epi 1 (UBD_F32 / UBD_BF16 / UBD_F16); epi 0 ignores it (bias is fp32)
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,
-                             const float *in, float *out, int n, int H4, int W4, hipStream_t st)
+                             const float *in, float *out, int n, int H4, int W4, hipStream_t st, const float *head)
 {
     const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
     const int d = dilation;
     const long half_rows = ((H4 + 2 * d - 1) / (2 * d)) * d, half_cols = ((W4 + 2 * d - 1) / (2 * d)) * d;
     const long groups = (long)n * half_rows * ((half_cols + 15) / 16);
-    int grid = ubd_grid_for(groups, h->num_cus, 4, epi == 0 ? 3 : 2);     // forward: 150 VGPRs, three waves per SIMD
+    int grid = ubd_grid_for(groups, h->num_cus, 4, epi != 1 ? 3 : 2);     // forward: 150 VGPRs, three waves per SIMD
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
-        hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
+    else if (epi == 2)       // out = logits (n, H4, W4, 1); head = 24 weights followed by the bias
+        hipLaunchKernelGGL((dilconv_wino_kernel<2, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, head);
     else if (aux_dtype == UBD_F32)
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
     else if (aux_dtype == UBD_BF16)
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, __bf16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, __bf16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
     else
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, _Float16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, _Float16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
 }
