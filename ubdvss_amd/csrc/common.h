@@ -87,4 +87,4 @@ void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, 
 struct ubd_fwd16_layout { size_t off_wfrag32, off_wfrag16, off_a1, off_a2, off_acts[7], total; };
 void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layout *L);
 int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
-                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st);
+                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st, bool inference = false);

@@ -467,9 +467,19 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
 #pragma unroll
     for (int c = 0; c < 7; ++c) { wr[c][0] = wfrag[(c * 2 + 0) * 64 + lane]; wr[c][1] = wfrag[(c * 2 + 1) * 64 + lane]; }
     f32x4 bA = {0.f, 0.f, 0.f, 0.f}, bB = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == 0) {
+    if constexpr (EPI != 1) {
         bA = *(const f32x4 *)(bias + 4 * q);
         if (q < 2) bB = *(const f32x4 *)(bias + 16 + 4 * q);
+    }
+    // EPI 2 (last hidden layer of an inference pass with one output channel): `mask` carries the fp32 head (24 weights +
+    // bias, net.py:308-311), `y` the fp32 logits; the activation is rounded to T as if it had been stored, never written
+    f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if constexpr (EPI == 2) {
+        const float *head = (const float *)mask;
+        hA = *(const f32x4 *)(head + 4 * q);
+        if (q < 2) hB = *(const f32x4 *)(head + 16 + 4 * q);
+        hbias = head[UBD_C];
     }
     // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c+q)/3, channel group ((4c+q)%3)*8.
     // delta[c]: byte offset of that tap / channel group relative to the centre pixel inside ONE image (the loads go through
@@ -524,9 +534,20 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         }
         const int x0 = tc.xt * 16;
         const int npx = w - x0 < 16 ? w - x0 : 16;
-        u32x2 m0 = {0u, 0u}, m1 = {0u, 0u};
-        if constexpr (EPI == 1) { m0 = a.m0; m1 = a.m1; }
-        store_tile16_t<T, EPI>(y, (size_t)tc.rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
+        if constexpr (EPI == 2) {
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(round16<T>(fmaxf(acc0[r] + bA[r], 0.f)), hA[r], part);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(round16<T>(fmaxf(acc1[r] + bB[r], 0.f)), hB[r], part);   // hB = 0 for q >= 2
+            part += __shfl_xor(part, 16, 64);                           // sum over the four channel quarters
+            part += __shfl_xor(part, 32, 64);
+            if (q == 0 && i < npx) ((float *)y)[(size_t)tc.rowid * w + x0 + i] = part + hbias;
+        } else {
+            u32x2 m0 = {0u, 0u}, m1 = {0u, 0u};
+            if constexpr (EPI == 1) { m0 = a.m0; m1 = a.m1; }
+            store_tile16_t<T, EPI>(y, (size_t)tc.rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
+        }
     };
     a16_frags A0, A1;
     dil16_tile T0, T1;
@@ -638,6 +659,9 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h);
+    else if (epi == 2)      // out = fp32 logits (n, H4, W4, 1), mask = fp32 head (24 weights + bias)
+        hipLaunchKernelGGL((dilconv16_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h);
     else
         hipLaunchKernelGGL((dilconv16_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h);
@@ -662,7 +686,7 @@ void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, 
 
 template <typename T>
 static int forward16_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n,
-                          int H, int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
+                          int H, int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st, bool inference)
 {
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
     float *wfrag = (float *)(ws + L.off_wfrag32);
@@ -690,8 +714,15 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     launch_sep16<UBD_C, 1, 2, T>(h, a1, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
     unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
     launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    // inference with a single output channel: the head rides in the epilogue of L9 and L9's activation is never written
+    const bool fuse_head = inference && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
         unsigned short *nxt = (unsigned short *)(ws + L.off_acts[k + 1]);
+        if (fuse_head && k == UBD_NUM_DIL - 1) {
+            ubd_launch_dilconv16(h, 2, wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32, params + h->off_dil_b[k], params + h->off_head_k, UBD_DILATIONS[k], cur, logits, n, H4, W4, st);
+            UBD_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         ubd_launch_dilconv16(h, 0, wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32, params + h->off_dil_b[k], nullptr, UBD_DILATIONS[k], cur, nxt, n, H4, W4, st);
         cur = nxt;
     }
@@ -704,15 +735,15 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
 }
 
 int ubd_forward16_layout(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
-                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st)
+                         int W, float *logits, char *ws, const ubd_fwd16_layout &L, hipStream_t st, bool inference)
 {
     UBD_REQUIRE((size_t)n * (H / 4) * (W / 4) * UBD_C * 2 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
     // dilconv16_kernel: per-image 30-bit byte offsets and magic-number division of the tile index
     UBD_REQUIRE((size_t)(H / 4) * (W / 4) * UBD_C * 2 < (1ull << 30), "ubd_forward: image too large for the 16-bit path (%d x %d)", H, W);
     UBD_REQUIRE((unsigned long long)n * (H / 4) * ((W / 4 + 15) / 16) * ((W / 4 + 15) / 16) < (1ull << 32) &&
                 (unsigned long long)n * (H / 4) * (H / 4) < (1ull << 32), "ubd_forward: batch too large for the 16-bit path; split the batch");
-    if (h->cfg.dtype == UBD_BF16) return forward16_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
-    return forward16_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
+    if (h->cfg.dtype == UBD_BF16) return forward16_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st, inference);
+    return forward16_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st, inference);
 }
 
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
@@ -721,5 +752,5 @@ int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in
     UBD_REQUIRE(ws_bytes >= ubd_forward16_workspace_bytes(n, H, W), "ubd_forward: workspace too small for the 16-bit path");
     ubd_fwd16_layout L;
     ubd_fwd16_layout_compute(n, H, W, 0, &L);
-    return ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st);
+    return ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, H, W, logits, ws, L, st, true);
 }
