@@ -188,29 +188,30 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
     __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
     for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
     __syncthreads();
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    // one 4-channel chunk per thread: the 16-byte stores (and the activation loads) of a wave are contiguous
+    f32x4 *pg = (f32x4 *)g;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < npix * 6; t += (long)gridDim.x * blockDim.x) {
+        const long p = t / 6;
+        const int c4 = (int)(t - p * 6);
         float dl[UBD_MAX_CLASSES + 1];
         for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
-        f32x4 *pg = (f32x4 *)(g + p * UBD_C);
-        float av[UBD_C];
+        float av[4];
+        if constexpr (sizeof(TX) == 4) {
+            const f32x4 a = ((const f32x4 *)a9)[t];
+            av[0] = a[0]; av[1] = a[1]; av[2] = a[2]; av[3] = a[3];
+        } else {
+            const TX *a = (const TX *)a9 + t * 4;
 #pragma unroll
-        for (int c6 = 0; c6 < 4; ++c6) {
-            float t6[6];
-            ld_act6<TX>(a9, (size_t)p * UBD_C + 6 * c6, t6);
-#pragma unroll
-            for (int e = 0; e < 6; ++e) av[6 * c6 + e] = t6[e];
+            for (int e = 0; e < 4; ++e) av[e] = (float)a[e];
         }
+        f32x4 o;
 #pragma unroll
-        for (int c4 = 0; c4 < 6; ++c4) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float acc = 0.f;
-                for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[(c4 * 4 + e) * k_out + k], acc);
-                o[e] = av[c4 * 4 + e] > 0.f ? acc : 0.f;
-            }
-            pg[c4] = o;
+        for (int e = 0; e < 4; ++e) {
+            float acc = 0.f;
+            for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[(c4 * 4 + e) * k_out + k], acc);
+            o[e] = av[e] > 0.f ? acc : 0.f;
         }
+        pg[t] = o;
     }
 }
 

@@ -25,30 +25,30 @@ __global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict_
     __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
     for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
     __syncthreads();
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    // one 16-byte chunk (8 channels of a pixel) per thread: loads and stores of a wave are contiguous
+    const u32x4 *pa = (const u32x4 *)a9;
+    u32x4 *pg = (u32x4 *)g;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < npix * 3; t += (long)gridDim.x * blockDim.x) {
+        const long p = t / 3;
+        const int c8 = (int)(t - p * 3);
         float dl[UBD_MAX_CLASSES + 1];
         for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
-        const u32x4 *pa = (const u32x4 *)(a9 + p * UBD_C);
-        u32x4 *pg = (u32x4 *)(g + p * UBD_C);
+        const u32x4 av = pa[t];
+        u32x4 o;
 #pragma unroll
-        for (int c8 = 0; c8 < 3; ++c8) {
-            const u32x4 av = pa[c8];
-            u32x4 o;
+        for (int e = 0; e < 4; ++e) {
+            unsigned short hbits[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short hbits[2];
-#pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int c = c8 * 8 + 2 * e + hlf;
-                    float acc = 0.f;
-                    for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[c * k_out + k], acc);
-                    const short abits = (short)(hlf ? (av[e] >> 16) : (av[e] & 0xFFFFu));
-                    hbits[hlf] = abits > 0 ? __builtin_bit_cast(unsigned short, (T)acc) : (unsigned short)0;
-                }
-                o[e] = (unsigned)hbits[0] | ((unsigned)hbits[1] << 16);
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int c = c8 * 8 + 2 * e + hlf;
+                float acc = 0.f;
+                for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[c * k_out + k], acc);
+                const short abits = (short)(hlf ? (av[e] >> 16) : (av[e] & 0xFFFFu));
+                hbits[hlf] = abits > 0 ? __builtin_bit_cast(unsigned short, (T)acc) : (unsigned short)0;
             }
-            pg[c8] = o;
+            o[e] = (unsigned)hbits[0] | ((unsigned)hbits[1] << 16);
         }
+        pg[t] = o;
     }
 }
 

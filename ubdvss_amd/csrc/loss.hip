@@ -77,13 +77,16 @@ __device__ __forceinline__ double block_reduce_sum(double v, double *sh)
 }
 
 // ---- pass 1: per-pixel BCE, batch sums, first-level histogram ------------------------------
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_stats_kernel(const float *__restrict__ logits, int k_out,
+// 1024 threads per block: with one block per CU (LOSS_MAX_BLOCKS) that is four waves per SIMD to hide the load -> exp/log ->
+// LDS-atomic chain of a pixel, at the same number of block-level global atomics
+#define LOSS_STATS_BLOCK 1024
+__global__ __launch_bounds__(LOSS_STATS_BLOCK) void loss_stats_kernel(const float *__restrict__ logits, int k_out,
                                                                 const int *__restrict__ y_true, long npix,
                                                                 loss_hdr *hdr, unsigned *__restrict__ hist,
                                                                 float *__restrict__ ce_buf)
 {
     __shared__ unsigned s_hist[2048];
-    __shared__ double s_red[LOSS_BLOCK / 64];
+    __shared__ double s_red[LOSS_STATS_BLOCK / 64];
     for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
     double sp = 0, sn = 0;
@@ -368,7 +371,7 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     long chunk = (npix + grid - 1) / grid;
     chunk = (chunk + LOSS_BLOCK - 1) / LOSS_BLOCK * LOSS_BLOCK;
     const int cgrid = (int)((npix + chunk - 1) / chunk);
-    hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce);
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_STATS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce);
     hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist, hist + 2048, 1);
     hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, hist + 4096, 2);
     hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, hist + 4096, blockties);
