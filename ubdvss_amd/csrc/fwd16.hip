@@ -60,6 +60,21 @@ template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float 
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
 }
 template <typename T> __device__ __forceinline__ float round16(float v) { return (float)(T)v; }
+// ReLU of two packed 16-bit floats: negative values have negative int16 patterns (v_pk_max_i16 with 0; -0 becomes +0)
+__device__ __forceinline__ unsigned relu_pk16(unsigned v)
+{
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+// 0xFFFF per half whose 16-bit pattern is a positive short, else 0: max(m, 0) -> min(., 1) -> * 0xFFFF (three packed ops)
+__device__ __forceinline__ unsigned mask_pk16(unsigned m)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = {1, 1}, ones = {0xFFFF, 0xFFFF};
+    const u16x2 p = __builtin_bit_cast(u16x2, relu_pk16(m));
+    return __builtin_bit_cast(unsigned, (u16x2)(__builtin_elementwise_min(p, one) * ones));
+}
 
 // ------------------------------------------------------------------------------------ pack
 // 16-bit B fragments of the dilated layers: lane (n = lane&15, q = lane>>4), chunk c, element j:
@@ -101,22 +116,18 @@ __device__ __forceinline__ void store_tile16_t(unsigned short *__restrict__ y, s
                                                f32x4 acc0, f32x4 acc1, f32x4 bA, f32x4 bB, u32x2 m0, u32x2 m1)
 {
     const int i = lane & 15, q = lane >> 4;
-    u32x2 o0, o1;
+    // EPI 0: bias added last (the order the oracle uses); ReLU is taken on the packed 16-bit values: a negative float
+    // has a negative 16-bit pattern, v_pk_max_i16 with 0 clears it (and turns -0 into +0), two channels per instruction.
+    if constexpr (EPI == 0) { acc0 += bA; acc1 += bB; }
+    unsigned w00 = pack2<T>(acc0[0], acc0[1]), w01 = pack2<T>(acc0[2], acc0[3]);
+    unsigned w10 = pack2<T>(acc1[0], acc1[1]), w11 = pack2<T>(acc1[2], acc1[3]);
     if constexpr (EPI == 0) {
-        o0[0] = pack2<T>(fmaxf(acc0[0] + bA[0], 0.f), fmaxf(acc0[1] + bA[1], 0.f));
-        o0[1] = pack2<T>(fmaxf(acc0[2] + bA[2], 0.f), fmaxf(acc0[3] + bA[3], 0.f));
-        o1[0] = pack2<T>(fmaxf(acc1[0] + bB[0], 0.f), fmaxf(acc1[1] + bB[1], 0.f));
-        o1[1] = pack2<T>(fmaxf(acc1[2] + bB[2], 0.f), fmaxf(acc1[3] + bB[3], 0.f));
+        w00 = relu_pk16(w00); w01 = relu_pk16(w01); w10 = relu_pk16(w10); w11 = relu_pk16(w11);
     } else {
         // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
-        o0[0] = pack2<T>(acc0[0], acc0[1]); o0[1] = pack2<T>(acc0[2], acc0[3]);
-        o1[0] = pack2<T>(acc1[0], acc1[1]); o1[1] = pack2<T>(acc1[2], acc1[3]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            o0[e] &= (((short)(m0[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)m0[e] >> 16) > 0) ? 0xFFFF0000u : 0u);
-            o1[e] &= (((short)(m1[e] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)m1[e] >> 16) > 0) ? 0xFFFF0000u : 0u);
-        }
+        w00 &= mask_pk16(m0[0]); w01 &= mask_pk16(m0[1]); w10 &= mask_pk16(m1[0]); w11 &= mask_pk16(m1[1]);
     }
+    const u32x2 o0 = {w00, w01}, o1 = {w10, w11};
     const unsigned long long rp = (unsigned long long)(y + first_pixel * UBD_C);
     const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
     const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
@@ -387,8 +398,8 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
                 }
                 if (yy >= 2) {                               // output row yy - 2 is complete
                     const int o = yy - 2, oy = oy0 + rb + o;
-                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                     const u32x4 av = {pack2<T>(dwv[o][0], dwv[o][1]), pack2<T>(dwv[o][2], dwv[o][3]), pack2<T>(dwv[o][4], dwv[o][5]), 0u};
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                     const f32x4 acc0 = h16<T>::mfma(pwb[0], av, z4);     // weights as the A operand: D = [channel][pixel]
                     const f32x4 acc1 = h16<T>::mfma(pwb[1], av, z4);
                     int npx = OW - ox0 < 16 ? OW - ox0 : 16;
