@@ -32,6 +32,7 @@ BYTES_PER_IMAGE_FP32 = 50.40e6            # layer-wise compulsor
 FLOP_PER_IMAGE = 1.1627e9
 PEAK_MFMA_F32 = 157.3                     # TFLOP/s, MI355X_MICROARCH.md (f32-input MFMA = vector peak)
 PEAK_HBM = 8000.0                         # GB/s
+SETTLE_STEPS = 300                        # untimed steps (settle + warm-up) before any timed region: clock ramp after idle
 
 
 def parse():
@@ -123,6 +124,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The chip needs a few hundred back-to-back steps after an idle gap before its clocks settle (20 steps: 0.54-0.60 ms,
+    # 500: 0.50 ms per step): untimed settle steps in front of the W warm-up steps keep `value` independent
+    # of the K / W the caller picks.  Reported as "clock_settle_steps".
+    settle = max(0, SETTLE_STEPS - args.warmup)
+    for _ in range(settle):
+        step()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -149,7 +156,7 @@ def main():
         tmodel = Model(cfg, dtype=dtype, seed=1)
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
-        for _ in range(max(1, args.warmup)):
+        for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
             trainer.train_step_on_device(tx, ty)
         sync_all()
         t0 = time.perf_counter()
@@ -272,6 +279,7 @@ def main():
             "metric": "images/sec (512x512) fwd+CCL", "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup),
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
