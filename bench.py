@@ -148,12 +148,13 @@ def main():
     # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), batch/GPU = --train-batch:
     #      configs[2] / configs[3] name bf16 activations (fp32 master weights, fp32 accumulation); the fp32
     #      variant is measured beside it
-    def time_train(dtype):
+    def time_train(dtype, n_cls=0):
         tb = args.train_batch
-        tlabels = synthetic.rectangle_maps(30 + rank, tb, SIDE // 4, SIDE // 4)
+        tlabels = synthetic.rectangle_maps(30 + rank, tb, SIDE // 4, SIDE // 4, n_classes=n_cls)
         tx = torch.from_numpy(synthetic.textured_images(31 + rank, tlabels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
         ty = torch.from_numpy(tlabels).to(dev)
-        tmodel = Model(cfg, dtype=dtype, seed=1)
+        tcfg = cfg if n_cls == 0 else NetConfig(class_names=[f"class{i}" for i in range(n_cls)], grey=False)
+        tmodel = Model(tcfg, dtype=dtype, seed=1)
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
@@ -169,10 +170,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tel = float(t.item())
         bpe = 4.0 if dtype == "float32" else 2.0
-        train_bytes_per_image = (3 * 12599296 - SIDE * SIDE * C_IN) * bpe       # E_train elements
+        e_fwd = SIDE * SIDE * (C_IN + 45 + (1 + n_cls) / 16.0)                    # E_fwd elements per image
+        train_bytes_per_image = (3 * e_fwd - SIDE * SIDE * C_IN) * bpe             # E_train = 3 E_fwd - H W C_in
         res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
                "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb,
-               "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype],
+               "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
                "parallelism": f"dp{world}: per-replica loss, one flat-gradient all-reduce (RCCL) per step" if world > 1 else "single GPU",
                "loss_last": round(float(trainer.loss[0]), 5),
                "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
@@ -180,9 +182,10 @@ def main():
         torch.cuda.empty_cache()
         return res
 
-    train = train_f32 = None
+    train = train_f32 = train_cls8 = None
     if not args.no_train:
         train = time_train("bfloat16")
+        train_cls8 = time_train("bfloat16", n_cls=8)       # configs[2], second run: 8 classes (labels 1..8), detection + classification loss
         train_f32 = time_train("float32")
 
     # ---- extra: configs[4], batch 8 of 1024x1024x3, fp16 activations, forward only ("HBM-bound roofline run")
@@ -283,7 +286,7 @@ def main():
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},
