@@ -245,13 +245,14 @@ __global__ __launch_bounds__(1024) void loss_tiescan_kernel(unsigned *blockties,
 }
 
 // ---- gradient + hard-negative / classification sums --------------------------------------------
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
+#define LOSS_GRAD_BLOCK 1024       // as loss_stats: four waves per SIMD on the one block a CU gets
+__global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
                                                                const int *__restrict__ y_true, long npix, long chunk,
                                                                loss_hdr *hdr, const unsigned *__restrict__ blockties,
                                                                const float *__restrict__ ce_buf, float *__restrict__ dlogits)
 {
-    __shared__ double s_red[LOSS_BLOCK / 64];
-    __shared__ unsigned s_wave_ties[LOSS_BLOCK / 64];
+    __shared__ double s_red[LOSS_GRAD_BLOCK / 64];
+    __shared__ unsigned s_wave_ties[LOSS_GRAD_BLOCK / 64];
     const unsigned T = hdr->T, need_eq = hdr->need_eq;
     const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
     const long n_neg_l = npix - hdr->n_pos;
@@ -376,7 +377,7 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, hist + 4096, 2);
     hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, hist + 4096, blockties);
     hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix, k_out - 1, loss);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
