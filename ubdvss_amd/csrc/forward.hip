@@ -732,7 +732,7 @@ extern "C" int ubd_dilated_layer(ubd_handle *h, const float *params, int layer, 
     UBD_REQUIRE(h && params && in && out && workspace, "ubd_dilated_layer: null argument");
     UBD_REQUIRE(layer >= 0 && layer < UBD_NUM_DIL, "ubd_dilated_layer: layer %d out of range", layer);
     UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_dilated_layer: only UBD_F32 in this build");
-    UBD_REQUIRE((size_t)n * map_h * map_w * UBD_C * 4 < 0xFFFFFFFFull, "ubd_dilated_layer: tensor too large");
+    UBD_REQUIRE((size_t)n * map_h * map_w * UBD_C * 4 <= (1ull << 30), "ubd_dilated_layer: tensor too large (activation bytes must not exceed 2^30)");
     launch_dil(h, params, (const float *)workspace, layer, (const float *)in, (float *)out, n, map_h, map_w, (hipStream_t)stream);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
@@ -749,7 +749,9 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_forward: bad in_dtype %d", in_dtype);
     UBD_REQUIRE(!(in_dtype == UBD_IN_U8 && h->cfg.c_in == UBD_C), "ubd_forward: u8 input needs c_in 1 or 3");
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
-    UBD_REQUIRE((size_t)n * H4 * W4 * UBD_C * 4 < 0xFFFFFFFFull, "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
+    // the Winograd kernel marks out-of-image rows / columns with 2^30 offset terms: a quarter-resolution activation must
+    // stay within 2^30 bytes (11.2 M pixels, e.g. 682 images of 512 x 512)
+    UBD_REQUIRE((size_t)n * H4 * W4 * UBD_C * 4 <= (1ull << 30), "ubd_forward: batch too large for 32-bit buffer offsets; split the batch");
     float *wfrag = (float *)(ws + L.off_wfrag);
     float *a1 = (float *)(ws + L.off_a1), *a2 = (float *)(ws + L.off_a2);
 

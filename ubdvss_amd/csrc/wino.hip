@@ -141,24 +141,42 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
     int g = g_begin + (int)(blockIdx.x >> 3) * 4 + wave_in_block;
     const int g_last = g_end - 1;
 
-    // one row (a) of the 4 x 4 sample array of group gg: 4 samples x (4 + 2) channel registers
-    auto load_row = [&](wsamples &D, int gg, int a) {
+    // Offsets are separable: a wave-uniform row term (SGPR) plus a per-lane column term that already holds the lane's
+    // channel offset.  A term outside the image is 2^30 (host: tensor bytes <= 2^30), so the sum of any invalid pair is
+    // out of range for the buffer descriptor and the load returns the zero padding: one v_add per load, no compares or
+    // selects in the sample loop.
+    const unsigned BIG = 0x40000000u;
+    unsigned cq4[4];                                          // column terms of the group whose rows are being fetched
+    const unsigned dq2 = 64u - 8u * q;                        // b64 load (channels 16 + 2q, 17 + 2q) relative to the b128 load (4q ..)
+    auto tile_col = [&](int gg) {
         const int gx = (int)((unsigned)gg % (unsigned)groups_x);
-        const int rs = (int)((unsigned)gg / (unsigned)groups_x);
-        const int s = (int)((unsigned)rs % (unsigned)half_rows);
-        const int img = (int)((unsigned)rs / (unsigned)half_rows);
-        const int y0 = ((s >> log2d) << (log2d + 1)) + (s & dm1);
         const int tcol = gx * 16 + i;
-        const int xj = ((tcol >> log2d) << (log2d + 1)) + (tcol & dm1);   // this lane's tile column
-        const int iy = y0 + (a - 1) * d;
-        const bool rok = (iy >= 0) && (iy < h);
+        return ((tcol >> log2d) << (log2d + 1)) + (tcol & dm1);           // this lane's tile column (pixel x of output (., 0))
+    };
+    auto set_cols = [&](int gg) {
+        const int xj = tile_col(gg);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int ix = xj + (b - 1) * d;
-            const bool ok = rok && (ix >= 0) && (ix < w);
-            const unsigned byte_off = (unsigned)((img * h + iy) * w + ix) * (unsigned)(UBD_C * 4);
-            u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? byte_off + 16u * q : oob), 0, 0);
-            u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(ok ? byte_off + 64u + 8u * q : oob), 0, 0);
+            const bool ok = (unsigned)ix < (unsigned)w;
+            const unsigned cb = (unsigned)ix * (unsigned)(UBD_C * 4);
+            cq4[b] = ok ? cb + 16u * q : BIG;
+        }
+    };
+    auto row_term = [&](int gg, int dy) {                     // byte offset of pixel (row of the group + dy, x = 0); wave-uniform
+        const int rs = (int)((unsigned)gg / (unsigned)groups_x);
+        const int s = (int)((unsigned)rs % (unsigned)half_rows);
+        const int img = (int)((unsigned)rs / (unsigned)half_rows);
+        const int iy = ((s >> log2d) << (log2d + 1)) + (s & dm1) + dy;
+        return (iy >= 0 && iy < h) ? (unsigned)((img * h + iy) * w) * (unsigned)(UBD_C * 4) : BIG;
+    };
+    // one row (a) of the 4 x 4 sample array of group gg: 4 samples x (4 + 2) channel registers
+    auto load_row = [&](wsamples &D, int gg, int a) {
+        const unsigned rb = row_term(gg, (a - 1) * d);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(rb + cq4[b]), 0, 0);
+            u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(rb + cq4[b] + dq2), 0, 0);     // v_add3_u32
             D.v4[a][b] = __builtin_bit_cast(f32x4, r4);
             D.v2[a][b] = __builtin_bit_cast(f32x2, r2);
         }
@@ -169,6 +187,7 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
     // MFMAs), row 1 is fetched under the MFMAs of transform row 0, row 3 under those of transform row 2.
     // The first samples are requested before the block copies U into LDS: their latency hides behind the copy.
     wsamples D;
+    set_cols(g < g_last ? g : g_last);
     load_row(D, g < g_last ? g : g_last, 0);
     load_row(D, g < g_last ? g : g_last, 2);
     for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
@@ -205,6 +224,7 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
                 // all sample rows are dead: rows 0 and 2 of the next group under the last 48 MFMAs + epilogue.
                 // Unconditional (clamped) so that hipcc counts the outstanding loads exactly.
                 const int gn = g + stride;
+                set_cols(gn < g_last ? gn : g_last);
                 load_row(D, gn < g_last ? gn : g_last, 0);
                 load_row(D, gn < g_last ? gn : g_last, 2);
             }
@@ -242,23 +262,30 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
 
         // ---- epilogue: lane = (tile i of the group, channel quarter q); registers = 4 consecutive channels
         {
-            const int gx = (int)((unsigned)g % (unsigned)groups_x);
-            const int rs = (int)((unsigned)g / (unsigned)groups_x);
-            const int s = (int)((unsigned)rs % (unsigned)half_rows);
-            const int img = (int)((unsigned)rs / (unsigned)half_rows);
-            const int y0 = ((s >> log2d) << (log2d + 1)) + (s & dm1);
-            const int tc = gx * 16 + i;
-            const int xo0 = ((tc >> log2d) << (log2d + 1)) + (tc & dm1);
+            const int xo0 = tile_col(g);
+            const int rs_e = (int)((unsigned)g / (unsigned)groups_x);
+            const int s_e = (int)((unsigned)rs_e % (unsigned)half_rows);
+            const int img = (int)((unsigned)rs_e / (unsigned)half_rows);
+            const int y0 = ((s_e >> log2d) << (log2d + 1)) + (s_e & dm1);
+            unsigned st0[2], st1[2];                         // store column terms: channels 4q.. and 16 + 4q.. (q < 2)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int xo = xo0 + c * d;
+                const unsigned cb = (unsigned)xo * (unsigned)(UBD_C * 4) + 16u * q;
+                st0[c] = xo < w ? cb : BIG;
+                st1[c] = (xo < w && q < 2) ? cb + 64u : BIG;
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int yo = y0 + rr * d;
+                const unsigned rb = row_term(g, rr * d);     // BIG below the image
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int xo = xo0 + c * d;
                     const bool ok = yo < h && xo < w;
-                    const unsigned e = ((unsigned)(img * h + yo) * (unsigned)w + (unsigned)xo) * (unsigned)UBD_C + 4u * (unsigned)q;   // element index
-                    const unsigned o0 = ok ? e * 4u : oob;
-                    const unsigned o1 = (ok && q < 2) ? (e + 16u) * 4u : oob;
+                    const unsigned e = ((unsigned)(img * h + yo) * (unsigned)w + (unsigned)xo) * (unsigned)UBD_C + 4u * (unsigned)q;   // element index (EPI 1 mask loads)
+                    const unsigned o0 = rb + st0[c];
+                    const unsigned o1 = rb + st1[c];
                     f32x4 v0, v1;
                     if constexpr (EPI != 1) {
 #pragma unroll
