@@ -185,16 +185,21 @@ template <typename TX>
 __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ dlogits, const void *__restrict__ a9,
                                                       const float *__restrict__ hk, float *__restrict__ g, long npix, int k_out)
 {
-    __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
-    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
+    __shared__ __attribute__((aligned(16))) float s_kT[(UBD_MAX_CLASSES + 1) * UBD_C];     // head kernel transposed: [k][c]
+    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) { const int c = t / k_out, k = t - c * k_out; s_kT[k * UBD_C + c] = hk[t]; }
     __syncthreads();
     // one 4-channel chunk per thread: the 16-byte stores (and the activation loads) of a wave are contiguous
     f32x4 *pg = (f32x4 *)g;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < npix * 6; t += (long)gridDim.x * blockDim.x) {
         const long p = t / 6;
         const int c4 = (int)(t - p * 6);
-        float dl[UBD_MAX_CLASSES + 1];
-        for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < k_out; ++k) {
+            const float dl = dlogits[p * k_out + k];
+            const f32x4 wv = *(const f32x4 *)&s_kT[k * UBD_C + c4 * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(dl, wv[e], acc[e]);
+        }
         float av[4];
         if constexpr (sizeof(TX) == 4) {
             const f32x4 a = ((const f32x4 *)a9)[t];
@@ -206,51 +211,103 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
         }
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float acc = 0.f;
-            for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[(c4 * 4 + e) * k_out + k], acc);
-            o[e] = av[e] > 0.f ? acc : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) o[e] = av[e] > 0.f ? acc[e] : 0.f;
         pg[t] = o;
     }
 }
 
-// dhk[c][k] = sum_p a9[p][c] dl[p][k]; dhb[k] = sum_p dl[p][k]  (row 24 of the A operand is all ones)
+// dhk[c][k] = sum_p a9[p][c] dl[p][k]; dhb[k] = sum_p dl[p][k]  (row 24 of the A operand is all ones); k_out > 1.
+// Tiles of 64 pixels are staged through LDS with contiguous 16-byte loads (activations widened to fp32, a ones column
+// appended) and the MFMA operands are read back in their layout: lane (m, kq) takes A[c = m (+16)][px = 4 s + kq] and
+// B[px][k = m (+16)].  Row stride 48 floats: the four pixel rows of a k-step start 16 banks apart (conflict-free).
+// Wave w multiplies pixels 16 w .. 16 w + 15 of every tile.
+#define HW_TILE 64
+#define HW_STRIDE 48
 template <typename TX>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict__ a9, const float *__restrict__ dlogits,
-                                                         float *__restrict__ g_hk, float *__restrict__ g_hb, long npix, int k_out)
+                                                         float *__restrict__ partials, long npix, int k_out)
 {
-    const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
+    __shared__ __attribute__((aligned(16))) float sA[HW_TILE * HW_STRIDE];      // [px][c (24) | 1 | zeros]
+    __shared__ __attribute__((aligned(16))) float sB[HW_TILE * (UBD_MAX_CLASSES + 1) + 32];   // flat copy of the tile's dlogits: [px][k_out]; columns k >= k_out
+                                                                                            // of the B operand read the next pixel's values and are dropped at the end
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    for (int t = threadIdx.x; t < HW_TILE * HW_STRIDE; t += 256) {                // ones column, zero padding (written once)
+        const int c = t % HW_STRIDE;
+        sA[t] = c == UBD_C ? 1.f : 0.f;
+    }
+    for (int t = threadIdx.x; t < HW_TILE * (UBD_MAX_CLASSES + 1) + 32; t += 256) sB[t] = 0.f;
     f32x4 acc[2][2] = {};
-    const long nsteps = (npix + 3) >> 2;
-    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long per = (nsteps + nwaves - 1) / nwaves;
-    const long s0 = wave * per, s1 = (s0 + per < nsteps) ? s0 + per : nsteps;
-    for (long sb = s0; sb < s1; sb += 8) {
-        float a0[8], a1[8], b0[8], b1[8];
+    const long ntiles = (npix + HW_TILE - 1) / HW_TILE;
+    const bool wide = k_out > 16;
+    // register staging: the next tile's global loads are in flight while the current tile is multiplied
+    constexpr int CPP = sizeof(TX) == 4 ? 6 : 3, EPC = 16 / sizeof(TX);          // 16-byte chunks per pixel, elements per chunk
+    constexpr int AREGS = (HW_TILE * CPP + 255) / 256;                            // 2 (fp32) / 1 (16-bit)
+    constexpr int BREGS = (HW_TILE * (UBD_MAX_CLASSES + 1) + 255) / 256;          // 8
+    u32x4 ra[AREGS];
+    float rb[BREGS];
+    auto fetch = [&](long tile) {
+        const long p0 = tile * HW_TILE;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                          // 8 k-steps of loads in flight
-            const long p = (sb + u) * 4 + k;
-            const bool ok = (sb + u < s1) && p < npix;
-            a0[u] = ok ? ld_act<TX>(a9, (size_t)p * UBD_C + m) : 0.f;
-            a1[u] = ok ? (m < 8 ? ld_act<TX>(a9, (size_t)p * UBD_C + 16 + m) : (m == 8 ? 1.f : 0.f)) : 0.f;
-            b0[u] = (ok && m < k_out) ? dlogits[p * k_out + m] : 0.f;
-            b1[u] = (ok && 16 + m < k_out) ? dlogits[p * k_out + 16 + m] : 0.f;
+        for (int r = 0; r < AREGS; ++r) {
+            const int ch = r * 256 + threadIdx.x;
+            const int px = ch / CPP;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ra[r] = (ch < HW_TILE * CPP && p0 + px < npix) ? ((const u32x4 *)a9)[p0 * CPP + ch] : z;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-            if (k_out > 16) {
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        for (int r = 0; r < BREGS; ++r) {
+            const int e = r * 256 + threadIdx.x;
+            rb[r] = (e < HW_TILE * k_out && p0 * k_out + e < npix * k_out) ? dlogits[p0 * k_out + e] : 0.f;
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long p0 = tile * HW_TILE;
+        __syncthreads();                                                          // previous tile's operands consumed
+#pragma unroll
+        for (int r = 0; r < AREGS; ++r) {
+            const int ch = r * 256 + threadIdx.x;
+            if (ch < HW_TILE * CPP) {
+                const int px = ch / CPP, part = ch - px * CPP;
+                float *dst = sA + px * HW_STRIDE + part * EPC;
+                if constexpr (sizeof(TX) == 4) {
+                    *(f32x4 *)dst = __builtin_bit_cast(f32x4, ra[r]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dst[2 * e] = (float)__builtin_bit_cast(TX, (unsigned short)(ra[r][e] & 0xFFFFu));
+                        dst[2 * e + 1] = (float)__builtin_bit_cast(TX, (unsigned short)(ra[r][e] >> 16));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BREGS; ++r) {
+            const int e = r * 256 + threadIdx.x;
+            if (e < HW_TILE * k_out) sB[e] = rb[r];
+        }
+        if (p0 + HW_TILE > npix)                                                  // ragged last tile: no ones beyond the data
+            for (int px = threadIdx.x; px < HW_TILE; px += 256) sA[px * HW_STRIDE + UBD_C] = (p0 + px < npix) ? 1.f : 0.f;
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int px = 16 * wid + 4 * s4 + kq;
+            const float a0 = sA[px * HW_STRIDE + m], a1 = sA[px * HW_STRIDE + 16 + m];
+            const float b0 = sB[px * k_out + m];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (wide) {
+                const float b1 = sB[px * k_out + 16 + m];
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
     }
-    // D: col = lane&15 (k index), row = 4*(lane>>4) + r (channel index / ones row).
-    // Block reduction in LDS first: with k_out == 1 every wave targets the same 25 addresses.
-    __shared__ float red[32 * 32];
+    // D: col = lane&15 (k index), row = 4*(lane>>4) + r (channel index / ones row).  Block reduction in LDS first.
+    __syncthreads();
+    float *red = sA;                                                              // 32 x 32 floats
     for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) red[t] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -260,16 +317,14 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = acc[mt][nt][r];
-                if (v != 0.f) atomicAdd(&red[(16 * mt + 4 * k + r) * 32 + m + 16 * nt], v);
+                if (v != 0.f) atomicAdd(&red[(16 * mt + 4 * kq + r) * 32 + m + 16 * nt], v);
             }
     __syncthreads();
+    // one partial row [c (24) | ones][k_out] per block, summed by reduce_partials_kernel (a thousand blocks adding into the
+    // same 25 k_out addresses would serialise for tens of microseconds)
     for (int t = threadIdx.x; t < 25 * 32; t += blockDim.x) {
         const int row = t >> 5, col = t & 31;
-        const float v = red[t];
-        if (col < k_out && v != 0.f) {
-            if (row < UBD_C) atomicAdd(&g_hk[row * k_out + col], v);
-            else atomicAdd(&g_hb[col], v);
-        }
+        if (col < k_out) partials[(size_t)blockIdx.x * (25 * k_out) + row * k_out + col] = red[t];
     }
 }
 
@@ -848,9 +903,13 @@ static void launch_head_wgrad(const ubd_handle *h, const void *a9, const float *
                            grads + h->off_head_b, 1, (float *)nullptr);
         return;
     }
-    const long nsteps = (npix + 3) / 4;
-    int g2 = ubd_grid_for((nsteps + 63) / 64, h->num_cus, 4, 2);
-    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, grads + h->off_head_k, grads + h->off_head_b, npix, h->k_out);
+    long g2l = (npix + HW_TILE - 1) / HW_TILE;
+    if (g2l > h->num_cus * 4) g2l = h->num_cus * 4;
+    const int g2 = (int)g2l;
+    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out);
+    const int cols = (UBD_C + 1) * h->k_out;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, g2, cols, grads + h->off_head_k, UBD_C * h->k_out,
+                       grads + h->off_head_b, h->k_out, (float *)nullptr);
 }
 
 // Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9

@@ -22,31 +22,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict__ dlogits, const unsigned short *__restrict__ a9,
                                                         const float *__restrict__ hk, unsigned short *__restrict__ g, long npix, int k_out)
 {
-    __shared__ float s_k[UBD_C * (UBD_MAX_CLASSES + 1)];
-    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) s_k[t] = hk[t];
+    __shared__ __attribute__((aligned(16))) float s_kT[(UBD_MAX_CLASSES + 1) * UBD_C];     // head kernel transposed: [k][c]
+    for (int t = threadIdx.x; t < UBD_C * k_out; t += blockDim.x) { const int c = t / k_out, k = t - c * k_out; s_kT[k * UBD_C + c] = hk[t]; }
     __syncthreads();
-    // one 16-byte chunk (8 channels of a pixel) per thread: loads and stores of a wave are contiguous
+    // one 16-byte chunk (8 channels of a pixel) per thread: loads and stores of a wave are contiguous; per output
+    // channel k the thread's eight weights are two ds_read_b128
     const u32x4 *pa = (const u32x4 *)a9;
     u32x4 *pg = (u32x4 *)g;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < npix * 3; t += (long)gridDim.x * blockDim.x) {
         const long p = t / 3;
         const int c8 = (int)(t - p * 3);
-        float dl[UBD_MAX_CLASSES + 1];
-        for (int k = 0; k < k_out; ++k) dl[k] = dlogits[p * k_out + k];
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < k_out; ++k) {
+            const float dl = dlogits[p * k_out + k];
+            const f32x4 w0 = *(const f32x4 *)&s_kT[k * UBD_C + c8 * 8], w1 = *(const f32x4 *)&s_kT[k * UBD_C + c8 * 8 + 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = fmaf(dl, w0[e], acc[e]); acc[4 + e] = fmaf(dl, w1[e], acc[4 + e]); }
+        }
         const u32x4 av = pa[t];
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsigned short hbits[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                const int c = c8 * 8 + 2 * e + hlf;
-                float acc = 0.f;
-                for (int k = 0; k < k_out; ++k) acc = fmaf(dl[k], s_k[c * k_out + k], acc);
-                const short abits = (short)(hlf ? (av[e] >> 16) : (av[e] & 0xFFFFu));
-                hbits[hlf] = abits > 0 ? __builtin_bit_cast(unsigned short, (T)acc) : (unsigned short)0;
-            }
-            o[e] = (unsigned)hbits[0] | ((unsigned)hbits[1] << 16);
+            const short a_lo = (short)(av[e] & 0xFFFFu), a_hi = (short)(av[e] >> 16);
+            const unsigned lo = a_lo > 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)acc[2 * e]) : 0u;
+            const unsigned hi = a_hi > 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)acc[2 * e + 1]) : 0u;
+            o[e] = lo | (hi << 16);
         }
         pg[t] = o;
     }
