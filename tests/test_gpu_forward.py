@@ -152,3 +152,14 @@ def test_load_keras_weights_export(tmp_path):
         assert np.array_equal(a, b)
     with pytest.raises(ValueError):
         Model(NetConfig(grey=False), seed=0).load_keras_weights(path)      # wrong architecture
+
+
+def test_direct_dilated_kernel_path(monkeypatch):
+    """UBD_DILCONV=direct selects the implicit-GEMM dilated kernel (and the unfused head) instead of the Winograd one;
+    read when the handle is created.  Same oracle, same bounds."""
+    monkeypatch.setenv("UBD_DILCONV", "direct")
+    for cin, ncls, fml, n, hh, ww in ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100)):
+        w = onet.init_weights(300 + cin + ncls, cin, ncls, bias_scale=0.25)
+        x = synthetic.noise_images(9, n, hh, ww, cin)
+        ref = onet.forward(x.astype(np.float64), w, fml)
+        _check(_model(cin, ncls, fml, w).predict(x), ref)

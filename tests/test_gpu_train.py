@@ -47,6 +47,12 @@ def test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww):
     assert off == g.size
 
 
+def test_gradients_direct_dilated_kernel_path(monkeypatch):
+    """fp32 train step with UBD_DILCONV=direct: forward and data gradient of the dilated layers on the implicit-GEMM kernel."""
+    monkeypatch.setenv("UBD_DILCONV", "direct")
+    test_gradients_vs_autograd(3, 2, True, 2, 64, 96)
+
+
 def test_adam_step_and_training_reduces_loss():
     model, w, x, labels = _setup(3, 0, True, 4, 64, 64, 21)
     tr = Trainer(model, Adam(lr=1e-3))
