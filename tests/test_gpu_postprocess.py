@@ -88,6 +88,20 @@ def test_random_noise_maps_vs_oracle():
         _compare(_model(0), lg, 0, min_area=0, cap=2048)
 
 
+def test_ragged_and_tiny_maps_vs_oracle():
+    """Map sizes that are not multiples of the 64-pixel wave (ballot tails), single rows / columns, a 1 x 1 map, and the
+    largest map the one-launch front end takes (128 x 128) filled with noise; with and without classes."""
+    rng = np.random.default_rng(11)
+    for hw in [(1, 1), (1, 37), (29, 1), (3, 5), (17, 33), (50, 130), (128, 128)]:
+        m = rng.random((3,) + hw) < 0.55
+        if hw[0] >= 3 and hw[1] >= 3:
+            m[1] = ndi.binary_closing(m[1])
+        lg = np.where(m[..., None], 1.5, -1.5).astype(np.float32)
+        _compare(_model(0), lg, 0, min_area=0, cap=4200)
+        lg2 = np.concatenate([lg, rng.normal(0, 1, (3,) + hw + (2,)).astype(np.float32)], axis=-1)
+        _compare(_model(2), lg2, 2, min_area=1, cap=4200)
+
+
 def test_nested_rings_and_class_vote():
     m = np.zeros((1, 64, 64), bool)
     m[0, 4:60, 4:60] = 1; m[0, 10:54, 10:54] = 0; m[0, 16:48, 16:48] = 1; m[0, 22:42, 22:42] = 0; m[0, 28:36, 28:36] = 1
