@@ -18,6 +18,7 @@ struct ubd_handle {
     size_t off_head_k, off_head_b;
     size_t n_params;
     int num_cus;
+    int pp_lds_attr_set;      // pp_front_lds_kernel's dynamic-LDS limit has been raised on this handle's device
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
 };
 

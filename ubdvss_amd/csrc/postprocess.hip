@@ -1002,10 +1002,9 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     if (grid > gmax) grid = gmax;
     const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;         // test hook: exercise the multi-launch front end
     if (hw <= PP_LDS_MAX_HW && !force_global) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!hd->pp_lds_attr_set) {                              // per handle = per device (the attribute belongs to the device's code object)
             UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW)));
-            attr_set = true;
+            hd->pp_lds_attr_set = 1;
         }
         hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw), st, logits, hd->k_out, logit_threshold,
                            map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
