@@ -571,7 +571,8 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
     const int total = n * tiles_y * tiles_x;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    for (int ltile = blockIdx.x; ltile < total; ltile += gridDim.x) {
+        const int tile = ubd_xcd_tile(ltile, total);                       // neighbouring tiles on one XCD (shared halo lines)
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
         const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
         const int ty = (int)((unsigned)rr % (unsigned)tiles_y);

@@ -24,6 +24,18 @@ struct ubd_handle {
 
 static const int UBD_DILATIONS[UBD_NUM_DIL] = {1, 2, 4, 8, 16, 1};
 
+// XCD-aware tile order for kernels whose blocks walk logical indices L = blockIdx.x, + gridDim.x, ...: consecutive
+// blocks sit on different XCDs (8 of them, each with its own L2), so neighbouring tiles -- which share halo rows and
+// cache lines -- would be fetched into two L2s.  Logical index L is mapped to tile (L & 7) * total / 8 + (L >> 3): the
+// blocks of one XCD walk one contiguous eighth of the tiles.  A bijection for any grid size; identity when the tile
+// count is not a multiple of 8.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int ubd_xcd_tile(int L, int total)
+{
+    return (total & 7) == 0 ? (L & 7) * (total >> 3) + (L >> 3) : L;
+}
+#endif
+
 void ubd_set_error(const char *fmt, ...);
 
 #define UBD_CHECK_HIP(expr)                                                              \

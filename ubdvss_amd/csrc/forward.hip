@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
     const int cb = (q < CIN) ? q : 0;                                  // 1/3 channels
 
     auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
+        tile = ubd_xcd_tile(tile, total);                                  // neighbouring tiles on one XCD (shared halo lines)
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
         const int r = (int)((unsigned)tile / (unsigned)tiles_x);
         const int ty = (int)((unsigned)r % (unsigned)tiles_y);

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder; };
     auto tile_geom = [&](int tile) {
         geom g;
+        tile = ubd_xcd_tile(tile, total);                                  // neighbouring tiles on one XCD (shared halo lines)
         const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
         const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
         const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
