@@ -95,7 +95,7 @@ int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st);
 #define UBD_DIL16_FRAG_U32 (7 * 2 * 64 * 4)          // 16-bit dilated layer: [chunk 7][nt 2][lane 64] x 4 dwords (8 halves)
 void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
-                          const void *in, void *out, int n, int H4, int W4, hipStream_t st);
+                          const void *in, void *out, int n, int H4, int W4, hipStream_t st, float *logits3 = nullptr);
 void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, int transpose, hipStream_t st);
 struct ubd_fwd16_layout { size_t off_wfrag32, off_wfrag16, off_a1, off_a2, off_acts[7], total; };
 void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layout *L);

@@ -471,7 +471,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                         const u32x4 *__restrict__ wfrag, const float *__restrict__ bias,
                                                         const unsigned short *__restrict__ mask, int n, int h,
-                                                        int w, int d, unsigned mg_tx, unsigned mg_h)
+                                                        int w, int d, unsigned mg_tx, unsigned mg_h, float *__restrict__ logits3)
 {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
@@ -483,11 +483,13 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         bA = *(const f32x4 *)(bias + 4 * q);
         if (q < 2) bB = *(const f32x4 *)(bias + 16 + 4 * q);
     }
+    // EPI 3 (train step, one output channel): as EPI 2, but the activation is stored as well (the backward pass reads it)
+    // and the logits go to `logits3`.
     // EPI 2 (last hidden layer of an inference pass with one output channel): `mask` carries the fp32 head (24 weights +
     // bias, net.py:308-311), `y` the fp32 logits; the activation is rounded to T as if it had been stored, never written
     f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
     float hbias = 0.f;
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 2 || EPI == 3) {
         const float *head = (const float *)mask;
         hA = *(const f32x4 *)(head + 4 * q);
         if (q < 2) hB = *(const f32x4 *)(head + 16 + 4 * q);
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         }
         const int x0 = tc.xt * 16;
         const int npx = w - x0 < 16 ? w - x0 : 16;
-        if constexpr (EPI == 2) {
+        if constexpr (EPI == 2 || EPI == 3) {
             float part = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part = fmaf(round16<T>(fmaxf(acc0[r] + bA[r], 0.f)), hA[r], part);
@@ -554,8 +556,13 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
             for (int r = 0; r < 4; ++r) part = fmaf(round16<T>(fmaxf(acc1[r] + bB[r], 0.f)), hB[r], part);   // hB = 0 for q >= 2
             part += __shfl_xor(part, 16, 64);                           // sum over the four channel quarters
             part += __shfl_xor(part, 32, 64);
-            if (q == 0 && i < npx) ((float *)y)[(size_t)tc.rowid * w + x0 + i] = part + hbias;
-        } else {
+            float *lg = EPI == 2 ? (float *)y : logits3;
+            if (q == 0 && i < npx) lg[(size_t)tc.rowid * w + x0 + i] = part + hbias;
+        }
+        if constexpr (EPI == 3) {
+            const u32x2 nomask = {0u, 0u};
+            store_tile16_t<T, 0>(y, (size_t)tc.rowid * w + x0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
+        } else if constexpr (EPI != 2) {
             u32x2 m0 = {0u, 0u}, m1 = {0u, 0u};
             if constexpr (EPI == 1) { m0 = a.m0; m1 = a.m1; }
             store_tile16_t<T, EPI>(y, (size_t)tc.rowid * w + x0, npx, lane, acc0, acc1, bA, bB, m0, m1);
@@ -661,7 +668,7 @@ static unsigned magic_u32(unsigned d) { return d <= 1u ? 0u : (unsigned)(((1ull 
 
 template <typename T>
 static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
-                         const void *in, void *out, int n, int H4, int W4, hipStream_t st)
+                         const void *in, void *out, int n, int H4, int W4, hipStream_t st, float *logits3)
 {
     const unsigned tiles_x = (unsigned)(W4 + 15) / 16;
     const long tiles = (long)n * H4 * tiles_x;
@@ -670,21 +677,24 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     const unsigned mg_tx = magic_u32(tiles_x), mg_h = magic_u32((unsigned)H4);
     if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h);
+                           (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
     else if (epi == 2)      // out = fp32 logits (n, H4, W4, 1), mask = fp32 head (24 weights + bias)
         hipLaunchKernelGGL((dilconv16_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h);
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
+    else if (epi == 3)      // out = activation, logits3 = fp32 logits, mask = fp32 head
+        hipLaunchKernelGGL((dilconv16_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h, logits3);
     else
         hipLaunchKernelGGL((dilconv16_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h);
+                           (const u32x4 *)frag, bias, (const unsigned short *)mask, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
 }
 
 // 16-bit dense dilated layer (epi 0: forward, epi 1: data gradient with ReLU mask); element type from the handle
 void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
-                          const void *in, void *out, int n, int H4, int W4, hipStream_t st)
+                          const void *in, void *out, int n, int H4, int W4, hipStream_t st, float *logits3)
 {
-    if (h->cfg.dtype == UBD_BF16) launch_dil16<__bf16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st);
-    else launch_dil16<_Float16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st);
+    if (h->cfg.dtype == UBD_BF16) launch_dil16<__bf16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st, logits3);
+    else launch_dil16<_Float16>(h, epi, frag, bias, mask, d, in, out, n, H4, W4, st, logits3);
 }
 
 // packed 16-bit fragments of all six dilated layers (transpose = 1: data-gradient kernels)
@@ -730,6 +740,12 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     const bool fuse_head = inference && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
         unsigned short *nxt = (unsigned short *)(ws + L.off_acts[k + 1]);
+        if (!inference && h->k_out == 1 && k == UBD_NUM_DIL - 1 && h->off_head_b == h->off_head_k + UBD_C) {
+            // train step: L9 stores its activation (the backward pass reads it) and applies the head in the same epilogue
+            ubd_launch_dilconv16(h, 3, wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32, params + h->off_dil_b[k], params + h->off_head_k, UBD_DILATIONS[k], cur, nxt, n, H4, W4, st, logits);
+            UBD_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         if (fuse_head && k == UBD_NUM_DIL - 1) {
             ubd_launch_dilconv16(h, 2, wfrag16 + (size_t)k * UBD_DIL16_FRAG_U32, params + h->off_dil_b[k], params + h->off_head_k, UBD_DILATIONS[k], cur, logits, n, H4, W4, st);
             UBD_CHECK_HIP(hipGetLastError());
