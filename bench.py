@@ -86,7 +86,16 @@ def cpu_baseline(seconds):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 2000:
             break
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model, "host_cpus": ncpu,
             "sample": f"{n} batches of {nb} textured 512x512x3 images, torch-CPU fp32 forward (oneDNN) + C "
                       f"restatement of the OpenCV postprocess, {el:.1f} s"}
 
