@@ -100,6 +100,39 @@ def cpu_baseline(seconds):
                       f"restatement of the OpenCV postprocess, {el:.1f} s"}
 
 
+def cpu_baseline_train(seconds, threads):
+    """torch-CPU restatement of the train step (fp32 forward + loss + autograd backward + Keras Adam) at the reference's
+    default batch of 8 (train.py:31), bounded sample."""
+    from oracle import net_numpy as onet, net_torch as otorch
+    from ubdvss_amd import synthetic
+    nb = 8
+    w = onet.init_weights(1, C_IN, 0)
+    labels = synthetic.rectangle_maps(30, nb, SIDE // 4, SIDE // 4)
+    x = synthetic.textured_images(31, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0
+    flat = np.concatenate([a.reshape(-1) for a in w]).astype(np.float64)
+    m = np.zeros_like(flat); v = np.zeros_like(flat)
+    torch.set_num_threads(threads)
+
+    def step(t):
+        nonlocal flat, m, v
+        _, _, _, grads = otorch.loss_and_grads(x, labels[..., None], onet.unflatten_weights(flat.astype(np.float32), C_IN, 0), False, True,
+                                               dtype=torch.float32)
+        g = np.concatenate([a.reshape(-1) for a in grads]).astype(np.float64)
+        flat, m, v = otorch.adam_step(flat, g, m, v, t)
+
+    step(1)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        n += 1
+        step(1 + n)
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of batch {nb} (512x512x3), torch-CPU fp32 forward + loss + autograd backward + Adam, {el:.1f} s"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,6 +319,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_seconds)
+            if train is not None:
+                train["cpu_baseline"] = cpu_baseline_train(max(4.0, args.cpu_seconds * 0.75), cpu["cores"])
 
         line = {
             "metric": "images/sec (512x512) fwd+CCL", "value": round(value, 1), "unit": "images/s",
