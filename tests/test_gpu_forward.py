@@ -163,3 +163,87 @@ def test_direct_dilated_kernel_path(monkeypatch):
         x = synthetic.noise_images(9, n, hh, ww, cin)
         ref = onet.forward(x.astype(np.float64), w, fml)
         _check(_model(cin, ncls, fml, w).predict(x), ref)
+
+
+def test_broadcast_invalidates_packed_fragments(monkeypatch):
+    """c10d collectives write ``model.params`` without bumping its version counter: a rank that predicted
+    before ``Trainer.broadcast_weights`` must not keep its old packed fragments.  The broadcast is emulated by a
+    version-preserving write (``.data.copy_``), which is what ``dist.broadcast`` does to a non-src rank's tensor."""
+    from ubdvss_amd import Trainer, distributed
+    cfg = NetConfig(grey=False)
+    m = Model(cfg, seed=3)
+    x = torch.from_numpy(synthetic.noise_images(5, 2, 64, 64, 3)).cuda()
+    m.predict_on_device(x)                                   # packs the fragments of the seed-3 weights
+    src = Model(cfg, seed=4)
+
+    def fake_broadcast(flat_params, src=0, group=None):
+        v = flat_params._version
+        flat_params.data.copy_(src_params)
+        assert flat_params._version == v                    # like c10d: no version bump
+    src_params = src.params
+    monkeypatch.setattr(distributed, "broadcast_parameters", fake_broadcast)
+    Trainer(m).broadcast_weights()
+    assert torch.equal(m.predict_on_device(x), src.predict_on_device(x))
+
+
+def test_failed_forward_does_not_poison_the_prepacked_key():
+    """A rejected ubd_forward call (batch over the 2^30-byte L3 limit) must not leave a key that makes the next call
+    skip weight packing on a fresh workspace."""
+    cfg = NetConfig(grey=False)
+    m = Model(cfg, seed=3)
+    ref = Model(cfg, seed=3)
+    x = torch.from_numpy(synthetic.noise_images(5, 2, 64, 64, 3)).cuda()
+    with pytest.raises(ValueError):
+        m.predict_on_device(torch.zeros((2, 64, 64, 1), dtype=torch.float32, device="cuda"))   # wrong channel count
+    with pytest.raises(RuntimeError, match="batch too large"):
+        m.predict_on_device(torch.zeros((1, 13392, 13392, 3), dtype=torch.uint8, device="cuda"))  # quarter-res activation > 2^30 B
+    assert m._packed_key is None                                  # the rejected call packed nothing
+    assert torch.equal(m.predict_on_device(x), ref.predict_on_device(x))
+
+
+def test_uint8_rule_is_the_same_at_every_entry_point():
+    """uint8 images are raw pixels and take NetConfig's preprocessing on device, float images are fed as they are --
+    Model.predict, ModelRunner.predict, Trainer.train_on_batch and the *_on_device calls agree."""
+    from ubdvss_amd import PreprocessingType, ModelRunner, Trainer
+    w = onet.init_weights(6, 3, 0, bias_scale=0.1)
+    cfg = NetConfig(grey=False, preprocessing=PreprocessingType.MOBILENET_LIKE)
+    m = Model(cfg); m.set_weights(w)
+    xu8 = synthetic.noise_images(11, 2, 64, 64, 3, as_float=False)
+    xf = onet.preprocess_mobilenet(xu8.astype(np.float64)).astype(np.float32)
+    a = m.predict_on_device(torch.from_numpy(xu8).cuda()).cpu().numpy()
+    assert np.array_equal(m.predict(xu8), a)
+    _check(m.predict(xf), onet.forward(xf.astype(np.float64), w))
+    _check(a, onet.forward(xf.astype(np.float64), w))
+    det_u8 = ModelRunner(cfg).predict(m, xu8)[0]
+    det_f = ModelRunner(cfg).predict(m, xf)[0]
+    assert np.array_equal(det_u8, det_f)
+    labels = synthetic.rectangle_maps(6, 2, 16, 16)
+    m2 = Model(cfg); m2.set_weights(w)
+    l_u8 = Trainer(m).train_on_batch(xu8, labels[..., None])
+    l_f = Trainer(m2).train_on_batch(xf, labels[..., None])
+    assert abs(l_u8 - l_f) <= 1e-5 * abs(l_f)
+
+
+def test_net_manager_loads_reference_files(tmp_path, golden_dir):
+    """A log dir as the reference leaves it -- Keras ``inference_model.h5`` + pickled NetConfig -- loads through
+    NetManager(log_dir).load_model() (net.py:443-466) and predicts like the oracle on those weights."""
+    import shutil
+    from ubdvss_amd import NetManager, keras_h5
+    from ubdvss_amd.net import weight_shapes
+    shutil.copy(os.path.join(golden_dir, "keras_model_rgb.h5"), tmp_path / "inference_model.h5")
+    mgr = NetManager(str(tmp_path), NetConfig(grey=False))
+    mgr.save_config()
+    mgr2 = NetManager(str(tmp_path))
+    mgr2.load_model()
+    w, _ = keras_h5.read_keras_weights(os.path.join(golden_dir, "keras_model_rgb.h5"))
+    assert [a.shape for a in w] == [tuple(s) for s in weight_shapes(3, 0)]
+    x = synthetic.noise_images(9, 1, 64, 64, 3)
+    _check(mgr2.get_keras_model().predict(x), onet.forward(x.astype(np.float64), w))
+    mgr2.save_model(7)                                        # net.py:418-420: numbered snapshot + current model
+    assert (tmp_path / "model007.npz").exists() and (tmp_path / "model.npz").exists()
+    other = tmp_path / "other"; other.mkdir()
+    mgr3 = NetManager(str(other), NetConfig(grey=False, max_image_side=1024))
+    cfg3 = mgr3.load_another_model(str(tmp_path))
+    assert cfg3.get_max_side() == 1024 and torch.equal(mgr3.get_keras_model().params, mgr2.get_keras_model().params)
+    with pytest.raises(AssertionError):
+        mgr2.load_model("somewhere/else.h5")

@@ -102,6 +102,21 @@ def test_ragged_and_tiny_maps_vs_oracle():
         _compare(_model(2), lg2, 2, min_area=1, cap=4200)
 
 
+def test_isolated_pixel_grids_on_odd_sizes():
+    """Most components a map can hold: isolated pixels on every other row and column = ceil(h/2) * ceil(w/2) external
+    components, which exceeds h*w/4 when a side is odd (127 x 127: 4096).  Every one has contourArea 0, so min_area -1
+    keeps them all; the image after a full grid must be untouched (per-image root slices do not overlap)."""
+    for hw in [(127, 127), (128, 127), (127, 128), (1, 255), (5, 3)]:
+        m = np.zeros((3,) + hw, bool)
+        m[0, ::2, ::2] = 1
+        m[1, 1::2, 1::2] = 1
+        m[2, hw[0] // 3:hw[0] // 3 + 1, :] = 1
+        lg = np.where(m[..., None], 1.0, -1.0).astype(np.float32)
+        _compare(_model(0), lg, 0, min_area=-1, cap=4200)
+        bmap, out, counts = _run(_model(0), lg, min_area=-1, cap=4200)
+        assert counts[0] == ((hw[0] + 1) // 2) * ((hw[1] + 1) // 2)
+
+
 def test_nested_rings_and_class_vote():
     m = np.zeros((1, 64, 64), bool)
     m[0, 4:60, 4:60] = 1; m[0, 10:54, 10:54] = 0; m[0, 16:48, 16:48] = 1; m[0, 22:42, 22:42] = 0; m[0, 28:36, 28:36] = 1

@@ -60,7 +60,8 @@ static void pp_layout_compute(int n, int h, int w, int cap, int n_cls, pp_layout
 {
     const size_t hw = (size_t)h * w;
     size_t off = 0;
-    L->root_cap = (int)(hw / 4 + 2);
+    // most external 8-connected components a map can hold: isolated pixels on every other row and column
+    L->root_cap = ((h + 1) / 2) * ((w + 1) / 2) + 1;
     L->off_nroots = off;   off += ubd_align_up(sizeof(int) * n, 256);
     L->off_nkept = off;    off += ubd_align_up(sizeof(int) * n, 256);
     L->off_label = off;    off += ubd_align_up(sizeof(int) * n * (hw + 1), 256);
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void pp_roots_kernel(const unsigned char *__re
         if (lab[loc + 1] != loc + 1) continue;             // not the raster-first pixel of its component
         const bool external = (loc < w) || (lab[loc + 1 - w] == 0);
         if (!external) continue;
-        const int idx = atomicAdd(&nroots[img], 1);        // idx < root_cap always: at most hw/4 components
+        const int idx = atomicAdd(&nroots[img], 1);        // idx < root_cap always: at most ceil(h/2) * ceil(w/2) components
         roots[(size_t)img * root_cap + idx] = loc;
         area2[(size_t)img * root_cap + idx] = 0;
         rootslot[p] = idx;
@@ -775,9 +776,9 @@ __device__ __forceinline__ void uf_union_wg(int *lab, int a, int b)
 
 // LDS layout (bytes): label int32 [hw + 1] | owner int16 [hw] | rootslot int16 [hw] | fg uint8 [hw] | 2 counters.
 // After the owner phase the label array is dead and is reused as area2 [root_cap] | kept [root_cap].
-static size_t pp_front_lds_bytes(int hw)
+static size_t pp_front_lds_bytes(int hw, int root_cap)
 {
-    const size_t lab_ints = (size_t)hw + 1 > 2 * ((size_t)hw / 4 + 2) ? (size_t)hw + 1 : 2 * ((size_t)hw / 4 + 2);
+    const size_t lab_ints = (size_t)hw + 1 > 2 * (size_t)root_cap ? (size_t)hw + 1 : 2 * (size_t)root_cap;
     return ubd_align_up(lab_ints * 4, 16) + (size_t)hw * 2 * 2 + ubd_align_up(hw, 16) + 16;
 }
 
@@ -1003,10 +1004,10 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;         // test hook: exercise the multi-launch front end
     if (hw <= PP_LDS_MAX_HW && !force_global) {
         if (!hd->pp_lds_attr_set) {                              // per handle = per device (the attribute belongs to the device's code object)
-            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW)));
+            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW, PP_LDS_MAX_HW / 2 + 2)));   // 1-pixel-high maps hold the most roots per pixel
             hd->pp_lds_attr_set = 1;
         }
-        hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw), st, logits, hd->k_out, logit_threshold,
+        hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
                            map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
                            n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote);
     } else {

@@ -82,9 +82,9 @@ class ModelRunner:
         x = np.asarray(images)
         if x.dtype != np.uint8:
             x = x.astype(np.float32)
+        # float images arrive already preprocessed, as in the reference; uint8 images are raw pixels and take the
+        # NetConfig preprocessing fused into the first layer (one rule for every entry point)
         xt = torch.from_numpy(np.ascontiguousarray(x)).to(model.device)
-        if xt.dtype == torch.uint8:
-            xt = xt.float()                 # numpy images arrive already preprocessed, as in the reference
         logits, bmap, quads, classes, counts = self.predict_on_device(model, xt)
         self.synchronize()
         counts_h = counts.cpu().numpy()

@@ -127,6 +127,25 @@ class NetConfig:
         return "\n".join(["Net Config:"] + rows)
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """``config.pkl`` files written by the reference name ``semantic_segmentation.net.NetConfig`` /
+    ``PreprocessingType`` (net.py:468-469); the attribute names are the same here, so those classes map onto this
+    module's.  Nothing else of the reference package is resolvable (and nothing else is needed)."""
+
+    def find_class(self, module, name):
+        if module in ("semantic_segmentation.net", "net") and name in ("NetConfig", "PreprocessingType"):
+            return globals()[name]
+        return super().find_class(module, name)
+
+
+def load_reference_pickle(path):
+    with open(path, "rb") as f:
+        cfg = _ReferenceUnpickler(f).load()
+    if isinstance(cfg, NetConfig) and not hasattr(cfg, "_class_name_to_id"):   # the reference sets it only with a class file
+        cfg._class_name_to_id = {}
+    return cfg
+
+
 def weight_shapes(c_in, n_classes):
     """Keras ``model.get_weights()`` order and shapes of the built model (net.py:292-311)."""
     shapes, cin = [], c_in
@@ -188,6 +207,12 @@ class Model:
                 out.append(rng.uniform(-lim, lim, shape).astype(np.float32))
         return out
 
+    def invalidate_packed_weights(self):
+        """Call after writing ``self.params`` through a raw pointer or a c10d collective (neither bumps the tensor's
+        version counter): the next forward pass re-packs the MFMA weight fragments."""
+        self._weights_epoch += 1
+        self._packed_key = None
+
     def count_params(self):
         return int(self.params.numel())
 
@@ -229,6 +254,16 @@ class Model:
             raise ValueError("no arr_<i> entries: export with np.savez(path, *model.get_weights())")
         self.set_weights([d[k] for k in names])
 
+    def load_keras_h5(self, path):
+        """Weights of a model file the reference wrote (``model.h5`` / ``inference_model.h5`` / ``model_weights.h5``,
+        net.py:418-427), parsed by ubdvss_amd.keras_h5 (no h5py): ``get_weights()`` order = this flat order."""
+        from . import keras_h5
+        arrays, names = keras_h5.read_keras_weights(path)
+        try:
+            self.set_weights(arrays)
+        except ValueError as e:
+            raise ValueError(f"{path}: {e} (Keras weights: {names})") from None
+
     # ---------------------------------------------------------------- forward
     def _workspace(self, attr, nbytes):
         ws = getattr(self, attr)
@@ -263,25 +298,30 @@ class Model:
             out = torch.empty((n, hh // 4, ww // 4, self.k_out), dtype=torch.float32, device=self.device)
         nbytes = self._lib.ubd_forward_workspace_bytes(self._h, n, hh, ww)
         ws = self._workspace("_ws", nbytes)
-        # the packed weight fragments at the head of the workspace stay valid until the parameters change
-        key = (ws.data_ptr(), self.params.data_ptr(), self.params._version, self._weights_epoch)
+        # the packed weight fragments at the head of the workspace stay valid until the parameters change; the key
+        # names the stream too (a pack on another stream is not ordered before this call) and is only stored once
+        # the call that packed has been accepted
+        stream = self._stream()
+        key = (ws.data_ptr(), self.params.data_ptr(), self.params._version, self._weights_epoch, stream.value)
         if key == self._packed_key:
             in_dtype |= _lib.UBD_IN_PREPACKED
-        self._packed_key = key
+        self._packed_key = None
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ubd_forward(self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre,
-                                             n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                                             n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
                        "ubd_forward")
+        self._packed_key = key
         return out
 
     def predict(self, images, batch_size=None):
-        """keras.Model.predict: numpy (N,H,W,C_in) float -> numpy float32 logits (N,H/4,W/4,K)."""
+        """keras.Model.predict: numpy (N,H,W,C_in) -> numpy float32 logits (N,H/4,W/4,K).  Float images are fed as
+        they are (the reference preprocesses on the host, data_generators.py:113,148); uint8 images are raw pixels
+        and get ``NetConfig``'s preprocessing fused into the first layer, exactly like ``predict_on_device``."""
         x = np.asarray(images)
         if x.dtype != np.uint8:
             x = x.astype(np.float32)
         xt = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
-        pre = PreprocessingType.NONE      # numpy float input is already preprocessed (data_generators.py:113,148)
-        return self.predict_on_device(xt, preprocessing=pre).cpu().numpy()
+        return self.predict_on_device(xt).cpu().numpy()
 
     # ---------------------------------------------------------------- postprocess
     def alloc_postprocess_outputs(self, n, mh, mw, cap, want_map=True):
@@ -316,8 +356,8 @@ class Model:
 
 
 class NetManager:
-    """Builds / saves / loads the model (net.py:255-494).  File formats are this package's own
-    (flat fp32 ``.npz`` + pickled NetConfig); Keras HDF5 interchange is out of scope here."""
+    """Builds / saves / loads the model (net.py:255-494) with the reference's method names and arguments.  Writes this
+    package's own format (flat fp32 ``.npz`` + pickled NetConfig); reads that and the reference's Keras ``.h5`` files."""
 
     CURRENT_MODEL_FILENAME = "model.npz"
     INFERENCE_MODEL_FILENAME = "inference_model.npz"
@@ -342,31 +382,62 @@ class NetManager:
     def get_model(self):
         return self._model
 
-    def save_model(self):
+    def save_model(self, step=None):
+        """net.py:418-420: a numbered snapshot ``model{step:03d}`` plus the current model (``step`` may be omitted
+        here; the reference requires it)."""
+        if step is not None:
+            self._model.save_weights(os.path.join(self._log_dir, "model{:03d}.npz".format(step)))
         self._model.save_weights(os.path.join(self._log_dir, self.CURRENT_MODEL_FILENAME))
         self.save_config()
 
     def save_inference(self):                           # net.py:422-427
         self._model.save_weights(os.path.join(self._log_dir, self.INFERENCE_MODEL_FILENAME))
 
-    def load_model(self, model_path=None, dtype="float32"):
-        if model_path is None:                          # loader preference of net.py:460-466
-            for name in (self.INFERENCE_MODEL_FILENAME, self.CURRENT_MODEL_FILENAME):
-                cand = os.path.join(self._log_dir, name)
-                if os.path.exists(cand):
-                    model_path = cand
-                    break
-        if model_path is None:
-            raise FileNotFoundError(f"no model file in {self._log_dir}")
-        logging.info(f"Loading model from {model_path}")
+    def load_another_model(self, another_log_dir, dtype="float32"):
+        """net.py:429-441: model and architecture-dependent configuration from ``another_log_dir``, the
+        architecture-independent knobs (side multiple, max image side, min pixels) of this manager's configuration.
+        (The reference passes its own config as ``from_others``' second positional argument, net.py:440, which makes
+        it the side multiple; the documented intent is implemented here.)"""
+        other = NetManager(another_log_dir, self._net_config)
+        other.load_config()
+        other.load_model(dtype=dtype)
+        self._model = other._model
+        mine = self._net_config
+        self._net_config = NetConfig.from_others(other._net_config, side_multiple=mine.get_side_multiple(),
+                                                 max_image_side=mine.get_max_side(),
+                                                 min_pixels_for_detection=mine.get_min_pixels_for_detection())
+        self._model.net_config = self._net_config
+        return self._net_config
+
+    def load_model(self, path_to_model=None, dtype="float32"):
+        """net.py:443-466: models live in the log dir next to their config, so ``path_to_model`` must stay None (the
+        reference asserts the same); preference: inference model, then current model; within each, this package's
+        ``.npz`` before a Keras ``.h5`` written by the reference (read by ubdvss_amd.keras_h5, no h5py needed)."""
+        assert path_to_model is None, "Programmer! Models are stored in log_dir, near their config. " \
+                                      "If you load model from other location model and config will not match most likely."
+        candidates = []
+        for name in (self.INFERENCE_MODEL_FILENAME, self.CURRENT_MODEL_FILENAME):
+            stem = os.path.splitext(name)[0]
+            candidates += [stem + ".npz", stem + ".h5"]
+        for name in candidates:
+            cand = os.path.join(self._log_dir, name)
+            if os.path.exists(cand):
+                return self._load_model(cand, dtype)
+        raise FileNotFoundError(f"Model not found in dir {self._log_dir}. Must contain "
+                                f"at least one of the following files {candidates}")
+
+    def _load_model(self, path_to_model, dtype="float32"):
+        logging.info(f"loading model from {path_to_model}")
         self._model = Model(self._net_config, dtype=dtype)
-        self._model.load_weights(model_path)
+        if path_to_model.endswith(".h5"):
+            self._model.load_keras_h5(path_to_model)
+        else:
+            self._model.load_weights(path_to_model)
         return self._net_config
 
     def save_config(self):                              # net.py:468-469
         with open(os.path.join(self._log_dir, self.PICKLED_CONFIG_FILENAME), 'wb') as f:
             pickle.dump(self._net_config, f)
 
-    def load_config(self):                              # net.py:471-472
-        with open(os.path.join(self._log_dir, self.PICKLED_CONFIG_FILENAME), 'rb') as f:
-            self._net_config = pickle.load(f)
+    def load_config(self):                              # net.py:471-472; also reads a config.pkl the reference wrote
+        self._net_config = load_reference_pickle(os.path.join(self._log_dir, self.PICKLED_CONFIG_FILENAME))

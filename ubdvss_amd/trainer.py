@@ -40,6 +40,8 @@ class Trainer:
 
     def broadcast_weights(self, src=0):
         distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
+        # c10d writes the tensor without bumping its version counter: invalidate the packed weight fragments
+        self.model.invalidate_packed_weights()
 
     def backward_on_device(self, images, targets):
         """images: device tensor (N,H,W,C) float32 or uint8; targets: device int32 (N,H/4,W/4[,1]).
@@ -70,7 +72,7 @@ class Trainer:
             _lib.check(self._lib.ubd_adam_step(self.model.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                                self.v.data_ptr(), self.grads.numel(), self.iterations, o.lr, o.beta_1,
                                                o.beta_2, o.epsilon, grad_scale, self.model._stream()), "ubd_adam_step")
-        self.model._weights_epoch += 1            # parameters changed behind torch's version counter
+        self.model.invalidate_packed_weights()    # parameters changed behind torch's version counter
 
     def train_step_on_device(self, images, targets):
         self.backward_on_device(images, targets)
@@ -78,13 +80,14 @@ class Trainer:
         return self.loss
 
     def train_on_batch(self, images, targets):
-        """Keras ``train_on_batch``: numpy batch in, scalar loss out."""
+        """Keras ``train_on_batch``: numpy batch in, scalar loss out.  Float images are fed as they are (already
+        preprocessed, data_generators.py:113,148); uint8 images are raw pixels and get ``NetConfig``'s preprocessing
+        fused into the first layer -- the same rule as every other entry point (Model.predict, ModelRunner.predict,
+        *_on_device)."""
         dev = self.model.device
         x = np.asarray(images)
         if x.dtype != np.uint8:
             x = x.astype(np.float32)
-        xt = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-        if xt.dtype == torch.uint8:
-            xt = xt.float()
+        xt = torch.from_numpy(np.ascontiguousarray(x)).to(dev)     # uint8 stays uint8: NetConfig preprocessing fused on device
         yt = torch.from_numpy(np.ascontiguousarray(np.asarray(targets)).astype(np.int32)).to(dev)
         return float(self.train_step_on_device(xt, yt)[0].item())
