@@ -11,12 +11,18 @@ Extra objects on the JSON line:
   roofline     -- the dominant kernel (dense dilated 3x3 conv, fp32 MFMA), timed live with HIP events
   cpu_baseline -- the torch-CPU restatement (oracle/, kind "port") on a bounded sample, rank 0, N=1
   parts        -- net-only / postprocess-only timings of the same step
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+  latency_batch1 -- the reference's own metric (predict.py:73-78): one timed predict of zeros (1,S,S,1) after one warm-up
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N>1 either the driver starts the ranks
+(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...) or, when no WORLD_SIZE is set, this script
+starts them itself as child processes BEFORE anything touches the GPU and relays rank 0's JSON line.  Every rank
+counts the ranks RCCL really connected (all-reduce of ones -> "n_ranks_rccl") and exits non-zero if that is not N.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,7 +43,10 @@ SETTLE_STEPS = 300                        # untimed steps (settle + warm-up) bef
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE or 1")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo check of the N-rank launch, barrier and timing plumbing (no GPU work)")
+    ap.add_argument("--cpu-child", choices=["forward", "train", "latency"], help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline (pinned, one per physical core)")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,102 +56,243 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(seconds):
-    """torch-CPU restatement of the same path (forward fp32 + C restatement of the OpenCV
-    postprocess) on a bounded sample: batches of 4 images 512x512x3, all host threads."""
-    from oracle import net_numpy as onet, net_torch as otorch, cv_post as ocv
-    from ubdvss_amd import synthetic
-    w = onet.init_weights(1, C_IN, 0)
-    tw = otorch.to_torch_weights(w, torch.float32)
-    nb = 4
-    labels = synthetic.rectangle_maps(3, nb, SIDE // 4, SIDE // 4)
-    x = torch.from_numpy(synthetic.textured_images(4, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0)
+# ------------------------------------------------------------------------------------------------ CPU baseline
+# The CPU legs run in a CHILD process that never touches the GPU: it pins itself to one hardware thread per physical
+# core of ONE socket before torch creates its thread pool, so the figure does not depend on where the scheduler puts
+# 32 threads on a 256-CPU host (round 1: 145 vs 526 images/s between two runs).  The parent only starts the child
+# (a plain subprocess, no exec) and parses its JSON line.
 
-    def step():
-        with torch.no_grad():
-            lg = otorch.forward(x, tw).numpy()
-        det = (lg[..., 0] > -0.0).astype(np.uint8)
-        return [ocv.postprocess(det[i], None, 4, 5) for i in range(nb)]
+def _pick_cpus(n_threads):
+    """One hardware thread per physical core, all on the socket that offers the most allowed cores."""
+    allowed = sorted(os.sched_getaffinity(0))
+    by_pkg = {}
+    for c in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        by_pkg.setdefault(pkg, {}).setdefault(core, c)          # first (lowest) hw thread of every core
+    pkg = max(by_pkg, key=lambda k: len(by_pkg[k]))
+    cpus = sorted(by_pkg[pkg].values())[:n_threads]
+    return cpus, pkg, len(by_pkg[pkg])
 
-    # thread count: oneDNN on these small convolutions does not scale to hundreds of host threads, so
-    # probe a few counts briefly and time the sample with the fastest (reported as "cores")
-    ncpu = os.cpu_count() or 1
-    best = (None, 1e30)
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-        torch.set_num_threads(nt)
-        step()
-        t0 = time.perf_counter(); step(); dt = time.perf_counter() - t0
-        if dt < best[1]:
-            best = (nt, dt)
-        if dt > 4.0:
-            break
-    torch.set_num_threads(best[0])
-    step()
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 2000:
-            break
-    cpu_model = "unknown"
+
+def _cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
             if ln.startswith("model name"):
-                cpu_model = ln.split(":", 1)[1].strip()
-                break
+                return ln.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": cpu_model, "host_cpus": ncpu,
-            "sample": f"{n} batches of {nb} textured 512x512x3 images, torch-CPU fp32 forward (oneDNN) + C "
-                      f"restatement of the OpenCV postprocess, {el:.1f} s"}
+    return "unknown"
 
 
-def cpu_baseline_train(seconds, threads):
-    """torch-CPU restatement of the train step (fp32 forward + loss + autograd backward + Keras Adam) at the reference's
-    default batch of 8 (train.py:31), bounded sample."""
-    from oracle import net_numpy as onet, net_torch as otorch
+def _timed_repeats(step, seconds, min_reps=5, max_reps=60):
+    step(); step()                                               # warm-up: oneDNN primitive creation, page faults
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < max_reps and (len(times) < min_reps or time.perf_counter() - t_start < seconds):
+        t0 = time.perf_counter(); step(); times.append(time.perf_counter() - t0)
+    return times, time.perf_counter() - t_start
+
+
+def cpu_child(kind, seconds, n_threads):
+    """Runs in the child process (bench.py --cpu-child ...).  Prints one JSON object."""
+    cpus, pkg, cores_on_pkg = _pick_cpus(n_threads)
+    os.sched_setaffinity(0, cpus)
+    os.environ["OMP_NUM_THREADS"] = str(len(cpus))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    import numpy as np
+    import torch
+    torch.set_num_threads(len(cpus))
+    from oracle import net_numpy as onet, net_torch as otorch, cv_post as ocv
     from ubdvss_amd import synthetic
-    nb = 8
-    w = onet.init_weights(1, C_IN, 0)
-    labels = synthetic.rectangle_maps(30, nb, SIDE // 4, SIDE // 4)
-    x = synthetic.textured_images(31, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0
-    flat = np.concatenate([a.reshape(-1) for a in w]).astype(np.float64)
-    m = np.zeros_like(flat); v = np.zeros_like(flat)
-    torch.set_num_threads(threads)
+    pin = {"cores": len(cpus), "pinned_to": f"{len(cpus)} physical cores of socket {pkg} (of {cores_on_pkg} allowed there), one thread per core",
+           "cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
+    if kind == "forward":
+        # the SAME tensor shape as the GPU step: one batch of 32 stripe-textured 512x512x3 images
+        w = onet.init_weights(1, C_IN, 0)
+        tw = otorch.to_torch_weights(w, torch.float32)
+        labels = synthetic.rectangle_maps(3, BATCH, SIDE // 4, SIDE // 4)
+        x = torch.from_numpy(synthetic.textured_images(4, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0)
 
-    def step(t):
-        nonlocal flat, m, v
-        _, _, _, grads = otorch.loss_and_grads(x, labels[..., None], onet.unflatten_weights(flat.astype(np.float32), C_IN, 0), False, True,
-                                               dtype=torch.float32)
-        g = np.concatenate([a.reshape(-1) for a in grads]).astype(np.float64)
-        flat, m, v = otorch.adam_step(flat, g, m, v, t)
+        def step():
+            with torch.no_grad():
+                lg = otorch.forward(x, tw).numpy()
+            det = (lg[..., 0] > -0.0).astype(np.uint8)
+            return [ocv.postprocess(det[i], None, 4, 5) for i in range(BATCH)]
+        times, el = _timed_repeats(step, seconds)
+        med = float(np.median(times))
+        res = {"value": round(BATCH / med, 2), "unit": "images/s", "kind": "port", **pin,
+               "min": round(BATCH / max(times), 2), "max": round(BATCH / min(times), 2), "repeats": len(times),
+               "sample": f"{len(times)} repeats of ONE batch of {BATCH} textured 512x512x3 images (the GPU step's tensor), torch-CPU fp32 "
+                         f"forward (oneDNN) + C restatement of the OpenCV postprocess; value = median, {el:.1f} s in all"}
+    elif kind == "train":
+        nb = 8                                                    # the reference's default batch (train.py:31)
+        w = onet.init_weights(1, C_IN, 0)
+        labels = synthetic.rectangle_maps(30, nb, SIDE // 4, SIDE // 4)
+        x = synthetic.textured_images(31, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0
+        state = {"flat": np.concatenate([a.reshape(-1) for a in w]).astype(np.float64), "t": 0}
+        state["m"] = np.zeros_like(state["flat"]); state["v"] = np.zeros_like(state["flat"])
 
-    step(1)
+        def step():
+            state["t"] += 1
+            _, _, _, grads = otorch.loss_and_grads(x, labels[..., None], onet.unflatten_weights(state["flat"].astype(np.float32), C_IN, 0),
+                                                   False, True, dtype=torch.float32)
+            g = np.concatenate([a.reshape(-1) for a in grads]).astype(np.float64)
+            state["flat"], state["m"], state["v"] = otorch.adam_step(state["flat"], g, state["m"], state["v"], state["t"])
+        times, el = _timed_repeats(step, seconds)
+        med = float(np.median(times))
+        res = {"value": round(nb / med, 2), "unit": "images/s", "kind": "port", **pin,
+               "min": round(nb / max(times), 2), "max": round(nb / min(times), 2), "repeats": len(times),
+               "sample": f"{len(times)} steps of batch {nb} (512x512x3), torch-CPU fp32 forward + loss + autograd backward + Adam; "
+                         f"value = median, {el:.1f} s in all"}
+    else:                                                         # "latency": predict.py:73-78 on the CPU stand-in
+        res = {**pin}
+        for side in (512, 1024):
+            w = onet.init_weights(1, 1, 0)
+            tw = otorch.to_torch_weights(w, torch.float32)
+            x = torch.zeros((1, side, side, 1), dtype=torch.float32)
+
+            def once():
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    otorch.forward(x, tw)
+                return (time.perf_counter() - t0) * 1e3
+            once()                                                # the one warm-up predict of predict.py:74
+            first = once()                                        # the timed predict of predict.py:75-77
+            more = [once() for _ in range(9)]
+            res[f"grey_{side}_ms"] = round(first, 2)
+            res[f"grey_{side}_ms_median_of_10"] = round(float(np.median([first] + more)), 2)
+    print("CPU_CHILD_JSON " + json.dumps(res), flush=True)
+
+
+def run_cpu_child(kind, seconds, n_threads):
+    """Parent side: start the child, return its JSON (or an error record -- the GPU numbers must not be lost to it)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", kind, "--cpu-seconds", str(seconds), "--cpu-threads", str(n_threads)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    env["HIP_VISIBLE_DEVICES"] = ""                              # the child is CPU only
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(120.0, 20 * seconds))
+        for ln in out.stdout.splitlines():
+            if ln.startswith("CPU_CHILD_JSON "):
+                return json.loads(ln[len("CPU_CHILD_JSON "):])
+        return {"error": (out.stderr or out.stdout)[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu baseline child timed out"}
+
+
+# ------------------------------------------------------------------------------------------------ N-rank launch
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (torch.distributed.run, one per GPU) as a child
+    process tree and relay rank 0's JSON line.  Runs before anything in this process has touched the GPU
+    (torch.cuda.device_count() does not initialise it on this image); nothing is exec'ed."""
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but only {have} GPU(s) visible; refusing to run fewer ranks than asked", file=sys.stderr)
+            return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 4
+    print(line, flush=True)
+    return 0
+
+
+def dry_run(args, world, rank):
+    """CPU/gloo walk through the N-rank contract: init, count the connected ranks, barrier-bracketed timing of K steps,
+    MAX over ranks, one JSON line from rank 0.  No GPU work, value is meaningless."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    n_ranks = int(ones.item())
+    x = torch.rand(64, 64)
+
+    def step():
+        return (x @ x).sum()
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
     t0 = time.perf_counter()
-    n = 0
-    while True:
-        n += 1
-        step(1 + n)
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
-            break
-    return {"value": round(nb * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of batch {nb} (512x512x3), torch-CPU fp32 forward + loss + autograd backward + Adam, {el:.1f} s"}
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    g = torch.full((8,), float(rank + 1))
+    dist.all_reduce(g)                                            # stands for the flat-gradient all-reduce
+    ok = n_ranks == args.gpus and float(g[0]) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (512x512) fwd+CCL", "value": round(world * BATCH * args.steps / float(t), 1), "unit": "images/s",
+                          "n_gpus": world, "n_ranks_rccl": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN on CPU/gloo: launch + collective plumbing only, no GPU work"}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 5
 
 
 def main():
     args = parse()
+    if args.cpu_child:
+        cpu_child(args.cpu_child, args.cpu_seconds, args.cpu_threads)
+        return 0
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if not launched and args.gpus > 1:
+        return launch_ranks(args)                                 # parent of the N ranks: never touches the GPU
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    n_ranks_rccl = 1
     if world > 1 or os.environ.get("UBD_BENCH_FORCE_DIST") == "1":      # the second: one-rank check of the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+            return 3
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        ones = torch.ones(1, device=f"cuda:{local_rank}")
+        dist.all_reduce(ones)                                     # how many ranks did RCCL really connect?
+        n_ranks_rccl = int(ones.item())
+        if n_ranks_rccl != args.gpus:
+            print(f"bench.py: RCCL connected {n_ranks_rccl} ranks, --gpus asked for {args.gpus}", file=sys.stderr)
+            return 5
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -186,6 +336,20 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH * args.steps / elapsed
+    # spread of the (short) timed region: five more blocks of K steps, same brackets; `value` stays the first block
+    block_ms = []
+    for _ in range(5):
+        sync_all()
+        tb0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        bt = time.perf_counter() - tb0
+        if dist is not None:
+            t = torch.tensor([bt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bt = float(t.item())
+        block_ms.append(bt / args.steps * 1e3)
 
     # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), batch/GPU = --train-batch:
     #      configs[2] / configs[3] name bf16 activations (fp32 master weights, fp32 accumulation); the fp32
@@ -226,9 +390,10 @@ def main():
 
     train = train_f32 = train_cls8 = None
     if not args.no_train:
-        train = time_train("bfloat16")
-        train_cls8 = time_train("bfloat16", n_cls=8)       # configs[2], second run: 8 classes (labels 1..8), detection + classification loss
-        train_f32 = time_train("float32")
+        train = time_train("bfloat16")                     # configs[2]; at N > 1 = configs[3] (64 images per GPU, DP all-reduce)
+        if world == 1:
+            train_cls8 = time_train("bfloat16", n_cls=8)   # configs[2], second run: 8 classes (labels 1..8), detection + classification loss
+            train_f32 = time_train("float32")
 
     # ---- extra: configs[4], batch 8 of 1024x1024x3, fp16 activations, forward only ("HBM-bound roofline run")
     def time_cfg5():
@@ -256,8 +421,36 @@ def main():
         return res
 
     cfg5 = None
-    if not args.no_train and rank == 0:
+    if not args.no_train and world == 1:
         cfg5 = time_cfg5()
+
+    # ---- extra: the reference's own metric (predict.py:73-78; README_RU.md:9-10): ONE predict of zeros (1,S,S,1) (grey
+    #      model), timed with the wall clock after ONE warm-up predict -- numpy in, numpy out, like keras Model.predict
+    def time_latency():
+        gcfg = NetConfig(grey=True)
+        gm = Model(gcfg, seed=1)
+        res = {"protocol": "predict.py:73-78: model.predict(zeros(1,S,S,1)) once as warm-up, second call timed with time.time(); "
+                           "numpy in / numpy out (H2D + D2H included); *_on_device = same with the image resident in HBM",
+               "reference_claim_ms": {"512": 50, "1024": 150, "source": "README_RU.md:9-10, 'cpu (4 cores)', unverified"}}
+        for side in (512, 1024):
+            xz = np.zeros((1, side, side, 1), np.float32)
+            gm.predict(xz)
+            torch.cuda.synchronize()
+            t0 = time.time(); gm.predict(xz); first = (time.time() - t0) * 1e3
+            more = []
+            for _ in range(19):
+                t0 = time.time(); gm.predict(xz); more.append((time.time() - t0) * 1e3)
+            xd = torch.from_numpy(xz).to(dev)
+            gm.predict_on_device(xd); torch.cuda.synchronize()
+            dts = []
+            for _ in range(20):
+                t0 = time.time(); gm.predict_on_device(xd); torch.cuda.synchronize(); dts.append((time.time() - t0) * 1e3)
+            res[f"grey_{side}"] = {"latency_ms_batch1": round(first, 4), "median_of_20_ms": round(float(np.median([first] + more)), 4),
+                                   "on_device_median_of_20_ms": round(float(np.median(dts)), 4)}
+        del gm
+        return res
+
+    latency = time_latency() if (world == 1 and rank == 0) else None
 
     line = None
     if rank == 0:
@@ -318,19 +511,23 @@ def main():
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cpu_seconds)
+            cpu = run_cpu_child("forward", args.cpu_seconds, args.cpu_threads)
             if train is not None:
-                train["cpu_baseline"] = cpu_baseline_train(max(4.0, args.cpu_seconds * 0.75), cpu["cores"])
+                train["cpu_baseline"] = run_cpu_child("train", max(4.0, args.cpu_seconds * 0.75), args.cpu_threads)
+            if latency is not None:
+                latency["cpu_baseline_4_threads"] = run_cpu_child("latency", 0, 4)
 
         line = {
             "metric": "images/sec (512x512) fwd+CCL", "value": round(value, 1), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "n_ranks_rccl": n_ranks_rccl, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_spread": {"blocks_of_K_steps_after_the_timed_one": [round(v, 4) for v in block_ms],
+                                   "min": round(min(block_ms), 4), "median": round(float(np.median(block_ms)), 4), "max": round(max(block_ms), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup),
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5, "latency_batch1": latency,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},
@@ -340,7 +537,8 @@ def main():
         dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -6,7 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+# UBD_GOLDEN_DIR: fixtures regenerated FROM THE REFERENCE by tests/golden/make_reference_golden.py (same file names and keys)
+GOLDEN = os.environ.get("UBD_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden")
 
 
 def _ensure_built():

@@ -44,6 +44,14 @@ def main():
                             logits=lg, c_in=cin, n_classes=ncls, fml=int(fml))
         cases.append(name)
     manifest["net_cases"] = cases
+    # ---- 16-bit activation variants (configs[2] bf16, configs[4] fp16): oracle with the SAME storage roundings
+    x = synthetic.noise_images(40, 2, 64, 96, 3)
+    w = onet.init_weights(41, 3, 2, bias_scale=0.2)
+    ref64 = onet.forward(x.astype(np.float64), w).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "net16_rgb_cls2.npz"), x=x, params=onet.flatten_weights(w).astype(np.float32),
+                        logits_f64=ref64, c_in=3, n_classes=2, fml=1,
+                        logits_bfloat16=onet.forward(x.astype(np.float64), w, act_dtype="bfloat16").astype(np.float32),
+                        logits_float16=onet.forward(x.astype(np.float64), w, act_dtype="float16").astype(np.float32))
     # ---- postprocess: rectangle maps -> quads
     maps = synthetic.rectangle_maps(3, 8, 128, 128, n_classes=4)
     lg = synthetic.logits_from_maps(maps, 4, seed=5, noise=0.0)     # deterministic: rebuilt from the maps by the tests

@@ -1,0 +1,55 @@
+"""GPU: the whole hot path on a model that really detects something.  Random-init weights give noise maps with 0-1
+objects, so the model is first TRAINED on device (Trainer, the HIP train step) for a few hundred steps on synthetic
+stripe-textured rectangles; then image -> logits -> threshold -> external components -> quads (ModelRunner.predict,
+model_runner.py:105-138) must agree with the CPU oracle fed the same trained weights: logits within 1e-3, detection
+maps identical outside a 1e-3 margin around the threshold, quads bit-exact on every image whose maps agree."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_numpy as onet, cv_post as ocv
+from ubdvss_amd import NetConfig, Model, ModelRunner, Trainer, Adam, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,n_cls", [("float32", 0), ("bfloat16", 3)])
+def test_trained_model_image_to_quads(dtype, n_cls):
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(n_cls)] if n_cls else None, grey=False)
+    train_model = Model(cfg, dtype=dtype, seed=5)
+    tr = Trainer(train_model, Adam(lr=3e-3))
+    labels = synthetic.rectangle_maps(70, 16, 48, 48, n_classes=n_cls)
+    x = synthetic.textured_images(71, labels, 4, 3).astype(np.float32) / 127.5 - 1.0
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    first = float(tr.train_step_on_device(xt, yt)[0])
+    for _ in range(400):
+        tr.train_step_on_device(xt, yt)
+    last = float(tr.loss[0])
+    assert last < 0.5 * first, (first, last)
+    # inference in fp32 on the trained weights, fresh images of the same distribution
+    w = train_model.get_weights()
+    model = Model(cfg, seed=0)
+    model.set_weights(w)
+    labels2 = synthetic.rectangle_maps(72, 8, 48, 48, n_classes=n_cls)
+    x2 = synthetic.textured_images(73, labels2, 4, 3).astype(np.float32) / 127.5 - 1.0
+    runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=512)
+    det, cls_logits, found = runner.predict(model, x2)
+    ref = onet.forward(x2.astype(np.float64), w)
+    lg = model.predict(x2)
+    assert np.abs(lg - ref).max() <= 1e-3                                              # north_star: logits within 1e-3 fp32
+    ref_det = (ref[..., 0] > 0.0)
+    undecided = np.abs(ref[..., 0]) <= 1e-3
+    assert not ((det[..., 0] != ref_det) & ~undecided).any()
+    n_obj, n_checked = 0, 0
+    for i in range(x2.shape[0]):
+        if not np.array_equal(det[i, ..., 0], ref_det[i]):
+            continue                                                                   # a pixel inside the margin flipped: not comparable
+        q, c = ocv.postprocess(det[i, ..., 0].astype(np.uint8), ref[i, ..., 1:].astype(np.float32) if n_cls else None, 4, 5)
+        got = np.array([o.bbox for o in found[i]]).reshape(-1, 8)
+        assert np.array_equal(got, q), (i, got, q)
+        if n_cls:
+            assert [int(o.object_type) for o in found[i]] == [int(v) for v in c]
+        n_obj += len(q); n_checked += 1
+    print(f"{dtype}: loss {first:.3f} -> {last:.3f}; {n_obj} objects on {n_checked} of {x2.shape[0]} images compared bit-exact; "
+          f"{int(undecided.sum())} pixels inside the margin")
+    assert n_checked >= 6 and n_obj >= 8            # a trained model: several objects per image, not the 0-1 of random weights
