@@ -238,7 +238,9 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
     w, _ = keras_h5.read_keras_weights(os.path.join(golden_dir, "keras_model_rgb.h5"))
     assert [a.shape for a in w] == [tuple(s) for s in weight_shapes(3, 0)]
     x = synthetic.noise_images(9, 1, 64, 64, 3)
-    _check(mgr2.get_keras_model().predict(x), onet.forward(x.astype(np.float64), w))
+    ref = onet.forward(x.astype(np.float64), w)                  # fixture weights are U(-1,1) noise: logits are huge
+    got = mgr2.get_keras_model().predict(x)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
     mgr2.save_model(7)                                        # net.py:418-420: numbered snapshot + current model
     assert (tmp_path / "model007.npz").exists() and (tmp_path / "model.npz").exists()
     other = tmp_path / "other"; other.mkdir()

@@ -5,8 +5,10 @@ Two gates per case:
     type after every layer): max |diff| <= 4e-3 (fp16) / 2e-2 (bf16: one storage ulp is 2^-8 = 0.4 %, and a
     rounding tie that flips because fp32 and fp64 accumulate in different orders propagates through the
     remaining layers) * max|logit| + 1e-5,
-  * vs the plain fp64 oracle: <= 2e-2 * max|logit| for fp16 and <= 8e-2 * max|logit| for bf16 (proposal of SURVEY.md
-    section 8(d) scaled to the 10-layer depth; reported, loose by design)."""
+  * vs the plain fp64 oracle: <= 5e-3 * max|logit| for fp16 and <= 2.5e-2 * max|logit| for bf16 (3 x the largest error
+    observed on MI355X, see GATE_FP64),
+  * the binary detection map equals the oracle's on every pixel whose oracle logit is further than the gate from the
+    threshold; the number of pixels inside that margin is printed."""
 import os
 
 import numpy as np
@@ -19,10 +21,13 @@ from ubdvss_amd import NetConfig, Model, ModelRunner, synthetic
 pytestmark = pytest.mark.gpu
 
 
-# Gates = 3 x the largest error observed on MI355X over all cases of this file (tools/parity16_report.py, round 2;
-# profiles/r02_parity16.json), relative to max|logit| of the case:
+# Gates relative to max|logit| of the case, set from the errors observed on MI355X over the cases of this file plus
+# 2 x 512 x 512 and 2 x 1024 x 1024 (tools/parity16_report.py -> profiles/r02_parity16.json): largest observed
+# bf16 9.4e-3 (same-rounding oracle) / 7.9e-3 (fp64 oracle), fp16 1.8e-3 / 1.6e-3.  A bf16 storage rounding that flips
+# between two correct evaluations (fp32 vs fp64 accumulation order) moves a value by 2^-8 relative and propagates, which is
+# why the same-rounding oracle is no closer than the fp64 one at the large shapes; gates = 2-3 x the observed maxima.
 GATE_SAME_ROUNDING = {"bfloat16": 2e-2, "float16": 4e-3}        # vs the oracle with the same storage roundings
-GATE_FP64 = {"bfloat16": 8e-2, "float16": 2e-2}                 # vs the plain fp64 oracle
+GATE_FP64 = {"bfloat16": 2.5e-2, "float16": 5e-3}               # vs the plain fp64 oracle (round 1: 8e-2 / 2e-2)
 
 
 def measure(dtype, cin, ncls, fml, n, hh, ww, seed, thr=0.0):
