@@ -249,3 +249,27 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
     assert cfg3.get_max_side() == 1024 and torch.equal(mgr3.get_keras_model().params, mgr2.get_keras_model().params)
     with pytest.raises(AssertionError):
         mgr2.load_model("somewhere/else.h5")
+
+
+def test_fused_stem_path(monkeypatch):
+    """UBD_STEM=fused runs L2 -> L3 of an inference pass as ONE kernel (L2's output stays in LDS, stem23.h) instead of the
+    two separate kernels (the default, and what training runs).  Same oracle, same bounds, and the two paths agree to
+    fp32 rounding; UBD_TEST_NUM_CUS=2 in a second round makes every block walk many tiles (2-tile-ahead DMA ring)."""
+    cases = ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100), (3, 1, True, 3, 64, 200), (3, 0, False, 1, 8, 8), (1, 0, True, 2, 4, 36))
+    outs = {}
+    for mode in ("unfused", "fused", "fused_few_cus"):
+        if mode != "unfused":
+            monkeypatch.setenv("UBD_STEM", "fused")
+        if mode == "fused_few_cus":
+            monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
+        for cin, ncls, fml, n, hh, ww in cases:
+            w = onet.init_weights(400 + cin + ncls, cin, ncls, bias_scale=0.25)
+            x = synthetic.noise_images(19, n, hh, ww, cin)
+            ref = onet.forward(x.astype(np.float64), w, fml)
+            lg = _model(cin, ncls, fml, w).predict(x)
+            _check(lg, ref)
+            outs[(mode, cin, ncls, fml, n, hh, ww)] = lg
+    for cin, ncls, fml, n, hh, ww in cases:
+        a, b = outs[("fused", cin, ncls, fml, n, hh, ww)], outs[("unfused", cin, ncls, fml, n, hh, ww)]
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+        assert np.array_equal(a, outs[("fused_few_cus", cin, ncls, fml, n, hh, ww)])          # tile -> block assignment is irrelevant

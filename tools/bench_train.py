@@ -13,8 +13,8 @@ tr = Trainer(m, Adam())
 lab = synthetic.rectangle_maps(30, n, 128, 128, n_classes=ncls)
 x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
 y = torch.from_numpy(lab).cuda()
-for _ in range(2): tr.train_step_on_device(x, y)
+for _ in range(200): tr.train_step_on_device(x, y)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): tr.train_step_on_device(x, y)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+for _ in range(100): tr.train_step_on_device(x, y)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
 print(f"{dtype}: train step {dt*1e3:.3f} ms  ({n/dt:.0f} img/s)")

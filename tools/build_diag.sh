@@ -1,0 +1,18 @@
+#!/bin/bash
+# Diagnostic build: libubd_hip_diag.so = the product sources + -DUBD_STAMPS (in-kernel s_memtime stamps, an extra
+# exported ubd_debug_set_stamps).  Never loaded by the package; tools/stamps_*.py load it explicitly.
+set -e
+cd "$(dirname "$0")/../ubdvss_amd/csrc"
+mkdir -p _obj_diag
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS"
+pids=()
+for f in api forward fwd16 wino postprocess loss backward train; do
+  extra=""
+  [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
+  [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
+  ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj_diag/$f.o ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libubd_hip_diag.so _obj_diag/*.o
+echo "built libubd_hip_diag.so"

@@ -39,6 +39,11 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     {
         const char *e = getenv("UBD_DILCONV");
         h->use_wino = !(e && strcmp(e, "direct") == 0);
+        // UBD_STEM=fused: inference runs L2 -> L3 as one kernel with L2's output in LDS (stem23.h).  Measured equal to the
+        // two separate kernels (121-141 us vs 134 us at 32 x 512 x 512: the fused kernel is bound by instruction issue, not by
+        // HBM), so the separate kernels -- which training needs anyway -- stay the default.
+        const char *s = getenv("UBD_STEM");
+        h->fuse_stem = (s && strcmp(s, "fused") == 0);
         // test hook: pretend the device has fewer CUs, so that every persistent kernel walks many tiles per block even
         // on the small shapes the CPU oracle can check (tests/test_gpu_persistent.py)
         const char *c = getenv("UBD_TEST_NUM_CUS");

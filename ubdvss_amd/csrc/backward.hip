@@ -571,12 +571,11 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
 
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
     const int total = n * tiles_y * tiles_x;
+    ubd_tile_decoder tdec;
+    tdec.init(tiles_x, tiles_y, total);
     for (int ltile = blockIdx.x; ltile < total; ltile += gridDim.x) {
-        const int tile = ubd_xcd_tile(ltile, total);                       // neighbouring tiles on one XCD (shared halo lines)
-        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
-        const int img = (int)((unsigned)rr / (unsigned)tiles_y);
+        int tx, ty, img;
+        tdec.decode(ltile, tx, ty, img);                                   // neighbouring tiles on one XCD (shared halo lines)
         const int oy0 = ty * C::TH, ox0 = tx * 16;
         const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
         __syncthreads();                                               // previous tile fully consumed

@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
             gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
             const size_t pixel = ((size_t)I.img * h + gy) * w + gx;
             const char *src = (const char *)((ci >> 24) ? x : gz) + pixel * (UBD_C * 2) + ((ci >> 16) & 0xFF) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 16), 16, 0, 0);
+            ubd_glds16(src, buf + (rd * 256 + wid * 64) * 16);     // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
 
@@ -157,7 +156,8 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
     for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         char *buf = smem + (iter & 1) * C::BUF_BYTES;
         const item_t I = decode(it);
-        __syncthreads();                              // this item's DMA landed; everyone left the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's DMA (issued one item ago, as asm) has landed
+        __syncthreads();                              // ... for every wave; everyone left the other buffer
         if (it + nblk_x < it_end) dma_item(it + nblk_x, smem + ((iter + 1) & 1) * C::BUF_BYTES);
         const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
                             (I.ry + (I.sy0 + W16_TH) * d >= h) || (I.rx + (I.sx0 + TW) * d >= w);   // block-uniform

@@ -19,6 +19,7 @@ struct ubd_handle {
     size_t n_params;
     int num_cus;
     int pp_lds_attr_set;      // pp_front_lds_kernel's dynamic-LDS limit has been raised on this handle's device
+    int fuse_stem;            // 1: inference runs L2 -> L3 as one kernel with L2's output in LDS (UBD_STEM=fused), 0: separate kernels (default)
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
 };
 
@@ -34,6 +35,54 @@ __device__ __forceinline__ int ubd_xcd_tile(int L, int total)
 {
     return (total & 7) == 0 ? (L & 7) * (total >> 3) + (L >> 3) : L;
 }
+#endif
+
+#if defined(__HIPCC__)
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at lds_dst + 16 * lane, no VGPR round trip) written as the
+// instruction itself.  hipcc treats the builtin form as a pending LDS write and drains it (s_waitcnt vmcnt(0)) before
+// the next ds_write -- and before LDS reads it cannot disambiguate (ds_read_b64_tr_b16) --, which exposes the whole
+// fetch latency in every kernel that touches LDS while the next tile's DMA is in flight.  The asm form is outside hipcc's
+// bookkeeping: the caller retires it with its own counted `s_waitcnt vmcnt(N)` + barrier before the staged bytes are read
+// (cdna_hip_programming.md, "What hipcc does not do").  lds_dst: wave-uniform LDS byte address (readfirstlane'd here).
+__device__ __forceinline__ void ubd_glds16(const void *gsrc, const void *lds_generic)
+{
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#endif
+
+#if defined(__HIPCC__)
+// Tile index -> (tx, ty, img) without integer divisions in the tile loop.  hipcc expands an unsigned division by a
+// run-time divisor into ~25 scalar instructions; the persistent stem / backward kernels decode two tile indices per tile
+// and were spending 75 of the 93 scalar instructions per 16-pixel row tile on them (PMC).  Division by the
+// launch constant d is n * m >> 32 with m = floor((2^32 - 1) / d) + 1, exact while n * d < 2^32 (checked once; tile
+// counts are < 2^24 and tiles_x, tiles_y < 2^8 for every supported shape) -- otherwise the real division is used.
+struct ubd_tile_decoder {
+    unsigned tiles_x, tiles_y, mx, my, total;
+    bool fast;
+    __device__ __forceinline__ void init(int tx_, int ty_, int total_)
+    {
+        tiles_x = (unsigned)tx_; tiles_y = (unsigned)ty_; total = (unsigned)total_;
+        mx = 0xFFFFFFFFu / tiles_x + 1u;
+        my = 0xFFFFFFFFu / tiles_y + 1u;
+        const unsigned dmax = tiles_x > tiles_y ? tiles_x : tiles_y;
+        fast = (unsigned long long)total * dmax < 0x100000000ull;
+    }
+    __device__ __forceinline__ unsigned div_x(unsigned v) const { return fast ? (tiles_x == 1u ? v : __umulhi(v, mx)) : v / tiles_x; }
+    __device__ __forceinline__ unsigned div_y(unsigned v) const { return fast ? (tiles_y == 1u ? v : __umulhi(v, my)) : v / tiles_y; }
+    // logical index L (blockIdx.x + k * gridDim.x) -> XCD-aware tile -> coordinates
+    __device__ __forceinline__ void decode(int L, int &tx, int &ty, int &img) const
+    {
+        const unsigned tile = (unsigned)ubd_xcd_tile(L, (int)total);
+        const unsigned r = div_x(tile);
+        tx = (int)(tile - r * tiles_x);
+        const unsigned im = div_y(r);
+        ty = (int)(r - im * tiles_y);
+        img = (int)im;
+    }
+};
 #endif
 
 void ubd_set_error(const char *fmt, ...);

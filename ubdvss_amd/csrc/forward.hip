@@ -202,12 +202,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
     const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int cb = (q < CIN) ? q : 0;                                  // 1/3 channels
 
+    ubd_tile_decoder tdec;                                                 // neighbouring tiles on one XCD (shared halo lines), no divisions
+    tdec.init(tiles_x, tiles_y, total);
     auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
-        tile = ubd_xcd_tile(tile, total);                                  // neighbouring tiles on one XCD (shared halo lines)
-        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int r = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int ty = (int)((unsigned)r % (unsigned)tiles_y);
-        img = (int)((unsigned)r / (unsigned)tiles_y);
+        int tx, ty;
+        tdec.decode(tile, tx, ty, img);
         oy0 = ty * C::TH; ox0 = tx * 16;
     };
     // 24 channels: LDS-DMA (global_load_lds_dwordx4): 64 x 16 B per wave instruction land linearly in LDS, no
@@ -455,6 +454,12 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
         tile = nxt;
     }
 }
+
+#ifdef UBD_STAMPS   // diagnostic build only: device buffer that receives in-kernel s_memtime stamps
+static unsigned long long *g_ubd_stamps = nullptr;
+extern "C" void ubd_debug_set_stamps(void *p) { g_ubd_stamps = (unsigned long long *)p; }
+#endif
+#include "stem23.h"
 
 // ------------------------------------------------------------------------------------
 // Dense dilated 3x3 conv 24 -> 24 (+bias+ReLU), fp32 MFMA, weights resident in VGPRs.
@@ -769,9 +774,22 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
         launch_sep<1, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
     else
         launch_sep<3, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
-    launch_sep<UBD_C, 1>(h, a1, 0, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
     float *cur = (float *)(ws + L.off_acts[0]);
-    launch_sep<UBD_C, 2>(h, a2, 0, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    if (inference && h->fuse_stem) {
+        // L2 -> L3 in one kernel: L2's activation stays in LDS (stem23.h); the a2 buffer is not touched
+        const int tiles = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3) * ((W4 + 15) / 16);
+        int grid = h->num_cus;                                   // one 8-wave block per CU (118 KB of LDS)
+        if (grid > tiles) grid = tiles;
+        hipLaunchKernelGGL(stem23_kernel, dim3(grid), dim3(s23_cfg::NT), 0, st, a1, cur, sf1, params + h->off_sep_b[1], sf2, params + h->off_sep_b[2],
+                           n, H2, W2, H4, W4, pad_s2
+#ifdef UBD_STAMPS
+                           , g_ubd_stamps
+#endif
+                           );
+    } else {
+        launch_sep<UBD_C, 1>(h, a1, 0, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+        launch_sep<UBD_C, 2>(h, a2, 0, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    }
 
     // inference with a single output channel: the head rides in the epilogue of L9 and L9's activation is never written
     const bool fuse_head = inference && h->use_wino && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;

@@ -213,12 +213,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
 
     const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + C::TH - 1) / C::TH;
     const int total = n * tiles_y * tiles_x;
+    ubd_tile_decoder tdec;                                                 // neighbouring tiles on one XCD (shared halo lines), no divisions
+    tdec.init(tiles_x, tiles_y, total);
     auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
-        tile = ubd_xcd_tile(tile, total);                                  // neighbouring tiles on one XCD (shared halo lines)
-        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int r = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int ty = (int)((unsigned)r % (unsigned)tiles_y);
-        img = (int)((unsigned)r / (unsigned)tiles_y);
+        int tx, ty;
+        tdec.decode(tile, tx, ty, img);
         oy0 = ty * C::TH; ox0 = tx * 16;
     };
     int dma_rel[C::ROUNDS];

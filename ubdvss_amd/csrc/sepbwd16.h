@@ -108,8 +108,7 @@ __device__ __forceinline__ void sepb16_stage(const char *__restrict__ tensor, in
             gx = gx < 0 ? 0 : (gx >= tw ? tw - 1 : gx);
             src = tensor + (((size_t)img * th + gy) * tw + gx) * (UBD_C * 2) + part * 16;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(dst + instr * 1024), 16, 0, 0);
+        ubd_glds16(src, dst + instr * 1024);                              // asm form: retired by the caller's explicit vmcnt(0)
     }
 }
 
@@ -240,13 +239,12 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // -> D / mask DMA of the NEXT tile (their LDS regions are free again) and, for 1/3 channels, the next tile's input
     // loads into registers -> phase 2.  Only the 24-channel X patch (single-buffered) is fetched with exposed latency.
     struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder; };
+    ubd_tile_decoder tdec;
+    tdec.init(tiles_x, tiles_y, total);
     auto tile_geom = [&](int tile) {
         geom g;
-        tile = ubd_xcd_tile(tile, total);                                  // neighbouring tiles on one XCD (shared halo lines)
-        const int tx = (int)((unsigned)tile % (unsigned)tiles_x);
-        const int rr = (int)((unsigned)tile / (unsigned)tiles_x);
-        const int ty = (int)((unsigned)rr % (unsigned)tiles_y);
-        g.img = (int)((unsigned)rr / (unsigned)tiles_y);
+        int tx, ty;
+        tdec.decode(tile, tx, ty, g.img);                                  // neighbouring tiles on one XCD (shared halo lines)
         g.oy0 = ty * C::TH; g.ox0 = tx * 16;
         g.ix0 = g.ox0 * STRIDE - pad_lo; g.iy0 = g.oy0 * STRIDE - pad_lo;
         g.dy0 = GSRC == 0 ? g.oy0 : (GSRC == 1 ? g.oy0 - 1 : (g.oy0 >> 1) - 1);       // origin of the D tile in the D tensor
@@ -333,7 +331,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                 }
             }
         }
-        __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
+        // The DMA is issued as asm (ubd_glds16, common.h): hipcc neither waits for it here nor drains the NEXT tile's D
+        // DMA in front of phase 2's LDS accesses (it did with the builtin: every tile waited a full fetch latency there).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this tile's DMA (and the mask loads) have landed
+        __syncthreads();                                               // ... for every wave; LDS writes visible
         {
             if ((CIN == UBD_C && xborder) || dborder) {                // block-uniform
                 const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -388,7 +389,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
                     const char *pd = draw + (dr * C::DCOLS + dc) * 48;
                     const u32x2 a = *(const u32x2 *)(pd + 8 * q);
-                    const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
+                    // channels 16+2q, 17+2q: a b64 read shared by the lane pair (q, q^1) + select; the b32 form has a
+                    // 32-bank map on which pixels i and i + 8 collide
+                    const u32x2 bb = *(const u32x2 *)(pd + 32 + 8 * (q >> 1));
+                    const unsigned b = (q & 1) ? bb[1] : bb[0];
                     if constexpr (UREG) {
                         const int t = ky * 3 + j;
                         acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                             // raw 16-bit activation pairs x packed taps -> depthwise output; x packed dDW pairs -> ddw
                             const char *px = xraw + pix * 48;
                             const u32x2 a = *(const u32x2 *)(px + 8 * q);
-                            const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
+                            const u32x2 bb = *(const u32x2 *)(px + 32 + 8 * (q >> 1));
+                            const unsigned b = (q & 1) ? bb[1] : bb[0];
                             const u32x4 w4 = *(const u32x4 *)(wtp + t * UBD_C + 4 * q);
                             const u32x2 w2 = *(const u32x2 *)(wtp + t * UBD_C + 16 + 2 * q);
                             dwv[0] = dot2b<T>(a[0], w4[0], dwv[0]); dwv[1] = dot2b<T>(a[0], w4[1], dwv[1]);
@@ -499,7 +504,11 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // dpw[ch][co] += sum over the 32 pixels DW[pixel][ch] G[pixel][co]; an all-ones column of the A operand gives db.
-            // Transposed reads: lane 4qq+pp of group grp supplies the address of pixel k = 8 grp + 4 j + qq, segment pp.
+            // Transposed reads: lane 4qq+pp of group grp supplies the address of ONE pixel k, segment pp.  K = pixel is a
+            // summation index, so any lane -> pixel bijection used for both operands is valid; the 32 lanes of an LDS
+            // group (grp 0,1 / grp 2,3) take the 8 even / the 8 odd pixels of a 16-pixel row: with the 12-dword pixel pitch
+            // their 8-dword windows (24 m mod 64, m = 0..7) tile the 64 banks exactly (the natural order 8 grp + 4 j + qq
+            // made pixels k and k + 8 collide: 28-42 % of the LDS cycles of round 1, profiles/r01_pmc_sepb16_*.txt).
             {
                 u32x4 am[MT_PW], bn[2];
 #pragma unroll
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     s16x4 h[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int k = 8 * grp + 4 * j + qq;
+                        const int k = 2 * (4 * (grp & 1) + qq) + (grp >> 1) + 16 * j;
                         const char *pa;
                         if constexpr (CIN == UBD_C) pa = mt == 0 ? sdw + k * 48 + 8 * pp : (pp < 2 ? sdw + k * 48 + 32 + 8 * pp : (pp == 2 ? c_ones : c_zero));
                         else pa = pp == 0 ? sdw + k * (C::SDW_W * 2) : c_zero;
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     s16x4 h[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int k = 8 * grp + 4 * j + qq;
+                        const int k = 2 * (4 * (grp & 1) + qq) + (grp >> 1) + 16 * j;
                         const char *pg = g16 + (((k < 16 ? r0 : r1) * 16 + (k & 15)) * 48);
                         const char *pb = nt == 0 ? pg + 8 * pp : (pp < 2 ? pg + 32 + 8 * pp : c_zero);
                         h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
