@@ -87,6 +87,14 @@ __device__ __forceinline__ f32x2 vadd(f32x2 a, f32x2 b) { return (f32x2){sadd(a[
 __device__ __forceinline__ float ssub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 vsub(f32x2 a, f32x2 b) { return (f32x2){ssub(a[0], b[0]), ssub(a[1], b[1])}; }
 
+#ifdef UBD_STAMPS   // diagnostic build only (tools/build_diag.sh)
+static unsigned long long *g_wino_stamps = nullptr;
+extern "C" void ubd_debug_set_stamps_wino(void *p) { g_wino_stamps = (unsigned long long *)p; }
+#define WSTAMP(k) do { if (stamps && lane == 0) stamps[((size_t)blockIdx.x * 4 + wave_in_block) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#endif
+
 struct wsamples {
     f32x4 v4[4][4];
     f32x2 v2[4][4];
@@ -97,7 +105,11 @@ template <int EPI, typename TAUX>
 __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               const float *__restrict__ ufrag,
                                                               const void *__restrict__ aux_, int n, int h, int w, int d,
-                                                              int log2d, unsigned in_bytes, const float *__restrict__ head)
+                                                              int log2d, unsigned in_bytes, const float *__restrict__ head
+#ifdef UBD_STAMPS
+                                                              , unsigned long long *__restrict__ stamps
+#endif
+                                                              )
 {
     const TAUX *__restrict__ aux = (const TAUX *)aux_;
     __shared__ __attribute__((aligned(16))) float s_u[UBD_WINO_FRAG_FLOATS];       // 48 KiB
@@ -187,12 +199,29 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
     // MFMAs), row 1 is fetched under the MFMAs of transform row 0, row 3 under those of transform row 2.
     // The first samples are requested before the block copies U into LDS: their latency hides behind the copy.
     wsamples D;
+    WSTAMP(0);
+    // U (48 KiB) goes to LDS by LDS-DMA, 12 pieces of 1 KiB per wave, issued as asm (common.h): no VGPR round trip and no
+    // ds_write pass, and the fetch overlaps the first sample requests.  vmcnt(0) retires this wave's pieces whatever
+    // hipcc does with the sample loads around it (they are needed next anyway); the raw barrier publishes everyone's.
+    // First version: 12 x (global_load_dwordx4 + ds_write_b128) + __syncthreads() = 10-12 k cycles of a 69 k-cycle launch
+    // (in-kernel stamps).
     set_cols(g < g_last ? g : g_last);
     load_row(D, g < g_last ? g : g_last, 0);
     load_row(D, g < g_last ? g : g_last, 2);
-    for (int t = threadIdx.x; t < UBD_WINO_FRAG_FLOATS / 4; t += 256) ((f32x4 *)s_u)[t] = ((const f32x4 *)ufrag)[t];
-    __syncthreads();
+    {
+        const char *usrc = (const char *)ufrag + (size_t)lane * 16;
+        constexpr int PER_WAVE = UBD_WINO_FRAG_FLOATS * 4 / 1024 / 4;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int piece = wave_in_block * PER_WAVE + k;
+            ubd_glds16(usrc + (size_t)piece * 1024, (const char *)s_u + piece * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    WSTAMP(1);
     if (g >= g_end) return;
+    int gcount = 0;
     for (;;) {
         // ---- transform-domain rows a = 0..3
         f32x4 Y[2][2][2];      // [output row rr][output col c][nt]; first written at a == 0 (row 0) / a == 1 (row 1)
@@ -320,11 +349,19 @@ __global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(c
                 }
             }
         }
+        ++gcount;
+        if (gcount <= 5) WSTAMP(1 + gcount);
         g += stride;
         if (g >= g_end) break;
     }
+    WSTAMP(7);
 }
 
+#ifdef UBD_STAMPS
+#define WSTAMP_ARG , g_wino_stamps
+#else
+#define WSTAMP_ARG
+#endif
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // frag: this layer's UBD_WINO_FRAG_FLOATS packed floats; aux: bias (epi 0) or mask source (epi 1)
@@ -339,13 +376,13 @@ void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, co
     int grid = ubd_grid_for(groups, h->num_cus, 4, epi != 1 ? 3 : 2);     // forward: 150 VGPRs, three waves per SIMD
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
-        hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
+        hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
     else if (epi == 2)       // out = logits (n, H4, W4, 1); head = 24 weights followed by the bias
-        hipLaunchKernelGGL((dilconv_wino_kernel<2, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, head);
+        hipLaunchKernelGGL((dilconv_wino_kernel<2, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, head WSTAMP_ARG);
     else if (aux_dtype == UBD_F32)
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
     else if (aux_dtype == UBD_BF16)
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, __bf16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, __bf16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
     else
-        hipLaunchKernelGGL((dilconv_wino_kernel<1, _Float16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr);
+        hipLaunchKernelGGL((dilconv_wino_kernel<1, _Float16>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
 }
