@@ -128,6 +128,13 @@ int ubd_train_step(ubd_handle *h, const float *params, const void *images, int i
 int ubd_adam_step(float *params, const float *grads, float *m, float *v, size_t count,
                   int t, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
+/* --- pipelining helper ---------------------------------------------------- */
+/* Enqueues a one-wave kernel that idles for `microseconds` (0..1000) on `stream`.  No reference counterpart:
+ * ModelRunner.predict (model_runner.py:105-138) runs the model and the postprocess one after the other; the MI355X host
+ * (ubdvss_amd.ModelRunner(pipelined=True)) overlaps the postprocess of batch k with the forward pass of batch k+1 on two
+ * streams and delays the latter by a few microseconds so that the postprocess blocks are placed first. */
+int ubd_stream_delay(void *stream, int microseconds);
+
 #ifdef __cplusplus
 }
 #endif

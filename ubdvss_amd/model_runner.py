@@ -5,11 +5,12 @@ The reference runs ``model.predict`` on the device, then thresholds with numpy a
 threshold, the component labelling and the box fitting all run on the MI355X; only the final
 (count, quads, classes) lists cross PCIe.
 """
+import ctypes
 import os
 import numpy as np
 import torch
 
-from . import utils
+from . import _lib, utils
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 
@@ -24,6 +25,7 @@ class ModelRunner:
         self._logit_threshold = - np.log(1 / np.clip(pixel_threshold, eps, 1 - eps) - 1)
         self._cap = max_objects_per_image
         self._pipelined = pipelined
+        self._stagger_us = int(os.environ.get("UBD_STAGGER_US", "3"))
         self._side = None
         self._slots = {}
         self._step = 0
@@ -63,6 +65,10 @@ class ModelRunner:
         if slot["done"] is not None and not slot["done"].query():
             main.wait_event(slot["done"])               # the previous postprocess of this slot still reads its logits
                                                         # (normally long finished: no barrier packet in the forward stream)
+        if self.last_event is not None and self._stagger_us > 0:
+            # the postprocess of the previous batch was enqueued on the side stream a moment ago: give its whole-CU blocks a
+            # head start over the 16 384 small blocks of the first stem kernel (ubd_stream_delay, include/ubd.h)
+            _lib.check(_lib.load().ubd_stream_delay(ctypes.c_void_p(main.cuda_stream), self._stagger_us), "ubd_stream_delay")
         logits = model.predict_on_device(images, out=slot["logits"])
         fwd_done = torch.cuda.Event()
         fwd_done.record(main)
