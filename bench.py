@@ -361,6 +361,11 @@ def main():
         ty = torch.from_numpy(tlabels).to(dev)
         tcfg = cfg if n_cls == 0 else NetConfig(class_names=[f"class{i}" for i in range(n_cls)], grey=False)
         tmodel = Model(tcfg, dtype=dtype, seed=1)
+        if dist is not None:
+            # the handle's own RCCL communicator (include/ubd.h ubd_comm_*): the gradient all-reduce runs inside ubd_train_step,
+            # the dilated + head segment on a communication stream under the stem layers' backward pass
+            from ubdvss_amd import distributed as ubd_dist
+            ubd_dist.attach_native_comm(tmodel, fused=True)
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
@@ -381,7 +386,8 @@ def main():
         res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
                "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb,
                "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
-               "parallelism": f"dp{world}: per-replica loss, one flat-gradient all-reduce (RCCL) per step" if world > 1 else "single GPU",
+               "parallelism": (f"dp{world}: per-replica loss, flat-gradient all-reduce per step through the C-ABI RCCL communicator, "
+                               f"fused into the train step under the stem backward") if dist is not None else "single GPU",
                "loss_last": round(float(trainer.loss[0]), 5),
                "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
         del trainer, tmodel, tx, ty

@@ -128,6 +128,26 @@ int ubd_train_step(ubd_handle *h, const float *params, const void *images, int i
 int ubd_adam_step(float *params, const float *grads, float *m, float *v, size_t count,
                   int t, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
+/* --- data parallelism (no reference counterpart: the reference is single-device) -------------------
+ * One process per GPU, per-replica loss (losses.py:86-126 applied to the rank's own images), ONE sum all-reduce of the flat
+ * fp32 gradient vector per step over RCCL / xGMI, 1/world applied by ubd_adam_step's grad_scale, parameters broadcast once.
+ * The handle owns the communicator.  unique_id: 128 HOST bytes created on one rank by ubd_comm_unique_id and handed to all
+ * ranks by the caller (file, socket, launcher store).  librccl is resolved with dlopen when the first of these is called. */
+#define UBD_UNIQUE_ID_BYTES 128
+/* flags of ubd_comm_init.  UBD_COMM_FUSED: ubd_train_step all-reduces `grads` itself (SUM over ranks) -- the dilated + head
+ * segment on a communication stream under the stem layers' backward pass, the stem segment on the caller's stream, which
+ * then joins the first -- so `grads` come back summed and the caller must NOT call ubd_allreduce_grads again. */
+enum { UBD_COMM_FUSED = 1 };
+int ubd_comm_unique_id(void *unique_id_out);
+int ubd_comm_init(ubd_handle *h, const void *unique_id, int rank, int world, int flags);   /* collective: every rank calls it */
+int ubd_comm_destroy(ubd_handle *h);                                                        /* also done by ubd_destroy */
+int ubd_comm_world(const ubd_handle *h);                                                    /* 1 without a communicator */
+/* In-place SUM all-reduce of grads[0..count) over the ranks, enqueued on `stream` (replaces nothing in the reference; it is
+ * the exchange step between ubd_train_step and ubd_adam_step). */
+int ubd_allreduce_grads(ubd_handle *h, float *grads, size_t count, void *stream);
+/* params[0..count) of rank `root` to every rank (initial weights / after loading a model on one rank). */
+int ubd_broadcast_params(ubd_handle *h, float *params, size_t count, int root, void *stream);
+
 /* --- pipelining helper ---------------------------------------------------- */
 /* Enqueues a one-wave kernel that idles for `microseconds` (0..1000) on `stream`.  No reference counterpart:
  * ModelRunner.predict (model_runner.py:105-138) runs the model and the postprocess one after the other; the MI355X host

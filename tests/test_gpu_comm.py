@@ -1,0 +1,61 @@
+"""GPU: the data-parallel exchange step inside the C ABI (include/ubd.h, ubd_comm_*; no reference counterpart --
+the reference is single-device).  The GPU box has one MI355X, so the communicator has one rank: what is checked here is that
+the RCCL calls really run on the handle's communicator / streams (fused into the train step under the stem backward, or as
+an explicit ubd_allreduce_grads) and leave gradients, loss and the Adam update bit-identical to the run without one.  The
+N-rank arithmetic (sum, 1/world scale, broadcast) is covered on CPU by tests/test_dist_gloo.py and by bench.py --gpus N."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic, distributed, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(n=4, side=64):
+    labels = synthetic.rectangle_maps(51, n, side // 4, side // 4)
+    x = synthetic.textured_images(52, labels, 4, 3).astype(np.float32) / 127.5 - 1.0
+    return torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_one_rank_communicator_leaves_the_step_unchanged(dtype, fused):
+    cfg = NetConfig(grey=False)
+    x, y = _batch()
+    ref = Trainer(Model(cfg, dtype=dtype, seed=3), Adam(lr=1e-3))
+    for _ in range(3):
+        ref.train_step_on_device(x, y)
+    m = Model(cfg, dtype=dtype, seed=3)
+    assert distributed.attach_native_comm(m, fused=fused) == 1
+    assert _lib.load().ubd_comm_world(m._h) == 1
+    tr = Trainer(m, Adam(lr=1e-3))
+    tr.broadcast_weights()                                    # ubd_broadcast_params on the handle's communicator
+    for _ in range(3):
+        tr.train_step_on_device(x, y)
+    torch.cuda.synchronize()
+    if dtype == "bfloat16":                                   # fixed-order reductions: bit-identical
+        assert torch.equal(tr.grads, ref.grads) and torch.equal(m.params, ref.model.params)
+    else:
+        assert torch.allclose(tr.grads, ref.grads, rtol=1e-4, atol=1e-7) and torch.allclose(m.params, ref.model.params, rtol=1e-5, atol=1e-7)
+    assert float(tr.loss[0]) == pytest.approx(float(ref.loss[0]), rel=1e-5)
+    # explicit collective on a raw buffer: in place, sum over one rank = identity
+    buf = torch.arange(33028, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.load().ubd_allreduce_grads(m._h, buf.data_ptr(), buf.numel(), m._stream()), "ubd_allreduce_grads")
+    torch.cuda.synchronize()
+    assert torch.equal(buf, torch.arange(33028, dtype=torch.float32, device="cuda"))
+    _lib.check(_lib.load().ubd_comm_destroy(m._h), "ubd_comm_destroy")
+    assert _lib.load().ubd_comm_world(m._h) == 1
+
+
+def test_collectives_without_a_communicator_fail_loudly():
+    m = Model(NetConfig(grey=False), seed=0)
+    lib = _lib.load()
+    buf = torch.zeros(8, device="cuda")
+    assert lib.ubd_allreduce_grads(m._h, buf.data_ptr(), 8, m._stream()) != 0
+    assert b"no communicator" in lib.ubd_last_error()
+    assert lib.ubd_broadcast_params(m._h, buf.data_ptr(), 8, 0, m._stream()) != 0
+    bad = (ctypes.c_char * 128)()
+    assert lib.ubd_comm_init(m._h, bad, 3, 2, 0) != 0 and b"out of range" in lib.ubd_last_error()

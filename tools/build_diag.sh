@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../ubdvss_amd/csrc"
 mkdir -p _obj_diag
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS"
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train; do
+for f in api forward fwd16 wino postprocess loss backward train comm; do
   extra=""
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
@@ -14,5 +14,5 @@ for f in api forward fwd16 wino postprocess loss backward train; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libubd_hip_diag.so _obj_diag/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libubd_hip_diag.so _obj_diag/*.o -ldl
 echo "built libubd_hip_diag.so"

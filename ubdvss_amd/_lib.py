@@ -9,6 +9,8 @@ UBD_F32, UBD_BF16, UBD_F16 = 0, 1, 2
 UBD_IN_F32, UBD_IN_U8 = 0, 1
 UBD_IN_PREPACKED = 0x100
 UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
+UBD_COMM_FUSED = 1
+UBD_UNIQUE_ID_BYTES = 128
 ABI_VERSION = 1
 
 
@@ -38,6 +40,12 @@ SIGNATURES = {
     "ubd_train_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ubd_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "ubd_stream_delay": (_i, [_vp, _i]),
+    "ubd_comm_unique_id": (_i, [_vp]),
+    "ubd_comm_init": (_i, [_vp, _vp, _i, _i, _i]),
+    "ubd_comm_destroy": (_i, [_vp]),
+    "ubd_comm_world": (_i, [_vp]),
+    "ubd_allreduce_grads": (_i, [_vp, _vp, _sz, _vp]),
+    "ubd_broadcast_params": (_i, [_vp, _vp, _sz, _i, _vp]),
 }
 
 _lib = None

@@ -69,6 +69,10 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     return 0;
 }
 
-extern "C" void ubd_destroy(ubd_handle *h) { free(h); }
+extern "C" void ubd_destroy(ubd_handle *h)
+{
+    if (h && h->comm) ubd_comm_destroy(h);
+    free(h);
+}
 
 extern "C" size_t ubd_param_count(const ubd_handle *h) { return h ? h->n_params : 0; }

@@ -965,6 +965,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }
+        if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
         // separable layers: G1 / G2 are built tile-wise in LDS from the bf16 dDW tensor of the layer above (sepbwd16.h)
         const int pad2 = h->cfg.fml_compatible ? 1 : 0;
         const float *dw0 = params + h->off_sep_dw[0], *dw1 = params + h->off_sep_dw[1], *dw2 = params + h->off_sep_dw[2];
@@ -984,6 +985,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
                                        grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
         UBD_CHECK_HIP(hipGetLastError());
+        if (ubd_comm_fused(h)) return ubd_comm_finish(h, grads, st);
         return 0;
     } else {
     // head
@@ -1009,6 +1011,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         cur ^= 1;
     }
     }
+    if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }       // dilated + head gradients are final
     // separable layers
     const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
@@ -1032,6 +1035,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     else
         launch_sep_bwd<3, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
     UBD_CHECK_HIP(hipGetLastError());
+    if (ubd_comm_fused(h)) return ubd_comm_finish(h, grads, st);
     return 0;
 }
 

@@ -6,7 +6,7 @@ OUT=../libubd_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 mkdir -p _obj
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train; do
+for f in api forward fwd16 wino postprocess loss backward train comm; do
   [ -f $f.hip ] || continue
   extra=""
   # OpenCV-exact float geometry: no FMA contraction in postprocess
@@ -22,6 +22,6 @@ for f in api forward fwd16 wino postprocess loss backward train; do
 done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
-for f in api forward fwd16 wino postprocess loss backward train; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+for f in api forward fwd16 wino postprocess loss backward train comm; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs -ldl
 echo "built $OUT"

@@ -9,8 +9,10 @@
 #define UBD_C 24              // n_filters (net.py:289)
 #define UBD_NUM_DIL 6         // dense dilated layers L4..L9 (net.py:298-304)
 
+struct ubd_comm;
 struct ubd_handle {
     ubd_config cfg;
+    ubd_comm *comm;           // RCCL communicator + communication stream (comm.hip), nullptr: single GPU
     int k_out;                // 1 + n_classes
     // offsets (in floats) into the flat Keras-ordered parameter vector
     size_t off_sep_dw[3], off_sep_pw[3], off_sep_b[3];
@@ -125,6 +127,9 @@ struct ubd_fwd_layout {
 };
 
 // ---- cross-file internals ------------------------------------------------------------------
+bool ubd_comm_fused(const ubd_handle *h);
+int ubd_comm_begin_tail(ubd_handle *h, float *grads, hipStream_t st);
+int ubd_comm_finish(ubd_handle *h, float *grads, hipStream_t st);
 void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L);
 int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
                      int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference = false);

@@ -58,6 +58,30 @@ def broadcast_parameters(flat_params, src=0, group=None):
         dist.broadcast(flat_params, src=src, group=group)
 
 
+def attach_native_comm(model, fused=True, group=None):
+    """Gives ``model``'s C-ABI handle its own RCCL communicator (include/ubd.h, ubd_comm_*): rank 0 creates the unique id,
+    torch.distributed (already initialised, any backend) only carries those 128 bytes to the other ranks.  With ``fused``
+    the train step all-reduces the gradients itself, overlapped with the stem layers' backward pass, and
+    ``Trainer.apply_gradients`` skips the torch collective.  Returns the world size.  Also valid for a single process."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    w, r = world_size(group), rank(group)
+    buf = (ctypes.c_char * _lib.UBD_UNIQUE_ID_BYTES)()
+    if r == 0:
+        _lib.check(lib.ubd_comm_unique_id(buf), "ubd_comm_unique_id")
+    if w > 1:
+        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        if dist.get_backend(group) == "nccl":
+            t = t.to(model.device)
+        dist.broadcast(t, src=0, group=group)
+        ctypes.memmove(buf, bytes(t.cpu().numpy().tobytes()), _lib.UBD_UNIQUE_ID_BYTES)
+    with torch.cuda.device(model.device):
+        _lib.check(lib.ubd_comm_init(model._h, buf, r, w, _lib.UBD_COMM_FUSED if fused else 0), "ubd_comm_init")
+    model._native_comm = "fused" if fused else "explicit"
+    return w
+
+
 def max_over_ranks(value, device=None, group=None):
     """max of a python float over all ranks (bench timing contract)."""
     if world_size(group) == 1:

@@ -39,7 +39,12 @@ class Trainer:
         self._pg = process_group
 
     def broadcast_weights(self, src=0):
-        distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
+        if getattr(self.model, "_native_comm", None):           # the handle's own RCCL communicator (ubd_broadcast_params)
+            with torch.cuda.device(self.model.device):
+                _lib.check(self._lib.ubd_broadcast_params(self.model._h, self.model.params.data_ptr(), self.model.params.numel(),
+                                                          src, self.model._stream()), "ubd_broadcast_params")
+        else:
+            distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
         # c10d writes the tensor without bumping its version counter: invalidate the packed weight fragments
         self.model.invalidate_packed_weights()
 
@@ -65,7 +70,16 @@ class Trainer:
                                                 mdl._stream()), "ubd_train_step")
 
     def apply_gradients(self):
-        grad_scale = distributed.allreduce_gradients(self.grads, group=self._pg)
+        native = getattr(self.model, "_native_comm", None)
+        if native:                                              # C-ABI collective: fused into ubd_train_step, or explicit here
+            world = self._lib.ubd_comm_world(self.model._h)
+            if native == "explicit":
+                with torch.cuda.device(self.model.device):
+                    _lib.check(self._lib.ubd_allreduce_grads(self.model._h, self.grads.data_ptr(), self.grads.numel(),
+                                                             self.model._stream()), "ubd_allreduce_grads")
+            grad_scale = 1.0 / world
+        else:
+            grad_scale = distributed.allreduce_gradients(self.grads, group=self._pg)
         self.iterations += 1
         o = self.opt
         with torch.cuda.device(self.model.device):
