@@ -128,6 +128,16 @@ int ubd_train_step(ubd_handle *h, const float *params, const void *images, int i
 int ubd_adam_step(float *params, const float *grads, float *m, float *v, size_t count,
                   int t, float lr, float beta1, float beta2, float eps, float grad_scale, void *stream);
 
+/* --- training labels --------------------------------------------------------
+ * Replaces SegmapManager.build_segmentation_map (segmap_manager.py:81-104) + _proper_round (:106-133) for a whole batch:
+ * every object quad (8 ints x1,y1..x4,y4 in IMAGE pixels) is divided by `scale`, its corners are snapped outward and the
+ * polygon is filled with PIL's ImageDraw.polygon rule, objects in order (later over earlier), into an int32 map of
+ * (map_h, map_w) = image size / scale.  values[i][o]: what to write (class id + 1, or 1; 255 for drawing).
+ *   quads int32 (n, cap, 8), values int32 (n, cap), counts int32 (n) (objects per image, <= cap), labels int32 (n, map_h, map_w):
+ * the y_true layout of ubd_loss / ubd_train_step.  Bit-identical to Pillow for convex quads (see raster.hip). */
+int ubd_build_label_maps(const int32_t *quads, const int32_t *values, const int32_t *counts, int n, int cap,
+                         int map_h, int map_w, int scale, int32_t *labels, void *stream);
+
 /* --- data parallelism (no reference counterpart: the reference is single-device) -------------------
  * One process per GPU, per-replica loss (losses.py:86-126 applied to the rank's own images), ONE sum all-reduce of the flat
  * fp32 gradient vector per step over RCCL / xGMI, 1/world applied by ubd_adam_step's grad_scale, parameters broadcast once.

@@ -6,9 +6,10 @@ cd "$(dirname "$0")/../ubdvss_amd/csrc"
 mkdir -p _obj_diag
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS"
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train comm; do
+for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   extra=""
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
+  [ "$f" = "raster" ] && extra="-ffp-contract=off"
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
   ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj_diag/$f.o ) &
   pids+=($!)

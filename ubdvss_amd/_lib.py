@@ -40,6 +40,7 @@ SIGNATURES = {
     "ubd_train_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ubd_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "ubd_stream_delay": (_i, [_vp, _i]),
+    "ubd_build_label_maps": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ubd_comm_unique_id": (_i, [_vp]),
     "ubd_comm_init": (_i, [_vp, _vp, _i, _i, _i]),
     "ubd_comm_destroy": (_i, [_vp]),

@@ -6,11 +6,13 @@ OUT=../libubd_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 mkdir -p _obj
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train comm; do
+for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   [ -f $f.hip ] || continue
   extra=""
   # OpenCV-exact float geometry: no FMA contraction in postprocess
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
+  # Pillow-exact float32 scan-line arithmetic: no FMA contraction
+  [ "$f" = "raster" ] && extra="-ffp-contract=off"
   # no SLP packing of adjacent fp32 adds into v_pk_add_f32: beside MFMAs the packed form issues slower than two scalar adds
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
   stale=0
@@ -22,6 +24,6 @@ for f in api forward fwd16 wino postprocess loss backward train comm; do
 done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
-for f in api forward fwd16 wino postprocess loss backward train comm; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
+for f in api forward fwd16 wino postprocess loss backward train comm raster; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs -ldl
 echo "built $OUT"

@@ -85,6 +85,39 @@ class SegmapManager:
         return canvas
 
     @staticmethod
+    def build_segmentation_maps_on_device(image_size, markups, scale=1, for_drawing=False, device=None):
+        """Batch form of ``build_segmentation_map`` on the MI355X (ubd_build_label_maps): ``markups`` is a list (one entry
+        per image) of lists of ObjectMarkup / ClassifiedObjectMarkup, ``image_size`` = (width, height) like ``PIL.Image.size``.
+        Returns an int32 device tensor (N, height/scale, width/scale) -- the y_true layout of the loss / train step."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("SegmapManager.build_segmentation_maps_on_device needs an MI355X; there is no CPU fallback")
+        lib = _lib.load()
+        device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        width, height = image_size
+        if width % scale or height % scale:
+            raise AssertionError("image size must be a multiple of the map scale")
+        n = len(markups)
+        cap = max(1, max((len(m) for m in markups), default=1))
+        quads = np.zeros((n, cap, 8), np.int32)
+        values = np.zeros((n, cap), np.int32)
+        counts = np.zeros((n,), np.int32)
+        for i, objs in enumerate(markups):
+            counts[i] = len(objs)
+            for j, obj in enumerate(objs):
+                value = 255 if for_drawing else (getattr(obj, "object_type", 0) + 1 if isinstance(obj, ClassifiedObjectMarkup) else 1)
+                if value > 255:
+                    raise AssertionError("No more than 255 classes are supported")
+                quads[i, j] = np.asarray(obj.bbox, dtype=np.int64).reshape(8)
+                values[i, j] = value
+        qd, vd, cd = (torch.from_numpy(a).to(device) for a in (quads, values, counts))
+        labels = torch.empty((n, height // scale, width // scale), dtype=torch.int32, device=device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            _lib.check(lib.ubd_build_label_maps(qd.data_ptr(), vd.data_ptr(), cd.data_ptr(), n, cap, height // scale, width // scale,
+                                                int(scale), labels.data_ptr(), stream), "ubd_build_label_maps")
+        return labels
+
+    @staticmethod
     def _proper_round(markup_bbox):
         """Outward snapping of a quad's corners (behaviour of segmap_manager.py:106-133): a coordinate is floored
         when at least two of the four coordinates on the same axis are strictly larger (the object extends to
