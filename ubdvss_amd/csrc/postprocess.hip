@@ -782,12 +782,27 @@ static size_t pp_front_lds_bytes(int hw, int root_cap)
     return ubd_align_up(lab_ints * 4, 16) + (size_t)hw * 2 * 2 + ubd_align_up(hw, 16) + 16;
 }
 
+#ifdef UBD_STAMPS   // diagnostic build only (tools/build_diag.sh)
+static unsigned long long *g_pp_stamps = nullptr;
+extern "C" void ubd_debug_set_stamps_pp(void *p) { g_pp_stamps = (unsigned long long *)p; }
+#endif
 __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     const float *__restrict__ logits, int k_out, float thr, int h, int w, float min_area, int cap, int n_cls, int root_cap,
     int *__restrict__ binary_map, int *__restrict__ g_nroots, int *__restrict__ g_nkept, int *__restrict__ g_owner,
     int *__restrict__ g_roots, int *__restrict__ g_kept, int *__restrict__ stage, int *__restrict__ ymax,
-    int *__restrict__ rows, float *__restrict__ vote)
+    int *__restrict__ rows, float *__restrict__ vote
+#ifdef UBD_STAMPS
+    , unsigned long long *__restrict__ stamps
+#endif
+    )
 {
+#ifdef UBD_STAMPS
+    int stamp_k = 0;
+#define PPSTAMP() do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 16 + stamp_k] = __builtin_amdgcn_s_memtime(); ++stamp_k; } while (0)
+#else
+#define PPSTAMP() do {} while (0)
+#endif
+    PPSTAMP();
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int hw = h * w;
     int *lab = smem;
@@ -834,6 +849,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         }
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- merge (pp_merge_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
@@ -864,6 +880,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         }
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- flatten (pp_flatten_kernel)
     for (int node = tid; node <= hw; node += PP_LDS_THREADS) {
@@ -871,6 +888,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         __hip_atomic_store(&lab[node], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- roots (pp_roots_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
@@ -882,6 +900,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         rs16[loc] = (short)idx;
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- owner (pp_owner_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
@@ -899,9 +918,11 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         if (g_owner) g_owner[pbase + loc] = own;
     }
     __syncthreads();
+    PPSTAMP();
     const int nroots = ctr[0];
     for (int s = tid; s < nroots; s += PP_LDS_THREADS) area2[s] = 0;       // the forest is dead from here on
     __syncthreads();
+    PPSTAMP();
 
     // ---- area (pp_area_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
@@ -921,6 +942,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         if (val != 0) atomicAdd(&area2[key], val);                                  // LDS atomic
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- keep (pp_keep_kernel)
     for (int s = tid; s < nroots; s += PP_LDS_THREADS) {
@@ -944,6 +966,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         if (g_kept) g_kept[(size_t)img * root_cap + s] = k;
     }
     __syncthreads();
+    PPSTAMP();
     {
         const int nk = min(ctr[1], cap);                                          // row extents of the kept objects: (+inf, -1)
         int2 *r = (int2 *)(rows + (size_t)img * cap * (size_t)(6 * h));
@@ -953,6 +976,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         }
     }
     __syncthreads();
+    PPSTAMP();
 
     // ---- extents (pp_extents_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
@@ -971,6 +995,8 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         if (bottom) atomicMax(&ymax[(size_t)img * cap + k], y);
     }
     if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1]; }
+    PPSTAMP();
+#undef PPSTAMP
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -1009,7 +1035,11 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
         }
         hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
                            map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
-                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote);
+                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote
+#ifdef UBD_STAMPS
+                           , g_pp_stamps
+#endif
+                           );
     } else {
     UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));          // the two per-image counters
     hipLaunchKernelGGL(pp_init_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, logit_threshold, npix, hw, map_w, fg, label, binary_map);
