@@ -147,7 +147,12 @@ int ubd_build_label_maps(const int32_t *quads, const int32_t *values, const int3
 /* flags of ubd_comm_init.  UBD_COMM_FUSED: ubd_train_step all-reduces `grads` itself (SUM over ranks) -- the dilated + head
  * segment on a communication stream under the stem layers' backward pass, the stem segment on the caller's stream, which
  * then joins the first -- so `grads` come back summed and the caller must NOT call ubd_allreduce_grads again. */
-enum { UBD_COMM_FUSED = 1 };
+enum { UBD_COMM_FUSED = 1, UBD_COMM_GLOBAL_LOSS = 2 };
+/* UBD_COMM_GLOBAL_LOSS: ubd_loss / ubd_train_step evaluate the reductions of losses.py:86-126 -- n_pos, n_neg, the positive /
+ * negative means, the top-k of the FLATTENED batch (losses.py:111) and the classification mean -- over the images of all
+ * ranks (rank r holds flat indices [r*npix, (r+1)*npix), equal shards), i.e. the reference's loss at the global batch
+ * instead of one loss per replica.  The returned loss is the global one on every rank and d loss / d logits is its exact
+ * gradient, so the parameter gradients must be SUMMED over the ranks and applied with grad_scale = 1 (not 1/world). */
 int ubd_comm_unique_id(void *unique_id_out);
 int ubd_comm_init(ubd_handle *h, const void *unique_id, int rank, int world, int flags);   /* collective: every rank calls it */
 int ubd_comm_destroy(ubd_handle *h);                                                        /* also done by ubd_destroy */

@@ -59,3 +59,24 @@ def test_collectives_without_a_communicator_fail_loudly():
     assert lib.ubd_broadcast_params(m._h, buf.data_ptr(), 8, 0, m._stream()) != 0
     bad = (ctypes.c_char * 128)()
     assert lib.ubd_comm_init(m._h, bad, 3, 2, 0) != 0 and b"out of range" in lib.ubd_last_error()
+
+
+@pytest.mark.parametrize("n_cls", [0, 3])
+def test_batch_global_loss_mode_one_rank_equals_local(n_cls):
+    """UBD_COMM_GLOBAL_LOSS with one rank: the eight collectives of the sharded loss run (sums, counters, three histograms, tie
+    counts, final sums) and must leave loss, metrics, gradients and the update identical to the per-replica path -- with one
+    replica the two semantics coincide.  (The sharded selection arithmetic itself is checked against the oracle's global
+    top-k on CPU: tests/test_oracle_loss.py::test_sharded_radix_select_equals_global_topk.)"""
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(n_cls)] if n_cls else None, grey=False)
+    labels = synthetic.rectangle_maps(61, 4, 16, 16, n_classes=n_cls)
+    x = torch.from_numpy(synthetic.textured_images(62, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    ref = Trainer(Model(cfg, seed=3), Adam(lr=1e-3))
+    ref.train_step_on_device(x, y)
+    m = Model(cfg, seed=3)
+    distributed.attach_native_comm(m, fused=True, global_loss=True)
+    tr = Trainer(m, Adam(lr=1e-3))
+    tr.train_step_on_device(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.loss, ref.loss)
+    assert torch.allclose(tr.grads, ref.grads, rtol=1e-4, atol=1e-7) and torch.allclose(m.params, ref.model.params, rtol=1e-5, atol=1e-7)

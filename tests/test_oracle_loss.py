@@ -69,3 +69,49 @@ def test_adam_matches_torch():
     # Keras folds the bias correction into lr_t and adds eps outside the corrected sqrt -- equal to
     # torch's form up to the eps placement: differences are O(eps)
     assert np.abs(p - tp.detach().numpy()).max() < 1e-6
+
+
+def test_sharded_radix_select_equals_global_topk():
+    """The batch-global loss mode (UBD_COMM_GLOBAL_LOSS, loss.hip) selects the hard negatives of the GLOBAL flattened batch
+    (losses.py:111) from per-rank shards with: summed counters -> k; three levels of summed 11/11/10-bit histograms of the
+    fp32 bit pattern -> the threshold T and the number of elements equal to T that are still selected; per-rank tie counts in
+    rank order -> each rank's first tie rank.  This is that arithmetic in numpy on 2-5 shards (many forced ties), checked
+    against the oracle's global top-k -- the multi-rank path cannot run on the one-GPU test box."""
+    rng = np.random.default_rng(17)
+    for world in (2, 3, 5):
+        for trial in range(6):
+            n_loc = int(rng.integers(200, 900))
+            z = (rng.random((world, n_loc)) < rng.choice([0.05, 0.3, 0.6])).astype(np.float32)
+            ce = np.abs(rng.normal(0, 1, (world, n_loc))).astype(np.float32)
+            if trial % 2:
+                ce = np.round(ce * 4) / 4                     # heavy ties
+            cn = (ce * (1 - z)).astype(np.float32)            # masked-negative BCE per rank (positives -> 0)
+            bits = cn.view(np.uint32)
+            # stage 1: counters + level-0 histogram, "all-reduced"
+            n_pos = int(z.sum()); n_tot = world * n_loc
+            k = int(min(max(n_pos, 1), max(n_tot - n_pos, 1)))
+
+            def select(hist, k_rem):                          # bin of the k_rem-th largest, elements strictly above it
+                acc = 0
+                for b in range(len(hist) - 1, -1, -1):
+                    if acc + hist[b] >= k_rem:
+                        return b, k_rem - acc
+                    acc += hist[b]
+                return 0, k_rem - acc
+            h0 = sum(np.bincount(bits[r] >> 21, minlength=2048) for r in range(world))
+            p0, k1 = select(h0, k)
+            h1 = sum(np.bincount((bits[r][(bits[r] >> 21) == p0] >> 10) & 2047, minlength=2048) for r in range(world))
+            b1, k2 = select(h1, k1)
+            p1 = (p0 << 11) | b1
+            h2 = sum(np.bincount(bits[r][(bits[r] >> 10) == p1] & 1023, minlength=1024) for r in range(world))
+            b2, need_eq = select(h2, k2)
+            T = np.uint32((p1 << 10) | b2)
+            # stage 2: tie counts gathered in rank order
+            ties = [int((bits[r] == T).sum()) for r in range(world)]
+            sel = np.zeros((world, n_loc), bool)
+            for r in range(world):
+                base = sum(ties[:r])
+                tie_rank = base + np.cumsum(bits[r] == T) - 1
+                sel[r] = (bits[r] > T) | ((bits[r] == T) & (tie_rank < need_eq))
+            ref = oloss.topk_mask(cn.reshape(-1).astype(np.float64), k).reshape(world, n_loc)
+            assert sel.sum() == k and np.array_equal(sel, ref), (world, trial)

@@ -10,6 +10,7 @@ UBD_IN_F32, UBD_IN_U8 = 0, 1
 UBD_IN_PREPACKED = 0x100
 UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
 UBD_COMM_FUSED = 1
+UBD_COMM_GLOBAL_LOSS = 2
 UBD_UNIQUE_ID_BYTES = 128
 ABI_VERSION = 1
 

@@ -1058,7 +1058,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     if (h->cfg.dtype == UBD_F32) {
         rc = ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, ws, T.fwd, st);
         if (rc) return rc;
-        rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
+        rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st, h);
         if (rc) return rc;
         for (int k = 0; k < 7; ++k) acts[k] = ws + T.fwd.off_acts[k];
         return backward_impl<float>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd.off_a1, ws + T.fwd.off_a2,
@@ -1067,7 +1067,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
     UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_train_step: bad in_dtype %d", in_dtype);
     rc = ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, height, width, logits, ws, T.fwd16, st);
     if (rc) return rc;
-    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st);
+    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st, h);
     if (rc) return rc;
     for (int k = 0; k < 7; ++k) acts[k] = ws + T.fwd16.off_acts[k];
     if (h->cfg.dtype == UBD_BF16)

@@ -24,6 +24,7 @@ struct ubd_comm {
     hipEvent_t ready, done;      // segment A ready on the compute stream / reduced on the communication stream
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     const char *(*GetErrorString)(ncclResult_t);
 };
@@ -77,9 +78,10 @@ extern "C" int ubd_comm_init(ubd_handle *h, const void *unique_id, int rank, int
     auto init = (ncclResult_t(*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(c->lib, "ncclCommInitRank");
     c->AllReduce = (decltype(c->AllReduce))dlsym(c->lib, "ncclAllReduce");
     c->Broadcast = (decltype(c->Broadcast))dlsym(c->lib, "ncclBroadcast");
+    c->AllGather = (decltype(c->AllGather))dlsym(c->lib, "ncclAllGather");
     c->CommDestroy = (decltype(c->CommDestroy))dlsym(c->lib, "ncclCommDestroy");
     c->GetErrorString = (decltype(c->GetErrorString))dlsym(c->lib, "ncclGetErrorString");
-    if (!init || !c->AllReduce || !c->Broadcast || !c->CommDestroy) { ubd_set_error("ubd_comm_init: librccl lacks a required symbol"); free(c); return 2; }
+    if (!init || !c->AllReduce || !c->Broadcast || !c->AllGather || !c->CommDestroy) { ubd_set_error("ubd_comm_init: librccl lacks a required symbol"); free(c); return 2; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclResult_t r = init(&c->comm, world, id, rank);
@@ -124,6 +126,25 @@ extern "C" int ubd_broadcast_params(ubd_handle *h, float *params, size_t count, 
     ubd_comm *c = h->comm;
     UBD_REQUIRE(root >= 0 && root < c->world, "ubd_broadcast_params: root %d out of range", root);
     UBD_CHECK_NCCL(c, c->Broadcast(params, params, count, ncclFloat32, root, c->comm, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- hooks of the loss (loss.hip) with UBD_COMM_GLOBAL_LOSS ---------------------------------------------------------------
+bool ubd_comm_global_loss(const ubd_handle *h) { return h->comm && (h->comm->flags & UBD_COMM_GLOBAL_LOSS); }
+int ubd_comm_rank(const ubd_handle *h) { return h->comm ? h->comm->rank : 0; }
+
+int ubd_comm_allreduce_raw(ubd_handle *h, void *buf, size_t count, int kind, hipStream_t st)
+{
+    ubd_comm *c = h->comm;
+    const ncclDataType_t dt = kind == UBD_RED_F64 ? ncclFloat64 : (kind == UBD_RED_I32 ? ncclInt32 : ncclUint32);
+    UBD_CHECK_NCCL(c, c->AllReduce(buf, buf, count, dt, ncclSum, c->comm, st));
+    return 0;
+}
+
+int ubd_comm_allgather_u32(ubd_handle *h, const unsigned *send_one, unsigned *recv_world, hipStream_t st)
+{
+    ubd_comm *c = h->comm;
+    UBD_CHECK_NCCL(c, c->AllGather(send_one, recv_world, 1, ncclUint32, c->comm, st));
     return 0;
 }
 

@@ -128,6 +128,12 @@ struct ubd_fwd_layout {
 
 // ---- cross-file internals ------------------------------------------------------------------
 bool ubd_comm_fused(const ubd_handle *h);
+bool ubd_comm_global_loss(const ubd_handle *h);
+int ubd_comm_rank(const ubd_handle *h);
+enum { UBD_RED_F64 = 0, UBD_RED_I32 = 1, UBD_RED_U32 = 2 };
+int ubd_comm_allreduce_raw(ubd_handle *h, void *buf, size_t count, int kind, hipStream_t st);      // in-place SUM
+int ubd_comm_allgather_u32(ubd_handle *h, const unsigned *send_one, unsigned *recv_world, hipStream_t st);
+extern "C" int ubd_comm_world(const ubd_handle *h);
 int ubd_comm_begin_tail(ubd_handle *h, float *grads, hipStream_t st);
 int ubd_comm_finish(ubd_handle *h, float *grads, hipStream_t st);
 void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L);
@@ -137,7 +143,7 @@ void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const f
                         const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu);
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
-                  char *ws, hipStream_t st);
+                  char *ws, hipStream_t st, ubd_handle *h = nullptr);
 extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,

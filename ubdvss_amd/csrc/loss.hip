@@ -18,22 +18,21 @@
 #define LOSS_MAX_BLOCKS 256      // one block per CU: every block ends with ~50 same-address global atomics (header sums, non-empty bins)
 
 struct loss_hdr {
-    double sum_pos, sum_neg, sum_hard, sum_cls;   // 0..31
-    int n_pos;                                    // 32
+    double sum_pos, sum_neg, sum_hard, sum_cls;   // [0..3]: (sum_pos, sum_neg) and (sum_hard, sum_cls) are all-reduced pairwise
+    // counters, contiguous (all-reduced as 6 ints in the batch-global mode): positives, the detection confusion matrix with
+    // pred = logit0 > 0 (keras_metrics.py:110-172; fn = n_pos - tp), positive pixels whose class argmax equals the label
+    int n_pos, tp, tn, fp, spare, cls_correct;
     unsigned k;                                   // top-k size
     unsigned prefix_l[2];                         // radix-select prefix after level 0 / level 1
     unsigned k_rem_l[2];                          // rank still to resolve inside that prefix bin
     unsigned T;                                   // final threshold bits (k-th largest value)
     unsigned need_eq;                             // how many elements == T are selected
-    // per-batch pixel metrics (keras_metrics.py:110-172): detection confusion matrix with pred = logit0 > 0,
-    // and the number of positive pixels whose class argmax equals the label
-    int tp, tn, fp, fn, cls_correct;
-    unsigned pad[1];
+    unsigned pad[3];
 };
 #define LOSS_HDR_BYTES 256
 
 struct loss_layout {
-    size_t off_hdr, off_hist, off_blockties, off_ce, total;
+    size_t off_hdr, off_hist, off_blockties, off_rankties, off_ce, total;
 };
 
 static void loss_layout_compute(long npix, loss_layout *L)
@@ -42,6 +41,7 @@ static void loss_layout_compute(long npix, loss_layout *L)
     L->off_hdr = off;       off += LOSS_HDR_BYTES;
     L->off_hist = off;      off += 3 * 2048 * sizeof(unsigned);
     L->off_blockties = off; off += ubd_align_up((LOSS_MAX_BLOCKS + 1) * sizeof(unsigned), 256);
+    L->off_rankties = off;  off += 1024;                       // batch-global mode: tie counts of every rank (<= 256 ranks)
     L->off_ce = off;        off += ubd_align_up((size_t)npix * sizeof(float), 256);
     L->total = off;
 }
@@ -188,7 +188,7 @@ __device__ __forceinline__ loss_sel loss_select_block(loss_hdr *hdr, const unsig
 }
 
 // histogram of level `level` (1 or 2) over the elements inside the bin selected at level - 1 (prev_hist)
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__restrict__ ce_buf, long npix,
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__restrict__ ce_buf, long npix, long npix_total,
                                                                loss_hdr *hdr, const unsigned *__restrict__ prev_hist,
                                                                unsigned *__restrict__ hist, int level)
 {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__re
     __shared__ unsigned s_part[256];
     __shared__ loss_sel s_sel;
     for (int t = threadIdx.x; t < 2048; t += blockDim.x) s_hist[t] = 0;
-    const unsigned prefix = loss_select_block(hdr, prev_hist, level - 1, npix, s_part, &s_sel).prefix;
+    const unsigned prefix = loss_select_block(hdr, prev_hist, level - 1, npix_total, s_part, &s_sel).prefix;
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         const unsigned b = __float_as_uint(ce_buf[p]);
         if (level == 1) {
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_hist_kernel(const float *__re
 }
 
 // ---- ties: per-chunk count of elements == T (chunks are contiguous index ranges) --------------
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *__restrict__ ce_buf, long npix, long chunk,
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *__restrict__ ce_buf, long npix, long npix_total, long chunk,
                                                                    loss_hdr *hdr, const unsigned *__restrict__ hist2,
                                                                    unsigned *__restrict__ blockties)
 {
     __shared__ double s_red[LOSS_BLOCK / 64];
     __shared__ unsigned s_part[256];
     __shared__ loss_sel s_sel;
-    const unsigned T = loss_select_block(hdr, hist2, 2, npix, s_part, &s_sel).prefix;    // final threshold bits
+    const unsigned T = loss_select_block(hdr, hist2, 2, npix_total, s_part, &s_sel).prefix;    // final threshold bits
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
     int c = 0;
     for (long p = lo + threadIdx.x; p < hi; p += blockDim.x) c += (__float_as_uint(ce_buf[p]) == T);
@@ -249,19 +249,21 @@ __global__ __launch_bounds__(1024) void loss_tiescan_kernel(unsigned *blockties,
 __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
                                                                const int *__restrict__ y_true, long npix, long chunk,
                                                                loss_hdr *hdr, const unsigned *__restrict__ blockties,
-                                                               const float *__restrict__ ce_buf, float *__restrict__ dlogits)
+                                                               const float *__restrict__ ce_buf, float *__restrict__ dlogits,
+                                                               long npix_total, const unsigned *__restrict__ rank_ties, int rank)
 {
     __shared__ double s_red[LOSS_GRAD_BLOCK / 64];
     __shared__ unsigned s_wave_ties[LOSS_GRAD_BLOCK / 64];
     const unsigned T = hdr->T, need_eq = hdr->need_eq;
     const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
-    const long n_neg_l = npix - hdr->n_pos;
+    const long n_neg_l = npix_total - hdr->n_pos;
     const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
     const float w_pos = (float)(15.0 / n_pos), w_neg = (float)(1.0 / n_neg), w_hard = (float)(5.0 / (double)hdr->k);
     const float w_cls = (float)(1.0 / n_pos);
     const int n_cls = k_out - 1;
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
     unsigned tie_base = blockties[blockIdx.x];          // ties before this iteration of this block
+    for (int j = 0; j < rank; ++j) tie_base += rank_ties[j];    // batch-global mode: the ranks before this one hold the lower flat indices
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double s_hard = 0, s_cls = 0;
     int c_correct = 0;
@@ -357,28 +359,54 @@ __global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, 
     loss4[15] = 0.f;
 }
 
+// h != nullptr with a UBD_COMM_GLOBAL_LOSS communicator: the reductions of losses.py:86-126 (n_pos, n_neg, the two means, the
+// top-k over the flattened batch, the classification mean) run over the images of ALL ranks -- the reference's semantics at
+// the global batch (option 2).  Rank r holds the flat indices [r * npix, (r + 1) * npix) (equal shards).
+// Eight small collectives on the caller's stream: (sums, counters, level-0 histogram), the two refined histograms, the tie
+// counts (all-gather), (hard-negative / classification sums, class hits).  Integer histograms make every rank select the
+// same threshold bit pattern; ties at the threshold go to the lower GLOBAL flat index like tf.nn.top_k.
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
-                  char *ws, hipStream_t st)
+                  char *ws, hipStream_t st, ubd_handle *h)
 {
     loss_layout L;
     loss_layout_compute(npix, &L);
     loss_hdr *hdr = (loss_hdr *)(ws + L.off_hdr);
     unsigned *hist = (unsigned *)(ws + L.off_hist);
     unsigned *blockties = (unsigned *)(ws + L.off_blockties);
+    unsigned *rankties = (unsigned *)(ws + L.off_rankties);
     float *ce = (float *)(ws + L.off_ce);
+    const bool glob = h && ubd_comm_global_loss(h);
+    const int world = glob ? ubd_comm_world(h) : 1, rank = glob ? ubd_comm_rank(h) : 0;
+    UBD_REQUIRE(world <= 256, "ubd_loss: batch-global loss supports at most 256 ranks");
+    const long npix_total = npix * world;
+    UBD_REQUIRE(npix_total < (1L << 31), "ubd_loss: too many pixels in the global batch");
     UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_blockties, st));     // header + 3 histograms
     int grid = (int)((npix + LOSS_BLOCK - 1) / LOSS_BLOCK);
     if (grid > LOSS_MAX_BLOCKS) grid = LOSS_MAX_BLOCKS;
     long chunk = (npix + grid - 1) / grid;
     chunk = (chunk + LOSS_BLOCK - 1) / LOSS_BLOCK * LOSS_BLOCK;
     const int cgrid = (int)((npix + chunk - 1) / chunk);
+    int rc;
     hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_STATS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce);
-    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist, hist + 2048, 1);
-    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, hdr, hist + 2048, hist + 4096, 2);
-    hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, chunk, hdr, hist + 4096, blockties);
+    if (glob) {
+        if ((rc = ubd_comm_allreduce_raw(h, &hdr->sum_pos, 2, UBD_RED_F64, st))) return rc;
+        if ((rc = ubd_comm_allreduce_raw(h, &hdr->n_pos, 6, UBD_RED_I32, st))) return rc;
+        if ((rc = ubd_comm_allreduce_raw(h, hist, 2048, UBD_RED_U32, st))) return rc;
+    }
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, npix_total, hdr, hist, hist + 2048, 1);
+    if (glob && (rc = ubd_comm_allreduce_raw(h, hist + 2048, 2048, UBD_RED_U32, st))) return rc;
+    hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, npix_total, hdr, hist + 2048, hist + 4096, 2);
+    if (glob && (rc = ubd_comm_allreduce_raw(h, hist + 4096, 2048, UBD_RED_U32, st))) return rc;
+    hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, npix_total, chunk, hdr, hist + 4096, blockties);
     hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix, k_out - 1, loss);
+    if (glob && (rc = ubd_comm_allgather_u32(h, blockties + cgrid, rankties, st))) return rc;     // this rank's tie count -> everyone
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
+                       npix_total, rankties, rank);
+    if (glob) {
+        if ((rc = ubd_comm_allreduce_raw(h, &hdr->sum_hard, 2, UBD_RED_F64, st))) return rc;
+        if ((rc = ubd_comm_allreduce_raw(h, &hdr->cls_correct, 1, UBD_RED_I32, st))) return rc;
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix_total, k_out - 1, loss);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -391,5 +419,5 @@ extern "C" int ubd_loss(ubd_handle *h, const float *logits, const int32_t *y_tru
     const long npix = (long)n * map_h * map_w;
     UBD_REQUIRE(npix < (1L << 31), "ubd_loss: too many pixels");
     UBD_REQUIRE(workspace_bytes >= ubd_loss_workspace_bytes(h, n, map_h, map_w), "ubd_loss: workspace too small");
-    return ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, (char *)workspace, (hipStream_t)stream);
+    return ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, (char *)workspace, (hipStream_t)stream, h);
 }

@@ -58,11 +58,14 @@ def broadcast_parameters(flat_params, src=0, group=None):
         dist.broadcast(flat_params, src=src, group=group)
 
 
-def attach_native_comm(model, fused=True, group=None):
+def attach_native_comm(model, fused=True, group=None, global_loss=False):
     """Gives ``model``'s C-ABI handle its own RCCL communicator (include/ubd.h, ubd_comm_*): rank 0 creates the unique id,
     torch.distributed (already initialised, any backend) only carries those 128 bytes to the other ranks.  With ``fused``
     the train step all-reduces the gradients itself, overlapped with the stem layers' backward pass, and
-    ``Trainer.apply_gradients`` skips the torch collective.  Returns the world size.  Also valid for a single process."""
+    ``Trainer.apply_gradients`` skips the torch collective.  ``global_loss``: the loss reductions (n_pos, n_neg, means, the top-k
+    of the flattened batch, losses.py:86-126) run over the images of all ranks -- the reference's loss at the global batch
+    (option 2) -- and the gradients are summed, not averaged.  Returns the world size.  Also valid for a single
+    process."""
     import ctypes
     from . import _lib
     lib = _lib.load()
@@ -77,8 +80,10 @@ def attach_native_comm(model, fused=True, group=None):
         dist.broadcast(t, src=0, group=group)
         ctypes.memmove(buf, bytes(t.cpu().numpy().tobytes()), _lib.UBD_UNIQUE_ID_BYTES)
     with torch.cuda.device(model.device):
-        _lib.check(lib.ubd_comm_init(model._h, buf, r, w, _lib.UBD_COMM_FUSED if fused else 0), "ubd_comm_init")
+        flags = (_lib.UBD_COMM_FUSED if fused else 0) | (_lib.UBD_COMM_GLOBAL_LOSS if global_loss else 0)
+        _lib.check(lib.ubd_comm_init(model._h, buf, r, w, flags), "ubd_comm_init")
     model._native_comm = "fused" if fused else "explicit"
+    model._global_loss = bool(global_loss)
     return w
 
 

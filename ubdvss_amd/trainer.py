@@ -77,7 +77,9 @@ class Trainer:
                 with torch.cuda.device(self.model.device):
                     _lib.check(self._lib.ubd_allreduce_grads(self.model._h, self.grads.data_ptr(), self.grads.numel(),
                                                              self.model._stream()), "ubd_allreduce_grads")
-            grad_scale = 1.0 / world
+            # per-replica losses are averaged; the batch-global loss (UBD_COMM_GLOBAL_LOSS) is ONE objective whose parameter
+            # gradient is the sum of the ranks' contributions
+            grad_scale = 1.0 if getattr(self.model, "_global_loss", False) else 1.0 / world
         else:
             grad_scale = distributed.allreduce_gradients(self.grads, group=self._pg)
         self.iterations += 1
