@@ -499,7 +499,7 @@ def main():
         traffic = None
         try:
             vals = {}
-            for ln in open(os.path.join(ROOT, "profiles", "r01_pmc_dilconv_wino.txt")):
+            for ln in open(os.path.join(ROOT, "profiles", "r02_pmc_dilconv_wino.txt")):
                 parts = ln.split()
                 if len(parts) >= 2:
                     vals[parts[0]] = float(parts[1])
@@ -508,7 +508,7 @@ def main():
             traffic = None
         roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
-                    "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r01_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
+                    "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r02_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
                     "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
         fwd_hbm = {"bound": "hbm", "achieved": round(BATCH * BYTES_PER_IMAGE_FP32 / (net_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM,

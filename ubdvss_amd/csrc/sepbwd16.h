@@ -389,10 +389,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
                     const char *pd = draw + (dr * C::DCOLS + dc) * 48;
                     const u32x2 a = *(const u32x2 *)(pd + 8 * q);
-                    // channels 16+2q, 17+2q: a b64 read shared by the lane pair (q, q^1) + select; the b32 form has a
-                    // 32-bank map on which pixels i and i + 8 collide
-                    const u32x2 bb = *(const u32x2 *)(pd + 32 + 8 * (q >> 1));
-                    const unsigned b = (q & 1) ? bb[1] : bb[0];
+                    const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
                     if constexpr (UREG) {
                         const int t = ky * 3 + j;
                         acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
@@ -471,8 +468,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                             // raw 16-bit activation pairs x packed taps -> depthwise output; x packed dDW pairs -> ddw
                             const char *px = xraw + pix * 48;
                             const u32x2 a = *(const u32x2 *)(px + 8 * q);
-                            const u32x2 bb = *(const u32x2 *)(px + 32 + 8 * (q >> 1));
-                            const unsigned b = (q & 1) ? bb[1] : bb[0];
+                            const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
                             const u32x4 w4 = *(const u32x4 *)(wtp + t * UBD_C + 4 * q);
                             const u32x2 w2 = *(const u32x2 *)(wtp + t * UBD_C + 16 + 2 * q);
                             dwv[0] = dot2b<T>(a[0], w4[0], dwv[0]); dwv[1] = dot2b<T>(a[0], w4[1], dwv[1]);
@@ -504,11 +500,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // dpw[ch][co] += sum over the 32 pixels DW[pixel][ch] G[pixel][co]; an all-ones column of the A operand gives db.
-            // Transposed reads: lane 4qq+pp of group grp supplies the address of ONE pixel k, segment pp.  K = pixel is a
-            // summation index, so any lane -> pixel bijection used for both operands is valid; the 32 lanes of an LDS
-            // group (grp 0,1 / grp 2,3) take the 8 even / the 8 odd pixels of a 16-pixel row: with the 12-dword pixel pitch
-            // their 8-dword windows (24 m mod 64, m = 0..7) tile the 64 banks exactly (the natural order 8 grp + 4 j + qq
-            // made pixels k and k + 8 collide: 28-42 % of the LDS cycles of round 1, profiles/r01_pmc_sepb16_*.txt).
+            // Transposed reads: lane 4qq+pp of group grp supplies the address of pixel k = 8 grp + 4 j + qq, segment pp.
             {
                 u32x4 am[MT_PW], bn[2];
 #pragma unroll
@@ -516,7 +508,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     s16x4 h[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int k = 2 * (4 * (grp & 1) + qq) + (grp >> 1) + 16 * j;
+                        const int k = 8 * grp + 4 * j + qq;
                         const char *pa;
                         if constexpr (CIN == UBD_C) pa = mt == 0 ? sdw + k * 48 + 8 * pp : (pp < 2 ? sdw + k * 48 + 32 + 8 * pp : (pp == 2 ? c_ones : c_zero));
                         else pa = pp == 0 ? sdw + k * (C::SDW_W * 2) : c_zero;
@@ -529,7 +521,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     s16x4 h[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int k = 2 * (4 * (grp & 1) + qq) + (grp >> 1) + 16 * j;
+                        const int k = 8 * grp + 4 * j + qq;
                         const char *pg = g16 + (((k < 16 ? r0 : r1) * 16 + (k & 15)) * 48);
                         const char *pb = nt == 0 ? pg + 8 * pp : (pp < 2 ? pg + 32 + 8 * pp : c_zero);
                         h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
