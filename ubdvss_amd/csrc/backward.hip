@@ -815,6 +815,14 @@ __global__ __launch_bounds__(256) void sep_dx_kernel(const float *__restrict__ d
     }
 }
 
+#ifdef UBD_STAMPS   // diagnostic build only: one stamp buffer per (CIN, STRIDE) variant of sepb16_kernel, selected by the caller
+static unsigned long long *g_sepb_stamps = nullptr;
+static int g_sepb_stamps_cin = 0, g_sepb_stamps_stride = 0;
+extern "C" void ubd_debug_set_stamps_sepb(void *p, int cin, int stride) { g_sepb_stamps = (unsigned long long *)p; g_sepb_stamps_cin = cin; g_sepb_stamps_stride = stride; }
+#define SB_STAMP_ARG , ((CIN == g_sepb_stamps_cin && STRIDE == g_sepb_stamps_stride) ? g_sepb_stamps : nullptr)
+#else
+#define SB_STAMP_ARG
+#endif
 #include "sepbwd16.h"
 
 // ------------------------------------------------------------------------------------ host
@@ -885,9 +893,9 @@ static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const u
     int grid = h->num_cus * C::BLOCKS_PER_CU;
     if (grid > tiles) grid = (int)tiles;
     if (in_u8)
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
     else
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
 }
 

@@ -52,7 +52,13 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int OFF_WT = OFF_SDW + NW * SDW_BYTES;        // own depthwise taps [9][24] fp32 (24-channel layers)
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
     static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,16): zeros
-    static constexpr int LDS_BYTES = OFF_CONST + 16;
+    // interior-tile byte offset of every X-patch chunk (24-channel kernels): the per-piece address arithmetic of the staging
+    // (c -> pixel -> row / column -> offset: ~40 vector instructions per 1 KiB piece, 3-4 k cycles per tile and wave in the
+    // stamps of round 2) becomes one LDS read
+    static constexpr int OFF_XREL = OFF_CONST + 16;
+    static constexpr bool XTAB = (CIN == UBD_C) && (STRIDE == 2);     // the stride-1 kernel sits exactly at its 168-VGPR budget: the table path spills there
+    static constexpr int XREL_BYTES = XTAB ? XI * 64 * 4 : 0;
+    static constexpr int LDS_BYTES = OFF_XREL + XREL_BYTES;
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
     // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
     static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : 2);
@@ -118,8 +124,18 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
                                                         int W, int OH, int OW, int pad_lo, int DH, int DW_, int pad_up, float pre_sub,
-                                                        float pre_div)
+                                                        float pre_div
+#ifdef UBD_STAMPS
+                                                        , unsigned long long *__restrict__ stamps
+#endif
+                                                        )
 {
+#ifdef UBD_STAMPS   // diagnostic build only: s_memtime of lane 0 of every wave at the phase boundaries of its first 8 tiles
+    int stamp_it = 0;
+#define SBSTAMP(k) do { if (stamps && stamp_it < 8 && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SBSTAMP(k) do {} while (0)
+#endif
     using C = sepb16_cfg<CIN, STRIDE, GSRC>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;
@@ -141,6 +157,14 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             ((unsigned short *)sdw)[t] = col == CIN ? __builtin_bit_cast(unsigned short, (T)1.0f) : (unsigned short)0;
         }
     }
+    int *xrel_tab = (int *)(lds + C::OFF_XREL);
+    if constexpr (C::XTAB)
+        for (int c = threadIdx.x; c < C::XI * 64; c += C::NT) {
+            const int cc = c < C::XCHUNKS ? c : C::XCHUNKS - 1;
+            const int pix = cc / 3, part = cc - pix * 3;
+            const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            xrel_tab[c] = (pr * W + pc) * (UBD_C * 2) + part * 16;
+        }
     unsigned *wtp = (unsigned *)(lds + C::OFF_WT);                          // own taps [9][24], packed like utp
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
@@ -300,11 +324,22 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         const geom g = tile_geom(tile);
         const int img = g.img, oy0 = g.oy0, ox0 = g.ox0, ix0 = g.ix0, iy0 = g.iy0, dy0 = g.dy0, dx0 = g.dx0;
         const bool xborder = g.xborder, dborder = g.dborder;
+        SBSTAMP(0);
         __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
+        SBSTAMP(1);
         if constexpr (!D_AHEAD) stage_dm(g);
-        if constexpr (CIN == UBD_C)
-            sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
-        else {
+        if constexpr (CIN == UBD_C) {
+            if (C::XTAB && !xborder) {                                 // block-uniform: offsets from the LDS table
+                const char *origin = (const char *)xin + (((long)img * H + iy0) * W + ix0) * (UBD_C * 2);
+#pragma unroll
+                for (int k = 0; k < C::XK; ++k) {
+                    const int instr = k * C::NW + wid;
+                    if (instr < C::XI) ubd_glds16(origin + xrel_tab[instr * 64 + lane], dma + instr * 1024);
+                }
+            } else {
+                sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
+            }
+        } else {
 #pragma unroll
             for (int k = 0; k < C::XREGS; ++k) {
                 const int e = k * C::NT + (int)threadIdx.x;
@@ -333,8 +368,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
         // The DMA is issued as asm (ubd_glds16, common.h): hipcc neither waits for it here nor drains the NEXT tile's D
         // DMA in front of phase 2's LDS accesses (it did with the builtin: every tile waited a full fetch latency there).
+        SBSTAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this tile's DMA (and the mask loads) have landed
         __syncthreads();                                               // ... for every wave; LDS writes visible
+        SBSTAMP(3);
         {
             if ((CIN == UBD_C && xborder) || dborder) {                // block-uniform
                 const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -359,9 +396,23 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                 __syncthreads();
             }
         }
+        SBSTAMP(4);
         // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
         if constexpr (GSRC != 0) {
         constexpr int P1_UNROLL = MPRE ? C::TH / C::NW : 1;
+        // register-bound 1/3-channel kernel: no room for all rows' masks, so the mask of row kr + 1 is requested while row kr
+        // runs its 54 tap products (fetched in place it exposed a global-load latency per row: 6.6 k of the tile's 14.8 k cycles)
+        u32x2 ma_nx = {0u, 0u};
+        unsigned mb_nx = 0u;
+        auto fetch_mask = [&](int r, u32x2 &a, unsigned &b) {
+            a = u32x2{0u, 0u}; b = 0u;
+            if (oy0 + r < OH && ox0 + i < OW) {
+                const char *pm = (const char *)maskact + (((size_t)img * OH + oy0 + r) * OW + ox0 + i) * (UBD_C * 2);
+                a = *(const u32x2 *)(pm + 8 * q);
+                b = *(const unsigned *)(pm + 32 + 4 * q);
+            }
+        };
+        if constexpr (!MPRE) fetch_mask(wid, ma_nx, mb_nx);
 #pragma unroll P1_UNROLL
         for (int kr = 0; kr < C::TH / C::NW; ++kr) {
             const int r = wid + C::NW * kr;
@@ -369,10 +420,9 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             u32x2 ma = {0u, 0u};
             unsigned mb = 0u;
             if constexpr (MPRE) { ma = mka[kr]; mb = mkb[kr]; }
-            else if (oy0 + r < OH && ox0 + i < OW) {                 // register-bound 1/3-channel kernel: fetched in place
-                const char *pm = (const char *)maskact + (((size_t)img * OH + oy0 + r) * OW + ox0 + i) * (UBD_C * 2);
-                ma = *(const u32x2 *)(pm + 8 * q);
-                mb = *(const unsigned *)(pm + 32 + 4 * q);
+            else {
+                ma = ma_nx; mb = mb_nx;
+                if (kr + 1 < C::TH / C::NW) fetch_mask(r + C::NW, ma_nx, mb_nx);
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -417,7 +467,9 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             *(unsigned *)(pg + 32 + 4 * q) = g2;
         }
         }
+        SBSTAMP(5);
         __syncthreads();
+        SBSTAMP(6);
         if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
             const geom gn = tile_geom(tile + gridDim.x);
             if constexpr (D_AHEAD) stage_dm(gn);
@@ -535,7 +587,12 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             }
             __builtin_amdgcn_wave_barrier();
         }
+        SBSTAMP(7);
+#ifdef UBD_STAMPS
+        ++stamp_it;
+#endif
     }
+#undef SBSTAMP
     // ---- flush: wave-sequential reduction of the per-lane sums into this block's row of the partial-sum matrix
     //      row layout: [9*CIN depthwise | CIN*24 pointwise | 24 bias]
     __syncthreads();
