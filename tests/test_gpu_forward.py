@@ -252,14 +252,15 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
 
 
 def test_fused_stem_path(monkeypatch):
-    """UBD_STEM=fused runs L2 -> L3 of an inference pass as ONE kernel (L2's output stays in LDS, stem23.h) instead of the
-    two separate kernels (the default, and what training runs).  Same oracle, same bounds, and the two paths agree to
-    fp32 rounding; UBD_TEST_NUM_CUS=2 in a second round makes every block walk many tiles (2-tile-ahead DMA ring)."""
-    cases = ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100), (3, 1, True, 3, 64, 200), (3, 0, False, 1, 8, 8), (1, 0, True, 2, 4, 36))
+    """Inference runs L2 -> L3 as ONE kernel with L2's output in LDS (stem23.h; default with the fml padding, UBD_STEM=fused
+    forces it for TF 'same' padding too) instead of the two separate kernels (UBD_STEM=unfused; what training runs).  Same
+    oracle, same bounds, the two paths agree to fp32 rounding; UBD_TEST_NUM_CUS=2 in a third round makes every block walk
+    several strips of tiles (2-tile-ahead DMA ring, the carried 33rd column across tiles and strip starts)."""
+    cases = ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100), (3, 1, True, 3, 64, 200), (3, 0, False, 1, 8, 8), (1, 0, True, 2, 4, 36),
+             (3, 0, True, 2, 96, 512), (3, 0, False, 2, 40, 264))
     outs = {}
     for mode in ("unfused", "fused", "fused_few_cus"):
-        if mode != "unfused":
-            monkeypatch.setenv("UBD_STEM", "fused")
+        monkeypatch.setenv("UBD_STEM", "unfused" if mode == "unfused" else "fused")
         if mode == "fused_few_cus":
             monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
         for cin, ncls, fml, n, hh, ww in cases:

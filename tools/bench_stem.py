@@ -8,8 +8,7 @@ cfg = NetConfig(grey=False)
 x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
 models = {}
 for mode in ("fused", "unfused"):
-    if mode == "fused": os.environ["UBD_STEM"] = "fused"
-    else: os.environ.pop("UBD_STEM", None)
+    os.environ["UBD_STEM"] = mode
     models[mode] = Model(cfg, seed=1)
 def timed(fn, reps):
     fn(); torch.cuda.synchronize()

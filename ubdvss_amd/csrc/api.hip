@@ -39,15 +39,14 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     {
         const char *e = getenv("UBD_DILCONV");
         h->use_wino = !(e && strcmp(e, "direct") == 0);
-        // UBD_STEM=fused: inference runs L2 -> L3 as one kernel with L2's output in LDS (stem23.h).  Measured equal to the
-        // two separate kernels (121-141 us vs 134 us at 32 x 512 x 512: the fused kernel is bound by instruction issue, not by
-        // HBM), so the separate kernels -- which training needs anyway -- stay the default.
+        // Inference runs L2 -> L3 as ONE kernel with L2's output in LDS (stem23.h) when the model uses the fml padding (the
+        // variant that inherits the 33rd L2 column from the tile to its left: 0.405 vs 0.417 ms per forward pass at
+        // 32 x 512 x 512); with TF 'same' padding the fused kernel only ties the two separate kernels and they
+        // stay the default.  UBD_STEM=fused / unfused overrides either way.  Training always runs the separate kernels.
         const char *s = getenv("UBD_STEM");
-        h->fuse_stem = (s && strcmp(s, "fused") == 0);
-        // test hook: pretend the device has fewer CUs, so that every persistent kernel walks many tiles per block even
-        // on the small shapes the CPU oracle can check (tests/test_gpu_persistent.py)
-        const char *c = getenv("UBD_TEST_NUM_CUS");
-        if (c && atoi(c) > 0) h->num_cus = atoi(c);
+        h->fuse_stem = cfg->fml_compatible != 0;
+        if (s && strcmp(s, "fused") == 0) h->fuse_stem = 1;
+        if (s && strcmp(s, "unfused") == 0) h->fuse_stem = 0;
     }
     // Keras model.get_weights() order
     size_t off = 0;

@@ -21,7 +21,7 @@ struct ubd_handle {
     size_t n_params;
     int num_cus;
     int pp_lds_attr_set;      // pp_front_lds_kernel's dynamic-LDS limit has been raised on this handle's device
-    int fuse_stem;            // 1: inference runs L2 -> L3 as one kernel with L2's output in LDS (UBD_STEM=fused), 0: separate kernels (default)
+    int fuse_stem;            // 1: inference runs L2 -> L3 as one kernel with L2's output in LDS (default with fml padding; UBD_STEM=fused|unfused)
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
 };
 
@@ -46,13 +46,26 @@ __device__ __forceinline__ int ubd_xcd_tile(int L, int total)
 // fetch latency in every kernel that touches LDS while the next tile's DMA is in flight.  The asm form is outside hipcc's
 // bookkeeping: the caller retires it with its own counted `s_waitcnt vmcnt(N)` + barrier before the staged bytes are read
 // (cdna_hip_programming.md, "What hipcc does not do").  lds_dst: wave-uniform LDS byte address (readfirstlane'd here).
-__device__ __forceinline__ void ubd_glds16(const void *gsrc, const void *lds_generic)
+// lds_dst: wave-uniform LDS byte address (ubd_lds_addr of the block's LDS object + an offset kept in scalar registers; the
+// generic-pointer form below costs a 64-bit VGPR pair per piece when hipcc hoists it out of a loop)
+__device__ __forceinline__ void ubd_glds16_at(const void *gsrc, unsigned lds_dst)
 {
-    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// same with a wave-uniform 64-bit base in scalar registers + a 32-bit per-lane byte offset (no 64-bit vector address arithmetic)
+__device__ __forceinline__ void ubd_glds16_sbase(const void *base_uniform, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base_uniform), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned ubd_lds_addr(const void *lds_generic)
+{
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);
+}
+__device__ __forceinline__ void ubd_glds16(const void *gsrc, const void *lds_generic) { ubd_glds16_at(gsrc, ubd_lds_addr(lds_generic)); }
 #endif
 
 #if defined(__HIPCC__)

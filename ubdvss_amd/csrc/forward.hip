@@ -777,15 +777,20 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     float *cur = (float *)(ws + L.off_acts[0]);
     if (inference && h->fuse_stem) {
         // L2 -> L3 in one kernel: L2's activation stays in LDS (stem23.h); the a2 buffer is not touched
-        const int tiles = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3) * ((W4 + 15) / 16);
-        int grid = h->num_cus;                                   // one 8-wave block per CU (118 KB of LDS)
-        if (grid > tiles) grid = tiles;
-        hipLaunchKernelGGL(stem23_kernel, dim3(grid), dim3(s23_cfg::NT), 0, st, a1, cur, sf1, params + h->off_sep_b[1], sf2, params + h->off_sep_b[2],
-                           n, H2, W2, H4, W4, pad_s2
+        const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);   // a block walks whole row strips of tiles
+        int grid = h->num_cus;                                   // one 8-wave block per CU (120 KB of LDS)
+        if (grid > strips) grid = strips;
 #ifdef UBD_STAMPS
-                           , g_ubd_stamps
+#define S23_STAMP_ARG , g_ubd_stamps
+#else
+#define S23_STAMP_ARG
 #endif
-                           );
+        if (pad_s2)
+            hipLaunchKernelGGL(stem23_kernel<true>, dim3(grid), dim3(s23_cfg::NT), 0, st, a1, cur, sf1, params + h->off_sep_b[1], sf2, params + h->off_sep_b[2],
+                               n, H2, W2, H4, W4, pad_s2 S23_STAMP_ARG);
+        else
+            hipLaunchKernelGGL(stem23_kernel<false>, dim3(grid), dim3(s23_cfg::NT), 0, st, a1, cur, sf1, params + h->off_sep_b[1], sf2, params + h->off_sep_b[2],
+                               n, H2, W2, H4, W4, pad_s2 S23_STAMP_ARG);
     } else {
         launch_sep<UBD_C, 1>(h, a1, 0, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
         launch_sep<UBD_C, 2>(h, a2, 0, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);

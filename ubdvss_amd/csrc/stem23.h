@@ -38,9 +38,13 @@ struct s23_cfg {
     static constexpr int L2_FLOATS = LR * LC * LP;
     static constexpr int W3PW_FLOATS = 2 * 64 * 8;             // L3 pointwise fragments: [nt][lane][s (6, +2 pad)]
     static constexpr int W3DW_FLOATS = 4 * 9 * 8;              // L3 depthwise taps per channel quarter: [q][tap][6 (+2 pad)]
-    static constexpr int SMEM_FLOATS = 2 * BUF_FLOATS + L2_FLOATS + W3PW_FLOATS + W3DW_FLOATS;
+    static constexpr int CARRY_FLOATS = 2 * LR * LP;           // position 32 of the previous tile, two generations
+    static constexpr int SMEM_FLOATS = 2 * BUF_FLOATS + L2_FLOATS + W3PW_FLOATS + W3DW_FLOATS + CARRY_FLOATS;
 };
 
+// CARRY: fml padding (pad_lo = 1): the 33rd L2 column is inherited from the tile to the left; otherwise (TF 'same' at stride 2,
+// pad_lo = 0) it is the column to the RIGHT of the tile and is computed as one more MFMA unit.
+template <bool CARRY>
 __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__restrict__ a1, float *__restrict__ y,
                                                         const float *__restrict__ frag2, const float *__restrict__ bias2,
                                                         const float *__restrict__ frag3, const float *__restrict__ bias3,
@@ -88,35 +92,25 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
     const f32x4 b2A = *(const f32x4 *)(bias2 + 4 * q), b2B = q < 2 ? *(const f32x4 *)(bias2 + 16 + 4 * q) : z4;
     const f32x4 b3A = *(const f32x4 *)(bias3 + 4 * q), b3B = q < 2 ? *(const f32x4 *)(bias3 + 16 + 4 * q) : z4;
 
-    // ---- tile sequence of this block: logical indices L = blockIdx.x + k * gridDim.x mapped XCD-aware (ubd_xcd_tile).
-    // When the map is affine in k (tile count and grid multiples of 8, or the identity map) the (tx, ty, img) triple
-    // advances by a constant step with carries; otherwise it is recomputed with divisions (small grids only).
+    // ---- tile sequence of this block: whole row STRIPS of tiles (strip = (image, tile row); logical strips blockIdx.x,
+    // + gridDim.x, ... mapped XCD-aware like ubd_xcd_tile), the tiles of a strip from left to right.  Walking a strip in x
+    // order lets a tile inherit its leftmost L2 column (position 0 = column 2*ox0 - 1 with the fml padding) from the tile
+    // before it -- that column is the previous tile's position 32 -- instead of computing it as a 19th MFMA unit.
     const int tiles_x = (W4 + 15) >> 4, tiles_y = (H4 + C::TH3 - 1) / C::TH3;
-    const int total = n * tiles_y * tiles_x;
+    const int strips = n * tiles_y;
     const int G = (int)gridDim.x;
-    const bool remap = (total & 7) == 0;
-    const bool affine = !remap || (G & 7) == 0;
-    const int step = remap ? (G >> 3) : G;
-    const int step_x = (int)((unsigned)step % (unsigned)tiles_x), step_r = (int)((unsigned)step / (unsigned)tiles_x);
-    const int step_y = (int)((unsigned)step_r % (unsigned)tiles_y), step_i = (int)((unsigned)step_r / (unsigned)tiles_y);
-    struct tpos { int tx, ty, img; };
-    ubd_tile_decoder tdec;
-    tdec.init(tiles_x, tiles_y, total);
-    auto decode = [&](int L) {
+    struct tpos { int tx, ty, img, ls; };                                          // ls: logical strip index (>= strips: past the end)
+    auto strip_pos = [&](int ls, int tx) {
         tpos p;
-        tdec.decode(L, p.tx, p.ty, p.img);
+        const int sidx = ubd_xcd_tile(ls < strips ? ls : strips - 1, strips);
+        p.ty = (int)((unsigned)sidx % (unsigned)tiles_y);
+        p.img = (int)((unsigned)sidx / (unsigned)tiles_y);
+        p.tx = tx; p.ls = ls;
         return p;
     };
-    auto advance = [&](tpos p, int L_next) {
-        if (!affine) return decode(L_next < total ? L_next : total - 1);
-        p.tx += step_x;
-        int c = p.tx >= tiles_x ? 1 : 0;
-        p.tx -= c ? tiles_x : 0;
-        p.ty += step_y + c;
-        c = p.ty >= tiles_y ? 1 : 0;
-        p.ty -= c ? tiles_y : 0;
-        p.img += step_i + c;
-        return p;
+    auto advance = [&](tpos p) {
+        if (p.tx + 1 < tiles_x) { ++p.tx; return p; }
+        return strip_pos(p.ls + G, 0);
     };
 
     // ---- LDS-DMA of one a1 patch = 37 pieces of 1 KiB (64 chunks of 16 B).  In the steady state waves 4-7 issue them (10, 9,
@@ -139,30 +133,39 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
         }
         return (const char *)a1 + ((((size_t)img * H2 + gy) * W2 + gx) * UBD_C + part * 4) * sizeof(float);
     };
-    int dma_rel[MAXP];                                                              // interior tiles: byte offset from the patch origin
+    unsigned dma_rel[MAXP];                                                         // interior tiles: byte offset from the patch origin (>= 0)
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) dma_rel[k] = (int)(chunk_src(my_first + (k < my_count ? k : 0), 0, 0, 0, true) - (const char *)a1);
+    for (int k = 0; k < MAXP; ++k) dma_rel[k] = (unsigned)(chunk_src(my_first + (k < my_count ? k : 0), 0, 0, 0, true) - (const char *)a1);
+    const unsigned lds_base = ubd_lds_addr(smem);
     auto dma_tile = [&](tpos p, float *patch, bool steady) {
+        const unsigned lds_patch = lds_base + (unsigned)(patch - smem) * 4u;        // wave-uniform
         const int iy0 = 2 * p.ty * C::TH3 - pad_lo - 1, ix0 = 32 * p.tx - pad_lo - 1;   // a1 pixel of patch (0, 0)
         const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + C::PH <= H2) && (ix0 + C::PW <= W2);   // block-uniform
         if (!steady) {                                                              // prologue: piece = wid, wid + 8, ...
-            for (int piece = wid; piece < PIECES; piece += C::NW) ubd_glds16(chunk_src(piece, iy0, ix0, p.img, interior), patch + piece * 256);
+            for (int piece = wid; piece < PIECES; piece += C::NW) ubd_glds16_at(chunk_src(piece, iy0, ix0, p.img, interior), lds_patch + (unsigned)piece * 1024u);
             return;
         }
         const char *origin = (const char *)a1 + (((size_t)p.img * H2 + iy0) * W2 + ix0) * (UBD_C * sizeof(float));
+        if (interior) {                                                             // scalar base + 32-bit lane offset
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (k < my_count)                                                       // wave-uniform
-                ubd_glds16(interior ? origin + dma_rel[k] : chunk_src(my_first + k, iy0, ix0, p.img, false), patch + (my_first + k) * 256);
+            for (int k = 0; k < MAXP; ++k)
+                if (k < my_count) ubd_glds16_sbase(origin, dma_rel[k], lds_patch + (unsigned)(my_first + k) * 1024u);   // wave-uniform count
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < my_count; ++k)
+                ubd_glds16_at(chunk_src(my_first + k, iy0, ix0, p.img, false), lds_patch + (unsigned)(my_first + k) * 1024u);
+        }
     };
 
     // ---- per-lane LDS read offsets (floats) of phase A: patch pixel (rb + yy, pos + kx), 16-byte chunk c in slot
     //      (c + 3f) % 6, f = (patch column >> 3) & 1; constant for the whole launch
-    // rows of the 9: column half 0 -> waves 0,2,4,6 take {0-2, 3-4, 5-6, 7-8}; half 1 -> waves 1,3,5 take {0-2, 3-5, 6-8} and
-    // wave 7 only computes the 33rd column (which costs about two rows: 18 LDS reads with 2-way conflicts)
+    // rows of the 9: each column half is split {0-2, 3-4, 5-6, 7-8} over its four waves when the 33rd column is inherited
+    // (fml padding); otherwise half 1 is split {0-2, 3-5, 6-8} over waves 1, 3, 5 and wave 7 computes the 33rd column (about
+    // two rows' worth: 18 LDS reads with 2-way conflicts)
+    constexpr bool carry = CARRY;
     const int half = wid & 1, rg = wid >> 1;
-    const int rb = half == 0 ? (rg == 0 ? 0 : 2 * rg + 1) : (rg < 3 ? 3 * rg : 0);
-    const int rw = half == 0 ? (rg == 0 ? 3 : 2) : (rg < 3 ? 3 : 0);
+    const int rb = (half == 0 || carry) ? (rg == 0 ? 0 : 2 * rg + 1) : (rg < 3 ? 3 * rg : 0);
+    const int rw = (half == 0 || carry) ? (rg == 0 ? 3 : 2) : (rg < 3 ? 3 : 0);
     const int pos = pad_lo + 16 * half + i;                                         // this lane's position column
     auto slot_off = [&](int prow, int pcol, int &o4, int &o2) {
         const int rot = 3 * ((pcol >> 3) & 1);
@@ -182,18 +185,18 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
     const int l2w = (rb * C::LC + pos) * C::LP + 4 * q;                             // phase A write offset of (row rb, this lane)
     const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;                        // phase B read offset of tap (0, 0)
 
-    if (blockIdx.x >= (unsigned)total) return;
+    float *carry_buf = w3dw + C::W3DW_FLOATS;                                       // [2][LR][LP]: position 32 of the previous tile
+    if ((int)blockIdx.x >= strips) return;
     __syncthreads();                                                                // weight tables written
-    tpos cur = decode(blockIdx.x);
-    tpos nx1 = advance(cur, blockIdx.x + G);
+    tpos cur = strip_pos(blockIdx.x, 0);
+    tpos nx1 = advance(cur);
     dma_tile(cur, smem, false);
-    if ((int)blockIdx.x + G < total) dma_tile(nx1, smem + C::BUF_FLOATS, false);
-    int L = blockIdx.x;
+    if (nx1.ls < strips) dma_tile(nx1, smem + C::BUF_FLOATS, false);
     for (int it = 0;; ++it) {
         const float *patch = smem + (it & 1) * C::BUF_FLOATS;
         const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
-        const bool has_next = L + G < total, has_next2 = L + 2 * G < total;         // block-uniform
-        const tpos nx2 = advance(nx1, L + 2 * G);
+        const tpos nx2 = advance(nx1);
+        const bool has_next = nx1.ls < strips, has_next2 = has_next && nx2.ls < strips;   // block-uniform
         const int R0 = 2 * oy0 - pad_lo, C0 = 2 * ox0 - pad_lo;                     // L2 pixel of position (0, 0)
         // This tile's patch has landed.  The DMA is issued as asm (ubd_glds16): hipcc neither drains it in front of the LDS
         // writes of phase A nor waits for it anywhere -- these counted waits are the only ones.  Outstanding on waves 4-7,
@@ -275,10 +278,26 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
                         float *dst = l2 + l2w + o * (C::LC * C::LP);
                         *(f32x4 *)dst = acc0;
                         if (q < 2) *(f32x4 *)(dst + 16) = acc1;
+                        if (CARRY && half == 1 && i == 15) {                        // position 32: the next tile's position 0
+                            float *cd = carry_buf + ((it & 1) * C::LR + rb + o) * C::LP + 4 * q;
+                            *(f32x4 *)cd = acc0;
+                            if (q < 2) *(f32x4 *)(cd + 16) = acc1;
+                        }
                     }
                 }
             }
-            if (wid == C::NW - 1) {
+            if constexpr (CARRY) if (wid == C::NW - 1) {
+                // position 0 (column 2*ox0 - 1): the previous tile's position 32, or L3's zero padding at the left image edge.
+                // The previous generation of the carry buffer is not written during this tile; the L2 image's column 0 is only
+                // read in phase B.
+                if (lane < C::LR * 6) {
+                    const int row = lane / 6, ch4 = lane - row * 6;
+                    f32x4 v = z4;
+                    if (cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);
+                    *(f32x4 *)(l2 + (row * C::LC) * C::LP + 4 * ch4) = v;
+                }
+            }
+            if constexpr (!CARRY) if (wid == C::NW - 1) {
                 // the 33rd column: lane i <-> position row i (9 of 16 lanes carry a pixel)
                 float dv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -309,13 +328,6 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
                 }
             }
         }
-        // waves 0-3: L3's weights (LDS tables, independent of the L2 image) are requested before the barrier
-        // (the b128 halves: 36 registers; the rest follows after the barrier, under the latency of the data reads)
-        f32x4 w3a[9];
-        if (wid < 4) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) w3a[t] = *(const f32x4 *)(w3dw + (q * 9 + t) * 8);
-        }
         __builtin_amdgcn_s_waitcnt(0xC07F);                                         // lgkmcnt(0): the L2 image is written
         UBD_STAMP(4);
         __builtin_amdgcn_s_barrier();                                               // ... by everyone; this tile's patch buffer is free
@@ -332,8 +344,9 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
                     const float *p = l2 + l2r + (ky * C::LC + kx) * C::LP;
                     const f32x4 v4 = *(const f32x4 *)(p + 4 * q);
                     const f32x2 v2 = *(const f32x2 *)(p + 16 + 2 * q);
-                    const f32x4 w4 = w3a[ky * 3 + kx];
-                    const f32x2 w2 = *(const f32x2 *)(w3dw + (q * 9 + ky * 3 + kx) * 8 + 4);
+                    const float *wt = w3dw + (q * 9 + ky * 3 + kx) * 8;
+                    const f32x4 w4 = *(const f32x4 *)wt;
+                    const f32x2 w2 = *(const f32x2 *)(wt + 4);
                     dv[0] = fmaf(v4[0], w4[0], dv[0]); dv[1] = fmaf(v4[1], w4[1], dv[1]);
                     dv[2] = fmaf(v4[2], w4[2], dv[2]); dv[3] = fmaf(v4[3], w4[3], dv[3]);
                     dv[4] = fmaf(v2[0], w2[0], dv[4]); dv[5] = fmaf(v2[1], w2[1], dv[5]);
@@ -353,7 +366,6 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem23_kernel(const float *__r
         if (wid >= 4 && has_next2) dma_tile(nx2, smem + (it & 1) * C::BUF_FLOATS, true);
         UBD_STAMP(7);
         if (!has_next) break;
-        L += G;
         cur = nx1;
         nx1 = nx2;
     }
