@@ -252,16 +252,18 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
 
 
 def test_fused_stem_path(monkeypatch):
-    """Inference runs L2 -> L3 as ONE kernel with L2's output in LDS (stem23.h; default with the fml padding, UBD_STEM=fused
-    forces it for TF 'same' padding too) instead of the two separate kernels (UBD_STEM=unfused; what training runs).  Same
-    oracle, same bounds, the two paths agree to fp32 rounding; UBD_TEST_NUM_CUS=2 in a third round makes every block walk
-    several strips of tiles (2-tile-ahead DMA ring, the carried 33rd column across tiles and strip starts)."""
+    """Inference stem variants (UBD_STEM): "fused123" = L1 -> L2 -> L3 in ONE kernel, neither intermediate activation ever in
+    memory (stem123.h; the default with the fml padding), "fused" = L1, then L2 -> L3 fused (stem23.h), "unfused" = three
+    kernels (what training runs).  Same oracle, same bounds, all variants agree to fp32 rounding; UBD_TEST_NUM_CUS=2 makes every
+    block walk several strips of tiles (register prefetch of the next input patch, the carried 33rd column across tiles and strip
+    starts); uint8 input with the fused preprocessing and grey input go through the one-kernel stem too."""
+    from ubdvss_amd import PreprocessingType
     cases = ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100), (3, 1, True, 3, 64, 200), (3, 0, False, 1, 8, 8), (1, 0, True, 2, 4, 36),
-             (3, 0, True, 2, 96, 512), (3, 0, False, 2, 40, 264))
+             (3, 0, True, 2, 96, 512), (3, 0, False, 2, 40, 264), (1, 1, True, 2, 136, 72))
     outs = {}
-    for mode in ("unfused", "fused", "fused_few_cus"):
-        monkeypatch.setenv("UBD_STEM", "unfused" if mode == "unfused" else "fused")
-        if mode == "fused_few_cus":
+    for mode in ("unfused", "fused", "fused123", "fused123_few_cus"):
+        monkeypatch.setenv("UBD_STEM", mode.replace("_few_cus", ""))
+        if mode.endswith("few_cus"):
             monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
         for cin, ncls, fml, n, hh, ww in cases:
             w = onet.init_weights(400 + cin + ncls, cin, ncls, bias_scale=0.25)
@@ -270,7 +272,13 @@ def test_fused_stem_path(monkeypatch):
             lg = _model(cin, ncls, fml, w).predict(x)
             _check(lg, ref)
             outs[(mode, cin, ncls, fml, n, hh, ww)] = lg
+        # uint8 input, preprocessing fused into the first layer
+        w = onet.init_weights(6, 3, 0, bias_scale=0.1)
+        m = Model(NetConfig(grey=False, preprocessing=PreprocessingType.MOBILENET_LIKE)); m.set_weights(w)
+        xu8 = synthetic.noise_images(11, 2, 72, 136, 3, as_float=False)
+        _check(m.predict(xu8), onet.forward(onet.preprocess_mobilenet(xu8.astype(np.float64)), w))
     for cin, ncls, fml, n, hh, ww in cases:
-        a, b = outs[("fused", cin, ncls, fml, n, hh, ww)], outs[("unfused", cin, ncls, fml, n, hh, ww)]
-        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
-        assert np.array_equal(a, outs[("fused_few_cus", cin, ncls, fml, n, hh, ww)])          # tile -> block assignment is irrelevant
+        b = outs[("unfused", cin, ncls, fml, n, hh, ww)]
+        for mode in ("fused", "fused123"):
+            assert np.abs(outs[(mode, cin, ncls, fml, n, hh, ww)] - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), (mode, cin, fml, hh, ww)
+        assert np.array_equal(outs[("fused123", cin, ncls, fml, n, hh, ww)], outs[("fused123_few_cus", cin, ncls, fml, n, hh, ww)])   # tile -> block assignment is irrelevant

@@ -7,7 +7,7 @@ torch.cuda.set_device(0)
 cfg = NetConfig(grey=False)
 x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
 models = {}
-for mode in ("fused", "unfused"):
+for mode in ("fused123", "fused", "unfused"):
     os.environ["UBD_STEM"] = mode
     models[mode] = Model(cfg, seed=1)
 def timed(fn, reps):
@@ -17,9 +17,10 @@ def timed(fn, reps):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for _ in range(300): models["fused"].predict_on_device(x)
+for _ in range(300): models["fused123"].predict_on_device(x)
 for rep in range(3):
     for mode, m in models.items():
         print(f"{mode}: net {timed(lambda: m.predict_on_device(x), 300):.4f} ms", flush=True)
-a = models["fused"].predict_on_device(x).clone(); b = models["unfused"].predict_on_device(x)
-print("max |fused - unfused| =", float((a - b).abs().max()), "max |logit| =", float(b.abs().max()))
+b = models["unfused"].predict_on_device(x).clone()
+for mode in ("fused", "fused123"):
+    print(f"max |{mode} - unfused| =", float((models[mode].predict_on_device(x) - b).abs().max()), "max |logit| =", float(b.abs().max()))

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-42:], r.get("Queue_Id", r.get("Stream_Id", "?"))) for r in rows]
 ev.sort()
 # last 3 steps: find sepconv_kernel<3 starts
-starts = [i for i, e in enumerate(ev) if "sepconv_kernel<3" in e[2]]
+starts = [i for i, e in enumerate(ev) if "sepconv_kernel<3" in e[2] or "stem123_kernel" in e[2]]
 i0 = starts[-4]; i1 = starts[-1]
 t0 = ev[i0][0]
 print("step period (us):", [(ev[starts[k + 1]][0] - ev[starts[k]][0]) / 1e3 for k in range(len(starts) - 6, len(starts) - 1)])

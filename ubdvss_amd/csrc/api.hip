@@ -44,8 +44,9 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         // 32 x 512 x 512); with TF 'same' padding the fused kernel only ties the two separate kernels and they
         // stay the default.  UBD_STEM=fused / unfused overrides either way.  Training always runs the separate kernels.
         const char *s = getenv("UBD_STEM");
-        h->fuse_stem = cfg->fml_compatible != 0;
-        if (s && strcmp(s, "fused") == 0) h->fuse_stem = 1;
+        h->fuse_stem = cfg->fml_compatible != 0 ? 2 : 0;        // 2: L1 -> L2 -> L3 in one kernel (stem123.h; fml padding only)
+        if (s && strcmp(s, "fused") == 0) { h->fuse_stem = 1; h->fuse_force = 1; }      // 1: L1, then L2 -> L3 fused (stem23.h)
+        if (s && strcmp(s, "fused123") == 0) { h->fuse_stem = 2; h->fuse_force = 1; }   // forced at any launch size (tests)
         if (s && strcmp(s, "unfused") == 0) h->fuse_stem = 0;
     }
     // Keras model.get_weights() order

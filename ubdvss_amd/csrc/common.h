@@ -21,7 +21,8 @@ struct ubd_handle {
     size_t n_params;
     int num_cus;
     int pp_lds_attr_set;      // pp_front_lds_kernel's dynamic-LDS limit has been raised on this handle's device
-    int fuse_stem;            // 1: inference runs L2 -> L3 as one kernel with L2's output in LDS (default with fml padding; UBD_STEM=fused|unfused)
+    int fuse_force;           // UBD_STEM named a fused variant explicitly: use it at any launch size
+    int fuse_stem;            // inference stem: 2 = L1 -> L2 -> L3 in one kernel (default with fml padding), 1 = L2 -> L3 fused, 0 = three kernels (UBD_STEM=fused123|fused|unfused)
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
 };
 
@@ -132,6 +133,7 @@ static inline size_t ubd_align_up(size_t v, size_t a) { return (v + a - 1) / a *
 #define UBD_FWD_FRAG_FLOATS (UBD_FWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)
 
 struct ubd_fwd_layout {
+    size_t off_tickets;   // int32 [64]: strip ticket counter of the one-kernel inference stem (zeroed per pass)
     size_t off_wfrag;     // packed weights
     size_t off_a1, off_a2;   // (n, H/2, W/2, 24) activations: L1 out, L2 out
     size_t off_b[2];         // (n, H/4, W/4, 24) ping-pong for L3..L9 outputs (inference)

@@ -460,6 +460,7 @@ static unsigned long long *g_ubd_stamps = nullptr;
 extern "C" void ubd_debug_set_stamps(void *p) { g_ubd_stamps = (unsigned long long *)p; }
 #endif
 #include "stem23.h"
+#include "stem123.h"
 
 // ------------------------------------------------------------------------------------
 // Dense dilated 3x3 conv 24 -> 24 (+bias+ReLU), fp32 MFMA, weights resident in VGPRs.
@@ -627,6 +628,7 @@ void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int traini
     const size_t wf = (size_t)UBD_FWD_FRAG_FLOATS * sizeof(float);
     size_t off = 0;
     L->off_wfrag = off; off += ubd_align_up(wf, 256);
+    L->off_tickets = off; off += 256;
     const size_t a = ubd_align_up(act_bytes(h, n, H / 2, W / 2), 256);
     const size_t b = ubd_align_up(act_bytes(h, n, H / 4, W / 4), 256);
     L->off_a1 = off; off += a;
@@ -770,12 +772,30 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     float sc = 0.f, sh = 1.f;
     if (preprocessing == UBD_PRE_MOBILENET) { sc = 127.5f; sh = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
-    if (h->cfg.c_in == 1)
+    float *cur = (float *)(ws + L.off_acts[0]);
+    // the fused stem kernels give every CU whole strips of tiles (n * H4 / 4 of them): they need ~2 strips per CU to fill the chip
+    // (a single 512 x 512 image has 32); smaller launches take the three separate kernels unless UBD_STEM forces a variant
+    const long stem_strips = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
+    const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
+    const bool fuse_all = inference && stem_big && h->fuse_stem == 2 && pad_s2 == 1;
+    if (fuse_all) {
+        // L1 -> L2 -> L3 in one kernel (stem123.h): neither a1 nor a2 is touched
+        const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
+        int grid = h->num_cus;
+        if (grid > strips) grid = strips;
+        const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
+        int *ticket = (int *)(ws + L.off_tickets);                // strip tickets of the one-kernel stem, zeroed per pass
+        UBD_CHECK_HIP(hipMemsetAsync(ticket, 0, 256, st));
+#define UBD_LAUNCH_S123(CINV, U8V) hipLaunchKernelGGL((stem123_kernel<CINV, U8V>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket)
+        if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1); else UBD_LAUNCH_S123(1, 0); }
+        else { if (u8) UBD_LAUNCH_S123(3, 1); else UBD_LAUNCH_S123(3, 0); }
+#undef UBD_LAUNCH_S123
+    } else if (h->cfg.c_in == 1)
         launch_sep<1, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
     else
         launch_sep<3, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
-    float *cur = (float *)(ws + L.off_acts[0]);
-    if (inference && h->fuse_stem) {
+    if (fuse_all) {
+    } else if (inference && stem_big && h->fuse_stem) {
         // L2 -> L3 in one kernel: L2's activation stays in LDS (stem23.h); the a2 buffer is not touched
         const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);   // a block walks whole row strips of tiles
         int grid = h->num_cus;                                   // one 8-wave block per CU (120 KB of LDS)

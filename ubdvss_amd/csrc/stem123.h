@@ -1,0 +1,344 @@
+// The whole stem L1 -> L2 -> L3 of an inference pass in ONE kernel (fml padding; included by forward.hip after stem23.h).
+//
+// Reference semantics: net.py:292-296 -- ZeroPadding2D((1,0),(1,0)) + SeparableConv2D(24, 3x3, stride 2, relu) (L1),
+// SeparableConv2D(24, 3x3, 'same', relu) (L2), ZeroPadding2D + SeparableConv2D(stride 2, relu) (L3) -- and the fused
+// (x - 127.5) / 127.5 of net.py:217-218 for uint8 input.  stem23.h keeps L2's output in LDS; this kernel also computes the
+// L1 outputs an L2 tile needs from the IMAGE, so neither L1's nor L2's activation (2 x 201 MB written + 2 x 201 MB read per
+// batch of 32 at fp32) ever exists in memory: the stem reads 100 MB (25 MB for uint8) and writes 50 MB.  Price: L1 is
+// recomputed on the 11 x 34 halo patch of every tile (1.46x its arithmetic -- L1 is the cheap layer: 3 input channels) and L2 on
+// 9 x 32 (1.125x).  The per-tile phases:
+//   0a  the tile's 23 x 69 x C_in input patch, requested a tile ago into registers, goes to LDS (preprocessing / uint8
+//       conversion on the way, 0 outside the image = L1's zero padding); the next tile's loads are issued
+//   0b  L1 on the 374 patch pixels as 24 units of 16 (flat index -> (row, col)): depthwise on the VALU (lane = pixel x input
+//       channel), pointwise = 2 fp32 MFMAs, bias + ReLU, 0 outside L1's map (= L2's zero padding), into the a1 patch image
+//       (the chunk-rotated layout stem23's phase A reads); wave 7 also moves the inherited 33rd L2 column into place
+//   A   L2 on 9 x 32 positions (as stem23.h, CARRY variant);   B   L3 (waves 0-3), 16-byte stores.
+// Three block barriers per tile, one 8-wave block per CU.  Training keeps the separate kernels (it needs a1 and a2).
+#pragma once
+
+template <int CIN> struct s123_cfg {
+    using B = s23_cfg;
+    static constexpr int NT = B::NT, NW = B::NW;
+    static constexpr int AC = B::LC + 1;                           // a1 patch columns that are needed: 1 .. 34 of the 35
+    static constexpr int XH = 2 * B::PH + 1, XW = 2 * AC + 1;      // input patch 23 x 69
+    static constexpr int XE = XH * XW * CIN;                       // elements
+    static constexpr int XREGS = (XE + NT - 1) / NT;
+    static constexpr int XP_FLOATS = (XE + 3) / 4 * 4;
+    static constexpr int A1_FLOATS = B::PH * B::PW * UBD_C;        // a1 patch, stem23's layout
+    static constexpr int NPIX = B::PH * AC;                        // 374 L1 outputs per tile
+    static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
+    static constexpr int UPW = (UNITS + NW - 1) / NW;              // units per wave
+    static constexpr int W1_FLOATS = 64 * 12 + 64 + 4;              // L1 per-lane weights (9 depthwise taps, 2 pointwise, pad) + biases of L1 / L3 (2 x 32) + the ring of strip ids
+    static constexpr int SMEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
+};
+
+template <int CIN, int IN_U8>
+__global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__restrict__ xin, float *__restrict__ y,
+                                                                const float *__restrict__ frag1, const float *__restrict__ bias1,
+                                                                const float *__restrict__ frag2, const float *__restrict__ bias2,
+                                                                const float *__restrict__ frag3, const float *__restrict__ bias3,
+                                                                int n, int H, int W, int H2, int W2, int H4, int W4,
+                                                                float pre_sub, float pre_div, int *__restrict__ ticket)
+{
+    using C = s23_cfg;
+    using X = s123_cfg<CIN>;
+    __shared__ __attribute__((aligned(16))) float smem[X::SMEM_FLOATS];                     // ONE LDS object
+    float *a1p = smem;
+    float *l2 = a1p + X::A1_FLOATS;
+    float *xp = l2 + C::L2_FLOATS;
+    float *w3pw = xp + X::XP_FLOATS, *w3dw = w3pw + C::W3PW_FLOATS;
+    float *carry_buf = w3dw + C::W3DW_FLOATS;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, q = lane >> 4;
+
+    // ---- weights.  L2's 66 per-lane values live in VGPRs (hot phase); L1's eleven too; L3's come from LDS tables.
+    float dwk2[9][6], pwf2[6][2];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+        const int src_lane = 16 * (ch / 6) + i, ss = ch % 6;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwk2[t][s] = frag2[UBD_SEP_FRAG_FLOATS + (t * 6 + ss) * 64 + src_lane];
+        pwf2[s][0] = frag2[(ss * 2 + 0) * 64 + src_lane]; pwf2[s][1] = frag2[(ss * 2 + 1) * 64 + src_lane];
+    }
+    // L1's eleven per-lane values (lane (i, q): input channel q, zero weights for q >= C_in) sit in an LDS table and are
+    // re-read at the start of every phase 0b: kept in VGPRs across phase A they cost 11 spilled registers
+    float *w1t = carry_buf + C::CARRY_FLOATS;
+    for (int e = threadIdx.x; e < 64 * 12; e += C::NT) {
+        const int ln = e / 12, k = e - ln * 12;
+        w1t[e] = k < 9 ? frag1[UBD_SEP_FRAG_FLOATS + (k * 6) * 64 + ln] : (k < 11 ? frag1[(k - 9) * 64 + ln] : 0.f);
+    }
+    float *bt = w1t + 64 * 12;                                     // [0,32): L1's bias (24 + zeros), [32,64): L3's
+    if (threadIdx.x < 64) bt[threadIdx.x] = (threadIdx.x & 31) < UBD_C ? (threadIdx.x < 32 ? bias1 : bias3)[threadIdx.x & 31] : 0.f;
+    for (int e = threadIdx.x; e < C::W3PW_FLOATS; e += C::NT) {
+        const int nt = e >> 9, ln = (e >> 3) & 63, s = e & 7, lq = ln >> 4, li = ln & 15;
+        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+        w3pw[e] = s < 6 ? frag3[((ch % 6) * 2 + nt) * 64 + 16 * (ch / 6) + li] : 0.f;
+    }
+    for (int e = threadIdx.x; e < C::W3DW_FLOATS; e += C::NT) {
+        const int lq = e / 72, r = e - lq * 72, t = r >> 3, s = r & 7;
+        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+        w3dw[e] = s < 6 ? frag3[UBD_SEP_FRAG_FLOATS + (t * 6 + ch % 6) * 64 + 16 * (ch / 6)] : 0.f;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 b2A = *(const f32x4 *)(bias2 + 4 * q), b2B = q < 2 ? *(const f32x4 *)(bias2 + 16 + 4 * q) : z4;
+
+    // ---- tile sequence: whole row strips of tiles, left to right (stem23.h).  Strips are handed out dynamically, every one
+    // of them a ticket from ONE global counter (zeroed by the host per pass; a strip is eight tiles = ~20 us of work, so a
+    // launch draws a few thousand tickets and the counter is never contended).  This kernel needs a whole CU per block, and
+    // the pipelined postprocess of the previous batch holds 32 CUs for ~60-130 us right when it starts: with a static split
+    // the 32 blocks that cannot be placed sit on an eighth of the strips (step 0.43 -> 0.46 ms); with tickets they come up
+    // late, find (almost) nothing left and exit.  A block claims as few strips ahead as the one-tile lookahead allows (D
+    // below: one for rows of three or more tiles) -- every strip claimed early by a late block ends after everybody else.
+    // The ids live in a four-entry LDS ring: entry j + D is requested when strip j starts and published at the end of that
+    // tile, at least one full tile (three barriers) before anybody reads it.
+    const int tiles_x = (W4 + 15) >> 4, tiles_y = (H4 + C::TH3 - 1) / C::TH3;
+    const int strips = n * tiles_y;
+    const int D = tiles_x >= 3 ? 1 : 4 - tiles_x;                                   // strips claimed ahead of the current one
+    int *ring = (int *)(bt + 64);                                                   // logical strip id of the block's strip ordinal j at [j & 3]
+    struct tpos { int tx, ty, img, ord, ls; };                                      // ord: ordinal of the strip in this block's sequence
+    auto strip_pos = [&](int ord, int tx) {
+        tpos p;
+        const int ls = __builtin_amdgcn_readfirstlane(ring[ord & 3]);
+        const int sidx = ubd_xcd_tile(ls < strips ? ls : strips - 1, strips);
+        p.ty = (int)((unsigned)sidx % (unsigned)tiles_y);
+        p.img = (int)((unsigned)sidx / (unsigned)tiles_y);
+        p.tx = tx; p.ord = ord; p.ls = ls;
+        return p;
+    };
+    auto advance = [&](tpos p) {
+        if (p.tx + 1 < tiles_x) { ++p.tx; return p; }
+        return strip_pos(p.ord + 1, 0);
+    };
+
+    // ---- input patch of a tile: rows 4*oy0 - 5 .. + 22, columns 4*ox0 - 3 .. + 68, raw bits into registers (fp32 pattern
+    //      or zero-extended byte; 0x100 / pre_sub bits = "outside the image", exactly 0 after the preprocessing)
+    unsigned xreg[X::XREGS];
+    // element e = threadIdx.x + 512 k of the patch in row-major order [23][69 * C_in]: (row, column * C_in + channel) advance by
+    // (512 / RW, 512 % RW) with a carry -- no divisions in the loop
+    constexpr int RWF = X::XW * CIN;                                                 // floats per patch row
+    const int e0_row = (int)threadIdx.x / RWF, e0_col = (int)threadIdx.x - e0_row * RWF;
+    auto load_x = [&](tpos p) {
+        const int iy0 = 4 * p.ty * C::TH3 - 5, ix0 = 64 * p.tx - 3;
+        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + X::XH <= H) && (ix0 + X::XW <= W);   // block-uniform
+        const size_t img_base = (size_t)p.img * H * W * CIN;
+        int pr = e0_row, pcf = e0_col;
+#pragma unroll
+        for (int k = 0; k < X::XREGS; ++k) {
+            const bool live = k * C::NT + (int)threadIdx.x < X::XE;
+            unsigned v = IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);
+            const int gy = iy0 + pr, gxf = ix0 * CIN + pcf;                          // gxf = gx * C_in + channel
+            const bool ok = live && (interior || (gy >= 0 && gy < H && gxf >= 0 && gxf < W * CIN));
+            if (ok) {
+                const size_t ge = img_base + (size_t)gy * (W * CIN) + gxf;
+                if constexpr (IN_U8) v = ((const unsigned char *)xin)[ge];
+                else v = ((const unsigned *)xin)[ge];
+            }
+            xreg[k] = v;
+            pr += C::NT / RWF; pcf += C::NT % RWF;
+            if (pcf >= RWF) { pcf -= RWF; ++pr; }
+        }
+    };
+
+    // ---- phase 0b: this wave's L1 units (flat pixel p = 16 u + i of the 11 x 34 needed a1 pixels), constant per launch
+    int u_rd[X::UPW], u_wr[X::UPW], u_rc[X::UPW];                  // input-patch read offset, a1-patch write offset, (row << 8 | col)
+#pragma unroll
+    for (int k = 0; k < X::UPW; ++k) {
+        const int u = wid + C::NW * k;
+        int p = u * 16 + i;
+        const bool live = u < X::UNITS && p < X::NPIX;
+        p = live ? p : 0;
+        const int ar = p / X::AC, ac = p - ar * X::AC + 1;         // a1 patch (row, column 1..34)
+        u_rd[k] = ((2 * ar) * X::XW + 2 * (ac - 1)) * CIN + (q < CIN ? q : 0);
+        const int rot = 3 * ((ac >> 3) & 1);
+        int s4 = q + rot;
+        s4 = s4 >= 6 ? s4 - 6 : s4;
+        u_wr[k] = (ar * C::PW + ac) * UBD_C + 4 * s4;              // chunk q; chunk 4 + q (q < 2) sits 16 floats further, modulo the rotation
+        u_rc[k] = live ? ((ar << 8) | ac) : -1;
+    }
+    // ---- phase A constants (stem23.h, CARRY variant)
+    const int half = wid & 1, rg = wid >> 1;
+    const int rb = rg == 0 ? 0 : 2 * rg + 1, rw = rg == 0 ? 3 : 2;
+    const int pos = 1 + 16 * half + i;
+    int ro4[3], ro2[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int pcol = pos + kx, rot = 3 * ((pcol >> 3) & 1);
+        int s4 = q + rot, s2 = 4 + (q >> 1) + rot;
+        s4 = s4 >= 6 ? s4 - 6 : s4; s2 = s2 >= 6 ? s2 - 6 : s2;
+        ro4[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s4;
+        ro2[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s2 + 2 * (q & 1);
+    }
+    const int l2w = (rb * C::LC + pos) * C::LP + 4 * q;
+    const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;
+
+    if (threadIdx.x == 0) {                                                          // the block's first D strips
+        const int t0 = __hip_atomic_fetch_add(ticket, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ring[0] = t0; ring[1] = t0 + 1; ring[2] = t0 + 2;                            // only the first D are this block's: the rest are overwritten before use
+    }
+    __syncthreads();
+    tpos cur = strip_pos(0, 0);
+    if (cur.ls >= strips) return;                                                    // block-uniform: nothing left
+    tpos nx1 = advance(cur);
+    load_x(cur);
+    int pending = 0;                                                                 // ticket in flight (thread 0)
+    for (int it = 0;; ++it) {
+        const bool new_strip = cur.tx == 0;                                          // block-uniform
+        if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
+        const bool has_next = nx1.ls < strips;                                       // block-uniform
+        const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
+        const int A0y = R0 - 1, A0x = C0 - 1;                                        // a1 pixel of patch (0, 0)
+
+        // ---- phase 0a: input patch -> LDS (fp32, preprocessed); request the next tile's
+        const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;              // already preprocessed fp32 input: a copy
+#pragma unroll
+        for (int k = 0; k < X::XREGS; ++k) {
+            const int e = k * C::NT + (int)threadIdx.x;
+            if (e < X::XE) {
+                if constexpr (IN_U8) xp[e] = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
+                else xp[e] = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
+            }
+        }
+        if (has_next) load_x(nx1);
+        __syncthreads();                                                             // patch complete; phase B of the previous tile is over
+
+        // ---- phase 0b: L1 -> a1 patch image
+        float dwk1[9], pwf1[2];
+        {
+            const f32x4 wa = *(const f32x4 *)(w1t + lane * 12), wb = *(const f32x4 *)(w1t + lane * 12 + 4), wc = *(const f32x4 *)(w1t + lane * 12 + 8);
+            dwk1[0] = wa[0]; dwk1[1] = wa[1]; dwk1[2] = wa[2]; dwk1[3] = wa[3]; dwk1[4] = wb[0]; dwk1[5] = wb[1]; dwk1[6] = wb[2]; dwk1[7] = wb[3];
+            dwk1[8] = wc[0]; pwf1[0] = wc[1]; pwf1[1] = wc[2];
+        }
+        const f32x4 b1A = *(const f32x4 *)(bt + 4 * q), b1B = *(const f32x4 *)(bt + 16 + 4 * q);      // zeros beyond channel 23
+#pragma unroll
+        for (int k = 0; k < X::UPW; ++k) {
+            if (wid + C::NW * k >= X::UNITS) continue;                               // wave-uniform
+            float dv = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd[k] + (ky * X::XW + kx) * CIN], dwk1[ky * 3 + kx], dv);
+            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv, b1A, 0, 0, 0);
+            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv, b1B, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.f); acc1[r] = fmaxf(acc1[r], 0.f); }
+            const int rc = u_rc[k];
+            const int ar = rc >> 8, ac = rc & 255;
+            const bool inside = rc >= 0 && (unsigned)(A0y + ar) < (unsigned)H2 && (unsigned)(A0x + ac) < (unsigned)W2;
+            if (!inside) { acc0 = z4; acc1 = z4; }                                   // L2's zero padding
+            if (rc >= 0) {
+                float *dst = a1p + u_wr[k];
+                *(f32x4 *)dst = acc0;
+                if (q < 2) {                                                         // chunk 4 + q: slot (4 + q + 3f) % 6
+                    const int rot = 3 * ((ac >> 3) & 1);
+                    int s1 = 4 + q + rot;
+                    s1 = s1 >= 6 ? s1 - 6 : s1;
+                    *(f32x4 *)(a1p + (ar * C::PW + ac) * UBD_C + 4 * s1) = acc1;
+                }
+            }
+        }
+        if (wid == C::NW - 1 && lane < C::LR * 6) {
+            // L2 position 0 (column 2*ox0 - 1): the previous tile's position 32, or L3's zero padding at the left image edge
+            const int row = lane / 6, ch4 = lane - row * 6;
+            f32x4 v = z4;
+            if (cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);
+            *(f32x4 *)(l2 + (row * C::LC) * C::LP + 4 * ch4) = v;
+        }
+        __syncthreads();
+
+        // ---- phase A: L2 on positions (0..8, 1..32)
+        const bool mask_needed = (R0 < 0) || (R0 + C::LR > H2) || (C0 + C::LC > W2);
+        {
+            float dwv[3][6];
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) dwv[o][s] = 0.f;
+#pragma unroll
+            for (int yy = 0; yy < 5; ++yy) {
+                if (yy < rw + 2) {                                                   // wave-uniform
+                    f32x4 v4[3];
+                    f32x2 v2[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        v4[kx] = *(const f32x4 *)(a1p + ro4[kx] + yy * (C::PW * UBD_C));
+                        v2[kx] = *(const f32x2 *)(a1p + ro2[kx] + yy * (C::PW * UBD_C));
+                    }
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const int ky = yy - o;
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int t = ky * 3 + kx;
+                            dwv[o][0] = fmaf(v4[kx][0], dwk2[t][0], dwv[o][0]);
+                            dwv[o][1] = fmaf(v4[kx][1], dwk2[t][1], dwv[o][1]);
+                            dwv[o][2] = fmaf(v4[kx][2], dwk2[t][2], dwv[o][2]);
+                            dwv[o][3] = fmaf(v4[kx][3], dwk2[t][3], dwv[o][3]);
+                            dwv[o][4] = fmaf(v2[kx][0], dwk2[t][4], dwv[o][4]);
+                            dwv[o][5] = fmaf(v2[kx][1], dwk2[t][5], dwv[o][5]);
+                        }
+                    }
+                    if (yy >= 2) {
+                        const int o = yy - 2;
+                        f32x4 acc0 = b2A, acc1 = b2B;
+#pragma unroll
+                        for (int s = 0; s < 6; ++s) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf2[s][0], dwv[o][s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf2[s][1], dwv[o][s], acc1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.f); acc1[r] = fmaxf(acc1[r], 0.f); }
+                        if (mask_needed) {
+                            const bool ok = (unsigned)(C0 + pos) < (unsigned)W2 && (unsigned)(R0 + rb + o) < (unsigned)H2;
+                            if (!ok) { acc0 = z4; acc1 = z4; }                       // L3's zero padding
+                        }
+                        float *dst = l2 + l2w + o * (C::LC * C::LP);
+                        *(f32x4 *)dst = acc0;
+                        if (q < 2) *(f32x4 *)(dst + 16) = acc1;
+                        if (half == 1 && i == 15) {                                  // position 32: the next tile's position 0
+                            float *cd = carry_buf + ((it & 1) * C::LR + rb + o) * C::LP + 4 * q;
+                            *(f32x4 *)cd = acc0;
+                            if (q < 2) *(f32x4 *)(cd + 16) = acc1;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B, waves 0-3: L3 output row oy0 + wid
+        if (wid < 4) {
+            const int oy = oy0 + wid;
+            float dv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float *p = l2 + l2r + (ky * C::LC + kx) * C::LP;
+                    const f32x4 v4 = *(const f32x4 *)(p + 4 * q);
+                    const f32x2 v2 = *(const f32x2 *)(p + 16 + 2 * q);
+                    const float *wt = w3dw + (q * 9 + ky * 3 + kx) * 8;
+                    const f32x4 w4 = *(const f32x4 *)wt;
+                    const f32x2 w2 = *(const f32x2 *)(wt + 4);
+                    dv[0] = fmaf(v4[0], w4[0], dv[0]); dv[1] = fmaf(v4[1], w4[1], dv[1]);
+                    dv[2] = fmaf(v4[2], w4[2], dv[2]); dv[3] = fmaf(v4[3], w4[3], dv[3]);
+                    dv[4] = fmaf(v2[0], w2[0], dv[4]); dv[5] = fmaf(v2[1], w2[1], dv[5]);
+                }
+            const f32x4 pa0 = *(const f32x4 *)(w3pw + lane * 8), pa1 = *(const f32x4 *)(w3pw + 512 + lane * 8);
+            const f32x2 pb0 = *(const f32x2 *)(w3pw + lane * 8 + 4), pb1 = *(const f32x2 *)(w3pw + 512 + lane * 8 + 4);
+            f32x4 acc0 = *(const f32x4 *)(bt + 32 + 4 * q), acc1 = *(const f32x4 *)(bt + 48 + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa0[s] : pb0[s - 4], dv[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa1[s] : pb1[s - 4], dv[s], acc1, 0, 0, 0);
+            }
+            store_tile_relu_t(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1, z4, z4);   // bias already in
+        }
+        if (!has_next) break;
+        if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;   // visible after the next tile's barriers
+        cur = nx1;
+        nx1 = advance(nx1);
+    }
+}
