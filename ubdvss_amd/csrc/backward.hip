@@ -118,16 +118,32 @@ __global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restr
 // Weight gradients are accumulated per block and written as one row of a [blocks][count] partial-sum matrix;
 // reduce_partials_kernel adds the rows in a fixed order (deterministic, and no same-address atomics: a few
 // thousand fp32 atomics per address cost ~0.4 ms per launch on MI355X).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int nblocks, int count,
-                                                              float *__restrict__ out0, int n0, float *__restrict__ out1, int n1,
-                                                              float *__restrict__ out2)
+// One launch reduces up to RP_MAX_JOBS partial-sum matrices (the head and the six dilated layers; the three separable
+// layers): ten separate launches of ~6 us each, serialised behind their producers, cost 65 us of the 1.57 ms bf16 step.
+#define RP_MAX_JOBS 8
+struct rp_job {
+    const float *part;
+    float *out0, *out1, *out2;
+    int nblocks, count, n0, n1, block0;                        // block0: first block of this job in the batched grid
+};
+struct rp_batch { rp_job job[RP_MAX_JOBS]; int njobs; };
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const rp_batch B)
 {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < RP_MAX_JOBS; ++k)
+        if (k < B.njobs && (int)blockIdx.x >= B.job[k].block0) j = k;            // block-uniform
+    const float *__restrict__ part = B.job[j].part;
+    float *__restrict__ out0 = B.job[j].out0, *__restrict__ out1 = B.job[j].out1, *__restrict__ out2 = B.job[j].out2;
+    const int nblocks = B.job[j].nblocks, count = B.job[j].count, n0 = B.job[j].n0, n1 = B.job[j].n1;
+    const int blk = (int)blockIdx.x - B.job[j].block0;
     // block = RP_COLS consecutive elements x (256 / RP_COLS) row groups; 8 independent loads in flight per thread.
     // 16 columns per block: 5208-element rows give 326 blocks (one per CU and more) instead of 82.
     constexpr int G = 256 / RP_COLS;
     __shared__ float s[G][RP_COLS];
     const int tx = threadIdx.x % RP_COLS, ty = threadIdx.x / RP_COLS;
-    const int e = blockIdx.x * RP_COLS + tx;
+    const int e = blk * RP_COLS + tx;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < count) {
         int b = ty;
@@ -825,13 +841,43 @@ extern "C" void ubd_debug_set_stamps_sepb(void *p, int cin, int stride) { g_sepb
 #endif
 #include "sepbwd16.h"
 
+// Host side of the batched reduction: every producer takes its own partial-sum matrix out of the workspace region and
+// queues a job; rp_flush launches the jobs queued so far (after the dilated loop: those gradients feed the overlapped
+// all-reduce; at the end of the pass).
+struct rp_queue {
+    rp_batch b;
+    int nblocks;
+    float *base;
+    size_t used, cap;                                          // floats
+};
+static void rp_init(rp_queue *q, float *base, size_t cap_floats) { q->b.njobs = 0; q->nblocks = 0; q->base = base; q->used = 0; q->cap = cap_floats; }
+static int rp_flush(rp_queue *q, hipStream_t st)
+{
+    if (q->b.njobs > 0) hipLaunchKernelGGL(reduce_partials_kernel, dim3(q->nblocks), dim3(256), 0, st, q->b);
+    q->b.njobs = 0; q->nblocks = 0;                            // the matrices stay allocated until the pass ends (the kernel is in flight)
+    return 0;
+}
+// a [rows][count] matrix for the next producer, reduced into out0[n0] | out1[n1] | out2[rest]
+static float *rp_add(rp_queue *q, int rows, int count, float *out0, int n0, float *out1, int n1, float *out2, hipStream_t st)
+{
+    if (q->b.njobs == RP_MAX_JOBS) rp_flush(q, st);
+    const size_t need = ((size_t)rows * count + 63) & ~(size_t)63;
+    if (q->used + need > q->cap) { ubd_set_error("backward: partial-sum region too small (%zu + %zu > %zu floats)", q->used, need, q->cap); return nullptr; }
+    float *part = q->base + q->used;
+    q->used += need;
+    rp_job &j = q->b.job[q->b.njobs++];
+    j.part = part; j.out0 = out0; j.out1 = out1; j.out2 = out2; j.nblocks = rows; j.count = count; j.n0 = n0; j.n1 = n1; j.block0 = q->nblocks;
+    q->nblocks += (count + RP_COLS - 1) / RP_COLS;
+    return part;
+}
+
 // ------------------------------------------------------------------------------------ host
 // Workspace of a train step: forward layout (all activations kept; fp32 or 16-bit), then backward fragments,
 // logits, dlogits, fp32 gradient ping-pong buffers, loss scratch, partial-sum matrix.
 struct train_layout {
     ubd_fwd_layout fwd;            // dtype == UBD_F32
     ubd_fwd16_layout fwd16;        // 16-bit activations
-    size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, off_partials, total;
+    size_t off_bfrag, off_logits, off_dlogits, off_gq[2], off_ddw3, off_gb[2], off_loss, off_partials, partials_floats, total;
 };
 
 static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train_layout *T)
@@ -851,7 +897,8 @@ static void train_layout_compute(const ubd_handle *h, int n, int H, int W, train
     T->off_gb[0] = off;   off += big;
     T->off_gb[1] = off;   off += big;
     T->off_loss = off;    off += ubd_align_up(ubd_loss_workspace_bytes(h, n, H / 4, W / 4), 256);
-    T->off_partials = off; off += ubd_align_up(((size_t)4 * h->num_cus + 8) * (217 * UBD_C) * sizeof(float), 256);
+    T->partials_floats = (size_t)8 * ((size_t)4 * h->num_cus + 8) * (217 * UBD_C);      // one matrix per producer (ten per pass), freed at the end of the pass
+    T->off_partials = off; off += ubd_align_up(T->partials_floats * sizeof(float), 256);
     T->total = off;
 }
 
@@ -864,8 +911,8 @@ extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int heig
 }
 
 template <int CIN, int STRIDE, typename TX, typename TR = TX>
-static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
-                           const float *bfrag, float *g_dw, float *g_pw, float *g_b, float *partials, int n, int H, int W,
+static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
+                           const float *bfrag, float *g_dw, float *g_pw, float *g_b, rp_queue *rq, int n, int H, int W,
                            int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
 {
     using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
@@ -874,50 +921,55 @@ static void launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const 
     const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float);
     int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
     if (grid > tiles) grid = (int)tiles;
+    const int part = 9 * CIN + CIN * UBD_C + UBD_C;
+    float *partials = rp_add(rq, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
+    if (!partials) return -1;
     if (in_u8)
         hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
     else
         hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
-    const int part = 9 * CIN + CIN * UBD_C + UBD_C;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((part + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
+    return 0;
 }
 
 template <int CIN, int STRIDE, int GSRC, typename T>
-static void launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const unsigned short *D, const unsigned short *maskact,
+static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const unsigned short *D, const unsigned short *maskact,
                           unsigned short *dDW, const float *dw_own, const float *pw_own, const float *dw_up, float *g_dw, float *g_pw,
-                          float *g_b, float *partials, int n, int H, int W, int OH, int OW, int pad_lo, int DH, int DWd, int pad_up,
+                          float *g_b, rp_queue *rq, int n, int H, int W, int OH, int OW, int pad_lo, int DH, int DWd, int pad_up,
                           float sub, float div, hipStream_t st)
 {
     using C = sepb16_cfg<CIN, STRIDE, GSRC>;
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
     int grid = h->num_cus * C::BLOCKS_PER_CU;
     if (grid > tiles) grid = (int)tiles;
+    float *partials = rp_add(rq, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
+    if (!partials) return -1;
     if (in_u8)
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
     else
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C::PART + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b);
+    return 0;
 }
 
 template <typename TX>
-static void launch_head_wgrad(const ubd_handle *h, const void *a9, const float *dlogits, float *grads, float *partials, long npix,
+static int launch_head_wgrad(const ubd_handle *h, const void *a9, const float *dlogits, float *grads, rp_queue *rq, long npix,
                               hipStream_t st)
 {
     if (h->k_out == 1) {
         long g1 = (npix + 255) / 256;
         if (g1 > h->num_cus * 4) g1 = h->num_cus * 4;
+        float *partials = rp_add(rq, (int)g1, UBD_C + 1, grads + h->off_head_k, UBD_C, grads + h->off_head_b, 1, nullptr, st);
+        if (!partials) return -1;
         hipLaunchKernelGGL((head_wgrad1_kernel<TX>), dim3((int)g1), dim3(256), 0, st, a9, dlogits, partials, npix);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((UBD_C + 1 + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, (int)g1, UBD_C + 1, grads + h->off_head_k, UBD_C,
-                           grads + h->off_head_b, 1, (float *)nullptr);
-        return;
+        return 0;
     }
     long g2l = (npix + HW_TILE - 1) / HW_TILE;
     if (g2l > h->num_cus * 4) g2l = h->num_cus * 4;
     const int g2 = (int)g2l;
-    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out);
     const int cols = (UBD_C + 1) * h->k_out;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, g2, cols, grads + h->off_head_k, UBD_C * h->k_out,
-                       grads + h->off_head_b, h->k_out, (float *)nullptr);
+    float *partials = rp_add(rq, g2, cols, grads + h->off_head_k, UBD_C * h->k_out, grads + h->off_head_b, h->k_out, nullptr, st);
+    if (!partials) return -1;
+    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out);
+    return 0;
 }
 
 // Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9
@@ -943,7 +995,8 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
     float *ddw3 = (float *)(ws + T.off_ddw3);
     float *gb[2] = {(float *)(ws + T.off_gb[0]), (float *)(ws + T.off_gb[1])};
-    float *partials = (float *)(ws + T.off_partials);
+    rp_queue rq;
+    rp_init(&rq, (float *)(ws + T.off_partials), T.partials_floats);
 
     int grid = (int)((npix + 255) / 256);
     if (grid > h->num_cus * 8) grid = h->num_cus * 8;
@@ -955,7 +1008,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         unsigned *frag16t = (unsigned *)(bfrag + UBD_BWD_DIRECT_FLOATS);
         ubd_launch_pack16(h, params, frag16t, 1, st);
         hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
-        launch_head_wgrad<TX>(h, acts[6], dlogits, grads, partials, npix, st);
+        if (launch_head_wgrad<TX>(h, acts[6], dlogits, grads, &rq, npix, st)) return -1;
         for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];
@@ -964,41 +1017,45 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             int gw = h->num_cus * 3;
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
+            float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
+            if (!partials) return -1;
             if (tw == 8)
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
             else
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
-                               grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }
+        rp_flush(&rq, st);
         if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
         // separable layers: G1 / G2 are built tile-wise in LDS from the bf16 dDW tensor of the layer above (sepbwd16.h)
         const int pad2 = h->cfg.fml_compatible ? 1 : 0;
         const float *dw0 = params + h->off_sep_dw[0], *dw1 = params + h->off_sep_dw[1], *dw2 = params + h->off_sep_dw[2];
         const float *pw0 = params + h->off_sep_pw[0], *pw1 = params + h->off_sep_pw[1], *pw2 = params + h->off_sep_pw[2];
         unsigned short *ddw3 = (unsigned short *)(ws + T.off_ddw3), *ddw2 = (unsigned short *)(ws + T.off_gb[0]);
-        launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
-                                       grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad2, H4, W4, 0, 0.f, 1.f, st);
-        launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, (const unsigned short *)a2, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
-                                       grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, H4, W4, pad2, 0.f, 1.f, st);
+        if (launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
+                                       grads + h->off_sep_b[2], &rq, n, H2, W2, H4, W4, pad2, H4, W4, 0, 0.f, 1.f, st)) return -1;
+        if (launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, (const unsigned short *)a2, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
+                                       grads + h->off_sep_b[1], &rq, n, H2, W2, H2, W2, 1, H4, W4, pad2, 0.f, 1.f, st)) return -1;
         float sub = 0.f, div = 1.f;
         if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
         const int u8 = in_dtype == UBD_IN_U8;
+        int rc1;
         if (h->cfg.c_in == 1)
-            launch_sepb16<1, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
-                                       grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
+            rc1 = launch_sepb16<1, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+                                             grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
         else
-            launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
-                                       grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
+            rc1 = launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+                                             grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
+        if (rc1) return -1;
+        rp_flush(&rq, st);
         UBD_CHECK_HIP(hipGetLastError());
         if (ubd_comm_fused(h)) return ubd_comm_finish(h, grads, st);
         return 0;
     } else {
     // head
     hipLaunchKernelGGL((head_dx_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, acts[6], params + h->off_head_k, gq[0], npix, h->k_out);
-    launch_head_wgrad<TX>(h, acts[6], dlogits, grads, partials, npix, st);
+    if (launch_head_wgrad<TX>(h, acts[6], dlogits, grads, &rq, npix, st)) return -1;
     // dilated layers, top to bottom
     for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
         const void *X = acts[k];                                // input of dilated layer k (= output of the layer below)
@@ -1008,9 +1065,9 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             int gw = h->num_cus * 2;
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
+            float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
+            if (!partials) return -1;
             hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((217 * UBD_C + RP_COLS - 1) / RP_COLS), dim3(256), 0, st, partials, gw, 217 * UBD_C,
-                               grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, (float *)nullptr);
         }
         if (h->use_wino)
             ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, act_dtype, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
@@ -1019,29 +1076,33 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         cur ^= 1;
     }
     }
+    rp_flush(&rq, st);
     if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }       // dilated + head gradients are final
     // separable layers
     const int pad_s2 = h->cfg.fml_compatible ? 1 : 0;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
     const float *bs0 = bfrag + UBD_BWD_DGRAD_FLOATS, *bs1 = bs0 + UBD_BWD_SEP_FLOATS, *bs2 = bs1 + UBD_BWD_SEP_FLOATS;
     // L3: input a2 (H2 x W2), output H4 x W4, G = gq[cur]
-    launch_sep_bwd<UBD_C, 2, TX>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], partials, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    if (launch_sep_bwd<UBD_C, 2, TX>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], &rq, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st)) return -1;
     {
         const long tiles = (long)n * H2 * ((W2 + 15) / 16);
         const int g3 = ubd_grid_for(tiles, h->num_cus, 4, 8);
         hipLaunchKernelGGL((sep_dx_kernel<2, TX>), dim3(g3), dim3(256), 0, st, ddw3, a2, gb[0], sf2, n, H2, W2, H4, W4, pad_s2);
         // L2: input a1, output H2 x W2, G = gb[0]
-        launch_sep_bwd<UBD_C, 1, TX>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], partials, n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
+        if (launch_sep_bwd<UBD_C, 1, TX>(h, a1, 0, gb[0], gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], &rq, n, H2, W2, H2, W2, 1, 0.f, 1.f, st)) return -1;
         hipLaunchKernelGGL((sep_dx_kernel<1, TX>), dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
     }
     // L1: input = images (fp32 / uint8), no data gradient
     float sub = 0.f, div = 1.f;
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
+    int rc1;
     if (h->cfg.c_in == 1)
-        launch_sep_bwd<1, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        rc1 = launch_sep_bwd<1, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad_s2, sub, div, st);
     else
-        launch_sep_bwd<3, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], partials, n, H, W, H2, W2, pad_s2, sub, div, st);
+        rc1 = launch_sep_bwd<3, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad_s2, sub, div, st);
+    if (rc1) return -1;
+    rp_flush(&rq, st);
     UBD_CHECK_HIP(hipGetLastError());
     if (ubd_comm_fused(h)) return ubd_comm_finish(h, grads, st);
     return 0;

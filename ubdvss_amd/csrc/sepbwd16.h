@@ -51,14 +51,8 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int SDW_BYTES = 32 * SDW_W * 2;                   // two row tiles per wave
     static constexpr int OFF_WT = OFF_SDW + NW * SDW_BYTES;        // own depthwise taps [9][24] fp32 (24-channel layers)
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
-    static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,16): zeros
-    // interior-tile byte offset of every X-patch chunk (24-channel kernels): the per-piece address arithmetic of the staging
-    // (c -> pixel -> row / column -> offset: ~40 vector instructions per 1 KiB piece, 3-4 k cycles per tile and wave in the
-    // stamps of round 2) becomes one LDS read
-    static constexpr int OFF_XREL = OFF_CONST + 16;
-    static constexpr bool XTAB = (CIN == UBD_C) && (STRIDE == 2);     // the stride-1 kernel sits exactly at its 168-VGPR budget: the table path spills there
-    static constexpr int XREL_BYTES = XTAB ? XI * 64 * 4 : 0;
-    static constexpr int LDS_BYTES = OFF_XREL + XREL_BYTES;
+    static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,32): zeros ([16,32): a 16-byte zero operand)
+    static constexpr int LDS_BYTES = OFF_CONST + 32;
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
     // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
     static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : 2);
@@ -91,6 +85,15 @@ template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float 
     hi = (float)__builtin_bit_cast(T, (unsigned short)(w >> 16));
 }
 
+// g (two 16-bit values) with each half zeroed where the matching half of the saved activation m is +0 / -0
+__device__ __forceinline__ unsigned relu_mask2(unsigned g, unsigned m)
+{
+    unsigned k, r;                                   // asm: hipcc rewrites the vector form into two compares, two selects and a v_perm
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(m & 0x7FFF7FFFu), "v"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(g), "v"(k));
+    return r;
+}
+
 // LDS-DMA of one staged region (NINSTR wave-instructions of 64 x 16 B; wave `wid` of NW issues every NW-th): interior
 // tiles add a precomputed per-lane offset to the tile origin, border tiles clamp every pixel into the tensor.
 template <int NK, int NINSTR, int NCHUNKS, int COLS, int NW, int UNROLL>
@@ -118,6 +121,51 @@ __device__ __forceinline__ void sepb16_stage(const char *__restrict__ tensor, in
     }
 }
 
+// floor(n / D) for 0 <= n < NMAX as (n * m) >> sh with n * m < 2^24 (one v_mul_u32_u24 + one shift); checked at compile time
+template <int D, int NMAX> struct sepb16_magic {
+    static constexpr int find_sh()
+    {
+        for (int sh = 8; sh < 24; ++sh) {
+            const long m = (1L << sh) / D + 1;
+            if (m * NMAX >= (1L << 24)) continue;
+            bool ok = true;
+            for (long n = 0; n < NMAX && ok; ++n) ok = ((n * m) >> sh) == n / D;
+            if (ok) return sh;
+        }
+        return -1;
+    }
+    static constexpr int sh = find_sh();
+    static_assert(sh > 0, "no 24-bit magic number for this divisor / range");
+    static constexpr unsigned m = (1u << sh) / D + 1;
+};
+
+// The staging of the 24-channel kernels: chunk -> (pixel, part) -> (row, column) with two magic-number divisions, clamps as
+// v_med3 (one path for interior and border tiles), image base in scalar registers + a 32-bit per-lane offset: ~14 vector
+// instructions per 1 KiB piece instead of ~40 (the staging was 4 k of the L2 tile's 23 k cycles in the stamps of round 2; a
+// table of the chunk coordinates in LDS was slower still -- 8 k: the reads queue behind phase 2 of the CU's other blocks).
+template <int NK, int NINSTR, int NCHUNKS, int COLS, int NW>
+__device__ __forceinline__ void sepb16_stage_ar(const char *__restrict__ tensor, int img, int th, int tw, int y0, int x0,
+                                                unsigned lds_dst, int lane, int wid)
+{
+    using M3 = sepb16_magic<3, NINSTR * 64>;
+    using MC = sepb16_magic<COLS, NCHUNKS / 3 + 1>;
+    const char *base = tensor + (size_t)img * th * tw * (UBD_C * 2);                 // wave-uniform
+    asm volatile("" : "+v"(lane));         // opaque per call: hipcc otherwise keeps every piece's (row, column, part) in registers across the tile loop and spills
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int instr = k * NW + wid;
+        if (instr >= NINSTR) break;                                       // wave-uniform
+        unsigned c = (unsigned)(instr * 64 + lane);
+        c = c < (unsigned)NCHUNKS ? c : (unsigned)(NCHUNKS - 1);
+        const unsigned pix = __umul24(c, M3::m) >> M3::sh, part = c - 3u * pix;
+        const unsigned pr = __umul24(pix, MC::m) >> MC::sh, pc = pix - (unsigned)COLS * pr;
+        int gy = y0 + (int)pr, gx = x0 + (int)pc;
+        gy = min(max(gy, 0), th - 1);
+        gx = min(max(gx, 0), tw - 1);
+        ubd_glds16_sbase(base, (unsigned)((__umul24(gy, tw) + gx) * (UBD_C * 2)) + part * 16u, lds_dst + instr * 1024);
+    }
+}
+
 template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
 __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU == 3) ? 3 : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
                                                         const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
@@ -140,6 +188,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;
+    constexpr int HR_UNROLL = (CIN == UBD_C) ? 1 : 2;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];             // ONE LDS object
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
@@ -150,21 +199,14 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
     char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
     const char *c_ones = lds + C::OFF_CONST, *c_zero = lds + C::OFF_CONST + 8;
-    if (threadIdx.x < 4) ((unsigned *)(lds + C::OFF_CONST))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
+    if (threadIdx.x < 8) ((unsigned *)(lds + C::OFF_CONST))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
     if constexpr (CIN != UBD_C) {                                           // [ch.., 1, 0..] rows: the constant columns are written once
         for (int t = lane; t < 32 * C::SDW_W; t += 64) {
             const int col = t % C::SDW_W;
             ((unsigned short *)sdw)[t] = col == CIN ? __builtin_bit_cast(unsigned short, (T)1.0f) : (unsigned short)0;
         }
     }
-    int *xrel_tab = (int *)(lds + C::OFF_XREL);
-    if constexpr (C::XTAB)
-        for (int c = threadIdx.x; c < C::XI * 64; c += C::NT) {
-            const int cc = c < C::XCHUNKS ? c : C::XCHUNKS - 1;
-            const int pix = cc / 3, part = cc - pix * 3;
-            const int pr = pix / C::PW, pc = pix - pr * C::PW;
-            xrel_tab[c] = (pr * W + pc) * (UBD_C * 2) + part * 16;
-        }
+    const unsigned lds_dma = ubd_lds_addr(dma);
     unsigned *wtp = (unsigned *)(lds + C::OFF_WT);                          // own taps [9][24], packed like utp
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
@@ -189,19 +231,38 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #pragma unroll
         for (int t = 0; t < 9; ++t) dwk1[t] = q < CIN ? (float)(T)dw_own[t * CIN + q] : 0.f;
     }
-    // the 1/3-channel kernel has registers to spare: it keeps the packed taps of the layer above (stride 1: no parity
-    // selection) in 54 VGPRs instead of re-reading the table for every tap
+    // GSRC 1 (the 1/3-channel kernels; stride-1 transposed depthwise conv): the G tile is built on the matrix pipe.  Per row
+    // of 16 pixels G^T[co][pixel] = sum_taps diag(w_tap) D^T: M = output channel, N = pixel, and because the weight matrix
+    // of a depthwise tap is diagonal, the K = 32 of one v_mfma_f32_16x16x32 carries SEVERAL taps: two taps x 16 channels
+    // for channels 0..15 (five MFMAs for the nine taps), four taps x 8 channels for channels 16..23 (three MFMAs, rows
+    // permuted so that lane (pixel, q) receives channels 16 + 2q, 17 + 2q).  B operand = 16 bytes of the raw D tile at the
+    // tap's pixel, one ds_read_b128 per MFMA; 8 reads + 8 MFMAs per row instead of 18 reads + 54 v_dot2c (phase 1 was
+    // 6.2 k of the tile's 14.3 k cycles in the stamps).
     constexpr bool UREG = (CIN != UBD_C) && (GSRC == 1);
-    unsigned ureg[UREG ? 9 : 1][6];
+    u32x4 ga0[UREG ? 5 : 1], ga1[UREG ? 3 : 1];               // A operands: lane (m = i, kg = q) holds k = 8q .. 8q+7
+    int gb0[UREG ? 5 : 1], gb1[UREG ? 3 : 1];                 // B operand byte offsets inside the D tile for row 0 (row r: + r * DCOLS * 48)
     if constexpr (UREG) {
+        auto wup = [&](int t, int ch) { return (unsigned)__builtin_bit_cast(unsigned short, (T)dw_up[t * UBD_C + ch]); };
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int j = 0; j < 5; ++j) {
+            const int ts = 2 * j + (q >> 1), t = ts < 9 ? ts : 8;  // this k-group's tap; the spare slot re-reads tap 8 with zero
+            const int e = i - 8 * (q & 1);                         // weights (data this pixel sums anyway: no foreign NaN can enter)
+            unsigned w[4] = {0u, 0u, 0u, 0u};                      // k = 8q + e <-> channel 8 (q & 1) + e == row i
+            if (ts < 9 && e >= 0 && e < 8) w[e >> 1] = wup(t, i) << (16 * (e & 1));
+            ga0[j] = u32x4{w[0], w[1], w[2], w[3]};
+            const int ky = t / 3, kx = t - 3 * ky;
+            gb0[j] = ((2 - ky) * C::DCOLS + (i + 2 - kx)) * 48 + 16 * (q & 1);
+        }
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
-                const unsigned wb = (unsigned)__builtin_bit_cast(unsigned short, (T)dw_up[t * UBD_C + ch]);
-                ureg[t][s] = (ch & 1) ? (wb << 16) : wb;
-            }
+        for (int j = 0; j < 3; ++j) {
+            const int ts = 4 * j + q, t = ts < 9 ? ts : 8;         // k-group q <-> tap 4j + q, channels 16..23
+            const int qq = i >> 2, r = i & 3, e = 2 * qq + r;       // row i = 4 qq + r <-> channel 16 + 2 qq + r (r < 2)
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && r < 2) w[e >> 1] = wup(t, 16 + e) << (16 * (e & 1));
+            ga1[j] = u32x4{w[0], w[1], w[2], w[3]};
+            const int ky = t / 3, kx = t - 3 * ky;
+            gb1[j] = ((2 - ky) * C::DCOLS + (i + 2 - kx)) * 48 + 32;
+        }
     }
     // A operand of the dDW product (K = output channel co, 24 padded to 32): lane (m = i, kg = q) holds
     // pw[ch(m, tile)][8q .. 8q+7] in T (zero for q = 3); the result rows 4q + r then are this lane's own channels:
@@ -233,7 +294,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     };
     // (the 24-channel kernels have no registers to spare for them and always take the clamped path)
     constexpr bool PRE = (CIN != UBD_C);
-    int xrel[C::XK > 0 ? C::XK : 1], drel[C::DK];
+    int drel[C::DK];
     if constexpr (PRE) {
 #pragma unroll
         for (int k = 0; k < C::DK; ++k) drel[k] = chunk_rel(k * C::NW + wid, C::DPIX * 3, C::DCOLS, DW_);
@@ -278,7 +339,8 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         return g;
     };
     auto stage_dm = [&](const geom &g) {
-        sepb16_stage<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW, (PRE ? C::DK : 1)>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, drel, g.dborder || !PRE, dma + C::OFF_D, lane, wid);
+        if constexpr (CIN == UBD_C) sepb16_stage_ar<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, lds_dma + C::OFF_D, lane, wid);
+        else sepb16_stage<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW, C::DK>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, drel, g.dborder, dma + C::OFF_D, lane, wid);
     };
     // 1/3-channel input: raw bits (fp32 pattern or zero-extended byte; 0x100 / pre_sub bits = "outside", exactly 0 after the
     // preprocessing) held in registers across phase 2
@@ -314,11 +376,31 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // GSRC 0 reads its G tile (= the staged D tile) throughout phase 2, so there the D tile cannot be prefetched under
     // phase 2: it is fetched together with the X patch at the top of the tile
     constexpr bool D_AHEAD = (GSRC != 0);
+    // ReLU mask (this layer's saved output) of this wave's G rows, straight from memory (outside the map: 0 -> G = 0).  The
+    // 24-channel kernels (168-VGPR budget) request it at the top of the tile, under the DMA wait; the 1/3-channel kernels
+    // have the registers to request the NEXT tile's masks in front of phase 2 (fetched inside phase 1 they exposed a
+    // global-load latency per row: 6.3 k of the tile's 14.3 k cycles, whatever the arithmetic of phase 1 cost).
+    constexpr bool MPRE = (CIN == UBD_C), MNEXT = (GSRC != 0) && !MPRE;
+    u32x2 mka[C::TH / C::NW];
+    unsigned mkb[C::TH / C::NW];
+    auto load_masks = [&](const geom &g) {
+#pragma unroll
+        for (int kr = 0; kr < C::TH / C::NW; ++kr) {
+            const int my = g.oy0 + wid + C::NW * kr, mx = g.ox0 + i;
+            mka[kr] = u32x2{0u, 0u}; mkb[kr] = 0u;
+            if (my < OH && mx < OW) {
+                const char *pm = (const char *)maskact + (((size_t)g.img * OH + my) * OW + mx) * (UBD_C * 2);
+                mka[kr] = *(const u32x2 *)(pm + 8 * q);
+                mkb[kr] = *(const unsigned *)(pm + 32 + 4 * q);
+            }
+        }
+    };
     int tile = blockIdx.x;
     if (tile < total) {
         const geom g0 = tile_geom(tile);
         if constexpr (D_AHEAD) stage_dm(g0);
         if constexpr (CIN != UBD_C) load_x(g0);
+        if constexpr (MNEXT) load_masks(g0);
     }
     for (; tile < total; tile += gridDim.x) {
         const geom g = tile_geom(tile);
@@ -329,43 +411,19 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         SBSTAMP(1);
         if constexpr (!D_AHEAD) stage_dm(g);
         if constexpr (CIN == UBD_C) {
-            if (C::XTAB && !xborder) {                                 // block-uniform: offsets from the LDS table
-                const char *origin = (const char *)xin + (((long)img * H + iy0) * W + ix0) * (UBD_C * 2);
-#pragma unroll
-                for (int k = 0; k < C::XK; ++k) {
-                    const int instr = k * C::NW + wid;
-                    if (instr < C::XI) ubd_glds16(origin + xrel_tab[instr * 64 + lane], dma + instr * 1024);
-                }
-            } else {
-                sepb16_stage<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW, 1>((const char *)xin, img, H, W, iy0, ix0, xrel, true, dma, lane, wid);
-            }
+            sepb16_stage_ar<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW>((const char *)xin, img, H, W, iy0, ix0, lds_dma, lane, wid);
         } else {
+            const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;      // already preprocessed fp32 input: a copy (no 12-instruction division)
 #pragma unroll
             for (int k = 0; k < C::XREGS; ++k) {
                 const int e = k * C::NT + (int)threadIdx.x;
                 if (e < C::XPIX * CIN) {
                     if constexpr (IN_U8) xf32[e] = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
-                    else xf32[e] = (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
+                    else xf32[e] = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
                 }
             }
         }
-        // ReLU mask (this layer's saved output) of this wave's G rows, straight from memory; the 24-channel kernels issue
-        // the loads here so that they arrive under the DMA wait (outside the map: 0 -> G = 0)
-        constexpr bool MPRE = (CIN == UBD_C);
-        u32x2 mka[C::TH / C::NW];
-        unsigned mkb[C::TH / C::NW];
-        if constexpr (GSRC != 0 && MPRE) {
-#pragma unroll
-            for (int kr = 0; kr < C::TH / C::NW; ++kr) {
-                const int my = oy0 + wid + C::NW * kr, mx = ox0 + i;
-                mka[kr] = u32x2{0u, 0u}; mkb[kr] = 0u;
-                if (my < OH && mx < OW) {
-                    const char *pm = (const char *)maskact + (((size_t)img * OH + my) * OW + mx) * (UBD_C * 2);
-                    mka[kr] = *(const u32x2 *)(pm + 8 * q);
-                    mkb[kr] = *(const unsigned *)(pm + 32 + 4 * q);
-                }
-            }
-        }
+        if constexpr (GSRC != 0 && MPRE) load_masks(g);
         // The DMA is issued as asm (ubd_glds16, common.h): hipcc neither waits for it here nor drains the NEXT tile's D
         // DMA in front of phase 2's LDS accesses (it did with the builtin: every tile waited a full fetch latency there).
         SBSTAMP(2);
@@ -399,69 +457,51 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         SBSTAMP(4);
         // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
         if constexpr (GSRC != 0) {
-        constexpr int P1_UNROLL = MPRE ? C::TH / C::NW : 1;
-        // register-bound 1/3-channel kernel: no room for all rows' masks, so the mask of row kr + 1 is requested while row kr
-        // runs its 54 tap products (fetched in place it exposed a global-load latency per row: 6.6 k of the tile's 14.8 k cycles)
-        u32x2 ma_nx = {0u, 0u};
-        unsigned mb_nx = 0u;
-        auto fetch_mask = [&](int r, u32x2 &a, unsigned &b) {
-            a = u32x2{0u, 0u}; b = 0u;
-            if (oy0 + r < OH && ox0 + i < OW) {
-                const char *pm = (const char *)maskact + (((size_t)img * OH + oy0 + r) * OW + ox0 + i) * (UBD_C * 2);
-                a = *(const u32x2 *)(pm + 8 * q);
-                b = *(const unsigned *)(pm + 32 + 4 * q);
-            }
-        };
-        if constexpr (!MPRE) fetch_mask(wid, ma_nx, mb_nx);
-#pragma unroll P1_UNROLL
+#pragma unroll
         for (int kr = 0; kr < C::TH / C::NW; ++kr) {
             const int r = wid + C::NW * kr;
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            u32x2 ma = {0u, 0u};
-            unsigned mb = 0u;
-            if constexpr (MPRE) { ma = mka[kr]; mb = mkb[kr]; }
-            else {
-                ma = ma_nx; mb = mb_nx;
-                if (kr + 1 < C::TH / C::NW) fetch_mask(r + C::NW, ma_nx, mb_nx);
-            }
+            const u32x2 ma = mka[kr];
+            const unsigned mb = mkb[kr];
+            if constexpr (UREG) {
+                const char *rowb = draw + r * (C::DCOLS * 48);
+                u32x4 b0[5], b1[3];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) b0[j] = *(const u32x4 *)(rowb + gb0[j]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) b1[j] = *(const u32x4 *)(rowb + gb1[j]);
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 5; ++j) c0 = mfma16<T>(ga0[j], b0[j], c0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) c1 = mfma16<T>(ga1[j], b1[j], c1);
+                acc[0] = c0[0]; acc[1] = c0[1]; acc[2] = c0[2]; acc[3] = c0[3]; acc[4] = c1[0]; acc[5] = c1[1];
+            } else {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                int dr;
-                if constexpr (GSRC == 1) dr = r + 2 - ky;
-                else {
-                    if (((r + pad_up - ky) & 1) != 0) continue;     // wave-uniform: row parity (oy0 is even)
-                    dr = ((r + pad_up - ky) >> 1) + 1;
-                }
+                if (((r + pad_up - ky) & 1) != 0) continue;         // wave-uniform: row parity (oy0 is even)
+                const int dr = ((r + pad_up - ky) >> 1) + 1;
 #pragma unroll
-                for (int j = 0; j < (GSRC == 1 ? 3 : 2); ++j) {
-                    int kx, dc;
-                    if constexpr (GSRC == 1) { kx = j; dc = i + 2 - j; }
-                    else { kx = par + 2 * j; dc = ((i + pad_up - par) >> 1) + 1 - j; }   // kx = 3: zero row of the table
+                for (int j = 0; j < 2; ++j) {
+                    const int kx = par + 2 * j, dc = ((i + pad_up - par) >> 1) + 1 - j;   // kx = 3: zero row of the table
                     const char *pd = draw + (dr * C::DCOLS + dc) * 48;
                     const u32x2 a = *(const u32x2 *)(pd + 8 * q);
                     const unsigned b = *(const unsigned *)(pd + 32 + 4 * q);
-                    if constexpr (UREG) {
-                        const int t = ky * 3 + j;
-                        acc[0] = dot2b<T>(a[0], ureg[t][0], acc[0]); acc[1] = dot2b<T>(a[0], ureg[t][1], acc[1]);
-                        acc[2] = dot2b<T>(a[1], ureg[t][2], acc[2]); acc[3] = dot2b<T>(a[1], ureg[t][3], acc[3]);
-                        acc[4] = dot2b<T>(b, ureg[t][4], acc[4]);    acc[5] = dot2b<T>(b, ureg[t][5], acc[5]);
-                    } else {
-                        const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
-                        const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
-                        const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
-                        acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
-                        acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
-                        acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
-                    }
+                    const unsigned *pu = utp + (ky * 4 + kx) * UBD_C;
+                    const u32x4 w4 = *(const u32x4 *)(pu + 4 * q);
+                    const u32x2 w2 = *(const u32x2 *)(pu + 16 + 2 * q);
+                    acc[0] = dot2b<T>(a[0], w4[0], acc[0]); acc[1] = dot2b<T>(a[0], w4[1], acc[1]);
+                    acc[2] = dot2b<T>(a[1], w4[2], acc[2]); acc[3] = dot2b<T>(a[1], w4[3], acc[3]);
+                    acc[4] = dot2b<T>(b, w2[0], acc[4]);    acc[5] = dot2b<T>(b, w2[1], acc[5]);
                 }
+            }
             }
 
             u32x2 g4 = {pack2b<T>(acc[0], acc[1]), pack2b<T>(acc[2], acc[3])};
             unsigned g2 = pack2b<T>(acc[4], acc[5]);
-            // ReLU mask: the saved activation is > 0 iff its 16-bit pattern is a positive short
-            g4[0] &= (((short)(ma[0] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)ma[0] >> 16) > 0) ? 0xFFFF0000u : 0u);
-            g4[1] &= (((short)(ma[1] & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)ma[1] >> 16) > 0) ? 0xFFFF0000u : 0u);
-            g2 &= (((short)(mb & 0xFFFFu) > 0) ? 0x0000FFFFu : 0u) | ((((int)mb >> 16) > 0) ? 0xFFFF0000u : 0u);
+            // ReLU mask: the saved activation (never negative) is > 0 iff its 15 magnitude bits are non-zero; per 16-bit half
+            // min(magnitude, 1) is the 0 / 1 factor of a packed integer multiply (three instructions per channel pair)
+            g4[0] = relu_mask2(g4[0], ma[0]); g4[1] = relu_mask2(g4[1], ma[1]); g2 = relu_mask2(g2, mb);
             char *pg = g16 + (r * 16 + i) * 48;
             *(u32x2 *)(pg + 8 * q) = g4;
             *(unsigned *)(pg + 32 + 4 * q) = g2;
@@ -474,6 +514,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             const geom gn = tile_geom(tile + gridDim.x);
             if constexpr (D_AHEAD) stage_dm(gn);
             if constexpr (CIN != UBD_C) load_x(gn);
+            if constexpr (MNEXT) load_masks(gn);
         }
 
         // ---- phase 2: two row tiles (one k-block of 32 pixels) per step
@@ -481,7 +522,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #pragma unroll 1
         for (int rp = 0; rp < C::TH / (2 * C::NW); ++rp) {
             const int r0 = wid + C::NW * (2 * rp), r1 = r0 + C::NW;
-#pragma unroll 1
+#pragma unroll HR_UNROLL
             for (int hr = 0; hr < 2; ++hr) {
                 const int r = hr ? r1 : r0;
                 const int oy = oy0 + r, ox = ox0 + i;
