@@ -27,7 +27,7 @@
 template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int NW = 4;
     static constexpr int NT = NW * 64;
-    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+    static constexpr int TH = (CIN == UBD_C) ? 8 : 16;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int XPIX = PH * PW;
@@ -36,12 +36,18 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int DCOLS = GSRC == 0 ? 16 : (GSRC == 1 ? 18 : 10);
     static constexpr int DPIX = DROWS * DCOLS;
     // DMA regions (16-byte chunks, 3 per bf16 pixel; each region is a whole number of 1 KiB wave-instructions):
-    // [X patch (24 ch only)] [D tile]
+    // [X patch (24 ch only) x XBUF] [D tile] [ReLU-mask tile = this layer's saved output (GSRC 1, 2)]
+    // XBUF 2 (the stride-1 24-channel layer, 8-row tiles): the NEXT tile's X patch is fetched under phase 2 into the other
+    // buffer -- with one buffer the patch was requested at the top of the tile and the wave sat out a memory round trip
+    // there (7.7 k of 25 k cycles per tile in the stamps: the CU had ~16 KB in flight on average, 2-3 TB/s chip-wide).
+    static constexpr int XBUF = (CIN == UBD_C && STRIDE == 1) ? 2 : 1;
     static constexpr int XCHUNKS = (CIN == UBD_C) ? XPIX * 3 : 0;
     static constexpr int XI = (XCHUNKS + 63) / 64, DI = (DPIX * 3 + 63) / 64;        // wave-instructions
-    static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW;           // per wave
-    static constexpr int OFF_D = XI * 1024;                                         // byte offset of the D tile inside the DMA area
-    static constexpr int DMA_BYTES = (XI + DI) * 1024;
+    static constexpr int MI = (GSRC != 0) ? (GPIX * 3 + 63) / 64 : 0;
+    static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW, MK = (MI + NW - 1) / NW;   // per wave
+    static constexpr int OFF_D = XBUF * XI * 1024;                                  // byte offsets inside the DMA area
+    static constexpr int OFF_M = OFF_D + DI * 1024;
+    static constexpr int DMA_BYTES = OFF_M + MI * 1024;
     static constexpr int XREGS = (CIN == UBD_C) ? 1 : (XPIX * CIN + NT - 1) / NT;                           // staged input elements per thread
     static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
     static constexpr int OFF_DMA = XF32_BYTES;
@@ -92,33 +98,6 @@ __device__ __forceinline__ unsigned relu_mask2(unsigned g, unsigned m)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(m & 0x7FFF7FFFu), "v"(0x00010001u));
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(g), "v"(k));
     return r;
-}
-
-// LDS-DMA of one staged region (NINSTR wave-instructions of 64 x 16 B; wave `wid` of NW issues every NW-th): interior
-// tiles add a precomputed per-lane offset to the tile origin, border tiles clamp every pixel into the tensor.
-template <int NK, int NINSTR, int NCHUNKS, int COLS, int NW, int UNROLL>
-__device__ __forceinline__ void sepb16_stage(const char *__restrict__ tensor, int img, int th, int tw, int y0, int x0,
-                                             const int (&rel)[NK > 0 ? NK : 1], bool border, char *dst, int lane, int wid)
-{
-    const char *origin = tensor + (((long)img * th + y0) * tw + x0) * (UBD_C * 2);      // only dereferenced when interior
-#pragma unroll UNROLL
-    for (int k = 0; k < NK; ++k) {
-        const int instr = k * NW + wid;
-        if (instr >= NINSTR) break;                                       // wave-uniform
-        const char *src;
-        if (!border) src = origin + rel[k];
-        else {
-            int c = instr * 64 + lane;
-            c = c < NCHUNKS ? c : NCHUNKS - 1;
-            const int pix = c / 3, part = c - pix * 3;
-            const int pr = pix / COLS, pc = pix - pr * COLS;
-            int gy = y0 + pr, gx = x0 + pc;
-            gy = gy < 0 ? 0 : (gy >= th ? th - 1 : gy);
-            gx = gx < 0 ? 0 : (gx >= tw ? tw - 1 : gx);
-            src = tensor + (((size_t)img * th + gy) * tw + gx) * (UBD_C * 2) + part * 16;
-        }
-        ubd_glds16(src, dst + instr * 1024);                              // asm form: retired by the caller's explicit vmcnt(0)
-    }
 }
 
 // floor(n / D) for 0 <= n < NMAX as (n * m) >> sh with n * m < 2^24 (one v_mul_u32_u24 + one shift); checked at compile time
@@ -194,8 +173,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     const int i = lane & 15, q = lane >> 4;
     float *xf32 = (float *)lds;                                                  // 1/3-channel patch (fp32)
     char *dma = lds + C::OFF_DMA;
-    const char *xraw = dma;                                                      // 24-channel patch (bf16)
-    const char *draw = dma + C::OFF_D;
+    const char *draw = dma + C::OFF_D, *mraw = dma + C::OFF_M;                   // D tile, ReLU-mask tile (raw 16-bit activations)
     char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
     char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
     const char *c_ones = lds + C::OFF_CONST, *c_zero = lds + C::OFF_CONST + 8;
@@ -283,22 +261,6 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // GSRC 2 (stride-2 transposed conv): the taps that reach this lane's pixel column have kx = par, par + 2
     const int par = (i + pad_up) & 1;
 
-    // staging offsets of interior tiles (everything inside its tensor): byte offset of this lane's 16-byte chunk relative
-    // to the tile origin, per wave-instruction; border tiles recompute clamped addresses
-    auto chunk_rel = [&](int instr, int nchunks, int cols, int row_pitch_pix) {
-        int c = instr * 64 + lane;
-        c = c < nchunks ? c : nchunks - 1;
-        const int pix = c / 3, part = c - pix * 3;
-        const int pr = pix / cols, pc = pix - pr * cols;
-        return (pr * row_pitch_pix + pc) * (UBD_C * 2) + part * 16;
-    };
-    // (the 24-channel kernels have no registers to spare for them and always take the clamped path)
-    constexpr bool PRE = (CIN != UBD_C);
-    int drel[C::DK];
-    if constexpr (PRE) {
-#pragma unroll
-        for (int k = 0; k < C::DK; ++k) drel[k] = chunk_rel(k * C::NW + wid, C::DPIX * 3, C::DCOLS, DW_);
-    }
     int ld_rel[C::XREGS];                                                       // 1/3 channels: element offsets
     if constexpr (CIN != UBD_C) {
 #pragma unroll
@@ -323,7 +285,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // Tile geometry and the staging steps.  Pipeline per tile: [X patch DMA (24 ch)] -> wait -> phase 1 (D, mask -> G tile)
     // -> D / mask DMA of the NEXT tile (their LDS regions are free again) and, for 1/3 channels, the next tile's input
     // loads into registers -> phase 2.  Only the 24-channel X patch (single-buffered) is fetched with exposed latency.
-    struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder; };
+    struct geom { int img, oy0, ox0, iy0, ix0, dy0, dx0; bool xborder, dborder, mborder; };
     ubd_tile_decoder tdec;
     tdec.init(tiles_x, tiles_y, total);
     auto tile_geom = [&](int tile) {
@@ -336,11 +298,19 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         g.dx0 = GSRC == 0 ? g.ox0 : (GSRC == 1 ? g.ox0 - 1 : (g.ox0 >> 1) - 1);
         g.xborder = (g.iy0 < 0) || (g.ix0 < 0) || (g.iy0 + C::PH > H) || (g.ix0 + C::PW > W);
         g.dborder = (g.dy0 < 0) || (g.dx0 < 0) || (g.dy0 + C::DROWS > DH) || (g.dx0 + C::DCOLS > DW_);
+        g.mborder = (g.oy0 + C::TH > OH) || (g.ox0 + 16 > OW);
         return g;
     };
+    // D tile and, for GSRC 1 / 2, the ReLU-mask tile (this layer's saved output under the G tile; used once per pixel in
+    // phase 1, so both regions are free for the next tile's data as soon as phase 1 is over)
     auto stage_dm = [&](const geom &g) {
-        if constexpr (CIN == UBD_C) sepb16_stage_ar<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, lds_dma + C::OFF_D, lane, wid);
-        else sepb16_stage<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW, C::DK>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, drel, g.dborder, dma + C::OFF_D, lane, wid);
+        sepb16_stage_ar<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, lds_dma + C::OFF_D, lane, wid);
+        if constexpr (GSRC != 0)
+            sepb16_stage_ar<C::MK, C::MI, C::GPIX * 3, 16, C::NW>((const char *)maskact, g.img, OH, OW, g.oy0, g.ox0, lds_dma + C::OFF_M, lane, wid);
+    };
+    auto stage_x = [&](const geom &g, int buf) {
+        if constexpr (CIN == UBD_C)
+            sepb16_stage_ar<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW>((const char *)xin, g.img, H, W, g.iy0, g.ix0, lds_dma + buf * (C::XI * 1024), lane, wid);
     };
     // 1/3-channel input: raw bits (fp32 pattern or zero-extended byte; 0x100 / pre_sub bits = "outside", exactly 0 after the
     // preprocessing) held in registers across phase 2
@@ -376,42 +346,26 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // GSRC 0 reads its G tile (= the staged D tile) throughout phase 2, so there the D tile cannot be prefetched under
     // phase 2: it is fetched together with the X patch at the top of the tile
     constexpr bool D_AHEAD = (GSRC != 0);
-    // ReLU mask (this layer's saved output) of this wave's G rows, straight from memory (outside the map: 0 -> G = 0).  The
-    // 24-channel kernels (168-VGPR budget) request it at the top of the tile, under the DMA wait; the 1/3-channel kernels
-    // have the registers to request the NEXT tile's masks in front of phase 2 (fetched inside phase 1 they exposed a
-    // global-load latency per row: 6.3 k of the tile's 14.3 k cycles, whatever the arithmetic of phase 1 cost).
-    constexpr bool MPRE = (CIN == UBD_C), MNEXT = (GSRC != 0) && !MPRE;
-    u32x2 mka[C::TH / C::NW];
-    unsigned mkb[C::TH / C::NW];
-    auto load_masks = [&](const geom &g) {
-#pragma unroll
-        for (int kr = 0; kr < C::TH / C::NW; ++kr) {
-            const int my = g.oy0 + wid + C::NW * kr, mx = g.ox0 + i;
-            mka[kr] = u32x2{0u, 0u}; mkb[kr] = 0u;
-            if (my < OH && mx < OW) {
-                const char *pm = (const char *)maskact + (((size_t)g.img * OH + my) * OW + mx) * (UBD_C * 2);
-                mka[kr] = *(const u32x2 *)(pm + 8 * q);
-                mkb[kr] = *(const unsigned *)(pm + 32 + 4 * q);
-            }
-        }
-    };
+    constexpr bool X_AHEAD = (C::XBUF == 2);
+    int xb = 0;                                                         // X buffer of the current tile
     int tile = blockIdx.x;
     if (tile < total) {
         const geom g0 = tile_geom(tile);
         if constexpr (D_AHEAD) stage_dm(g0);
         if constexpr (CIN != UBD_C) load_x(g0);
-        if constexpr (MNEXT) load_masks(g0);
+        if constexpr (X_AHEAD) stage_x(g0, 0);
     }
     for (; tile < total; tile += gridDim.x) {
         const geom g = tile_geom(tile);
         const int img = g.img, oy0 = g.oy0, ox0 = g.ox0, ix0 = g.ix0, iy0 = g.iy0, dy0 = g.dy0, dx0 = g.dx0;
-        const bool xborder = g.xborder, dborder = g.dborder;
+        const bool xborder = g.xborder, dborder = g.dborder, mborder = (GSRC != 0) && g.mborder;
+        const char *xraw = dma + xb * (C::XI * 1024);                  // 24-channel patch (bf16)
         SBSTAMP(0);
         __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
         SBSTAMP(1);
         if constexpr (!D_AHEAD) stage_dm(g);
         if constexpr (CIN == UBD_C) {
-            sepb16_stage_ar<C::XK, C::XI, C::XCHUNKS, C::PW, C::NW>((const char *)xin, img, H, W, iy0, ix0, lds_dma, lane, wid);
+            if constexpr (!X_AHEAD) stage_x(g, 0);
         } else {
             const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;      // already preprocessed fp32 input: a copy (no 12-instruction division)
 #pragma unroll
@@ -423,22 +377,20 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                 }
             }
         }
-        if constexpr (GSRC != 0 && MPRE) load_masks(g);
         // The DMA is issued as asm (ubd_glds16, common.h): hipcc neither waits for it here nor drains the NEXT tile's D
         // DMA in front of phase 2's LDS accesses (it did with the builtin: every tile waited a full fetch latency there).
         SBSTAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this tile's DMA (and the mask loads) have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this tile's DMA has landed
         __syncthreads();                                               // ... for every wave; LDS writes visible
-        SBSTAMP(3);
         {
-            if ((CIN == UBD_C && xborder) || dborder) {                // block-uniform
+            if ((CIN == UBD_C && xborder) || dborder || mborder) {     // block-uniform
                 const u32x4 zero = {0u, 0u, 0u, 0u};
                 if (CIN == UBD_C && xborder)
                     for (int pix = threadIdx.x; pix < C::XPIX; pix += C::NT) {
                         const int pr = pix / C::PW, pc = pix - pr * C::PW;
                         const int gy = iy0 + pr, gx = ix0 + pc;
                         if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                            u32x4 *z = (u32x4 *)(dma + pix * 48);
+                            u32x4 *z = (u32x4 *)(const_cast<char *>(xraw) + pix * 48);
                             z[0] = zero; z[1] = zero; z[2] = zero;
                         }
                     }
@@ -451,18 +403,24 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                             z[0] = zero; z[1] = zero; z[2] = zero;
                         }
                     }
+                if (mborder)                                           // G pixels outside the map: mask 0 -> G = 0
+                    for (int pix = threadIdx.x; pix < C::GPIX; pix += C::NT)
+                        if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
+                            u32x4 *z = (u32x4 *)(dma + C::OFF_M + pix * 48);
+                            z[0] = zero; z[1] = zero; z[2] = zero;
+                        }
                 __syncthreads();
             }
         }
-        SBSTAMP(4);
+        SBSTAMP(3);
         // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
         if constexpr (GSRC != 0) {
 #pragma unroll
         for (int kr = 0; kr < C::TH / C::NW; ++kr) {
             const int r = wid + C::NW * kr;
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const u32x2 ma = mka[kr];
-            const unsigned mb = mkb[kr];
+            const u32x2 ma = *(const u32x2 *)(mraw + (r * 16 + i) * 48 + 8 * q);
+            const unsigned mb = *(const unsigned *)(mraw + (r * 16 + i) * 48 + 32 + 4 * q);
             if constexpr (UREG) {
                 const char *rowb = draw + r * (C::DCOLS * 48);
                 u32x4 b0[5], b1[3];
@@ -507,15 +465,16 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             *(unsigned *)(pg + 32 + 4 * q) = g2;
         }
         }
-        SBSTAMP(5);
+        SBSTAMP(4);
         __syncthreads();
-        SBSTAMP(6);
+        SBSTAMP(5);
         if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
             const geom gn = tile_geom(tile + gridDim.x);
             if constexpr (D_AHEAD) stage_dm(gn);
             if constexpr (CIN != UBD_C) load_x(gn);
-            if constexpr (MNEXT) load_masks(gn);
+            if constexpr (X_AHEAD) stage_x(gn, xb ^ 1);
         }
+        SBSTAMP(6);
 
         // ---- phase 2: two row tiles (one k-block of 32 pixels) per step
         const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;   // roles in the transposed reads (bwd16.h)
@@ -632,6 +591,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #ifdef UBD_STAMPS
         ++stamp_it;
 #endif
+        if constexpr (X_AHEAD) xb ^= 1;
     }
 #undef SBSTAMP
     // ---- flush: wave-sequential reduction of the per-lane sums into this block's row of the partial-sum matrix
