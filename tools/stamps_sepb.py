@@ -16,18 +16,19 @@ x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32)
 y = torch.from_numpy(lab).cuda()
 for _ in range(100): tr.train_step_on_device(x, y)
 lib.ubd_debug_set_stamps_sepb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; lib.ubd_debug_set_stamps_sepb.restype = None
-names = ["top barrier", "stage X / write xf32 / mask loads", "wait DMA + barrier + border fix", "phase 1 (G tile)", "barrier", "next tile: D DMA / x / mask loads", "phase 2"]
+names = ["top barrier", "stage X / write xf32 / mask loads", "wait DMA + barrier + border fix", "phase 1 (G tile)", "barrier", "next tile: D DMA / x / mask loads", "phase 2a (dDW, depthwise, dpw)", "barrier", "phase 2b (ddw)"]
 for cin, stride in ((24, 1), (3, 2), (24, 2)):
-    st = torch.zeros((1024, 4, 8, 8), dtype=torch.int64, device="cuda")
+    st = torch.zeros((1024, 4, 8, 12), dtype=torch.int64, device="cuda")
     lib.ubd_debug_set_stamps_sepb(st.data_ptr(), cin, stride)
     tr.train_step_on_device(x, y); torch.cuda.synchronize()
     lib.ubd_debug_set_stamps_sepb(None, 0, 0)
     s = st.cpu().numpy()
     used = s[:, 0, 2, 0] > 0
     s = s[used]
-    seg = np.diff(s[:, :, 1:7, :], axis=-1)          # (blk, wave, tile 1..6, 7 segments between the 8 stamps)
-    nxt = s[:, :, 2:8, 0] - s[:, :, 1:7, 7]          # end of phase 2 -> top of the next tile
+    if not (s[0, 0, 2, 8] > 0): s[:, :, :, 7] = s[:, :, :, 9]; s[:, :, :, 8] = s[:, :, :, 9]   # 1/3-channel kernel: phase 2 in one piece
+    seg = np.diff(s[:, :, 1:7, :10], axis=-1)          # (blk, wave, tile 1..6, 7 segments between the 8 stamps)
+    nxt = s[:, :, 2:8, 0] - s[:, :, 1:7, 9]          # end of phase 2 -> top of the next tile
     period = s[:, 0, 2:8, 0] - s[:, 0, 1:7, 0]
     print(f"sepb16<{cin},{stride}>: blocks {used.sum()}, tile period median {np.median(period):.0f} cycles")
     for w in range(4):
-        print(f"  wave {w}: " + "  ".join(f"{names[k]}: {np.median(seg[:, w, :, k]):.0f}" for k in range(7)) + f"  loop: {np.median(nxt[:, w]):.0f}")
+        print(f"  wave {w}: " + "  ".join(f"{names[k]}: {np.median(seg[:, w, :, k]):.0f}" for k in range(9)) + f"  loop: {np.median(nxt[:, w]):.0f}")

@@ -55,7 +55,8 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int OFF_SDW = OFF_G + (GSRC == 0 ? 0 : GPIX * UBD_C * 2);   // per-wave depthwise-output images
     static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // columns per pixel ([ch.., 1, 0..] for 1/3 channels)
     static constexpr int SDW_BYTES = 32 * SDW_W * 2;                   // two row tiles per wave
-    static constexpr int OFF_WT = OFF_SDW + NW * SDW_BYTES;        // own depthwise taps [9][24] fp32 (24-channel layers)
+    static constexpr int OFF_SDD = OFF_SDW + NW * SDW_BYTES;       // per-wave dDW images [32 pixels][24] in T (24-channel layers)
+    static constexpr int OFF_WT = OFF_SDD + (CIN == UBD_C ? NW * SDW_BYTES : 0);   // (unused since the depthwise recompute moved to the matrix pipe)
     static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
     static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,32): zeros ([16,32): a 16-byte zero operand)
     static constexpr int LDS_BYTES = OFF_CONST + 32;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 {
 #ifdef UBD_STAMPS   // diagnostic build only: s_memtime of lane 0 of every wave at the phase boundaries of its first 8 tiles
     int stamp_it = 0;
-#define SBSTAMP(k) do { if (stamps && stamp_it < 8 && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + stamp_it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SBSTAMP(k) do { if (stamps && stamp_it < 8 && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + stamp_it) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SBSTAMP(k) do {} while (0)
 #endif
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     const char *draw = dma + C::OFF_D, *mraw = dma + C::OFF_M;                   // D tile, ReLU-mask tile (raw 16-bit activations)
     char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
     char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
+    char *sdd = lds + C::OFF_SDD + wid * C::SDW_BYTES;                      // ... and dDW values (24-channel layers)
     const char *c_ones = lds + C::OFF_CONST, *c_zero = lds + C::OFF_CONST + 8;
     if (threadIdx.x < 8) ((unsigned *)(lds + C::OFF_CONST))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
     if constexpr (CIN != UBD_C) {                                           // [ch.., 1, 0..] rows: the constant columns are written once
@@ -242,6 +244,54 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             gb1[j] = ((2 - ky) * C::DCOLS + (i + 2 - kx)) * 48 + 32;
         }
     }
+    // 24-channel layers, phase 2 on the matrix pipe (M2).  The depthwise recompute uses the same tap-folded diagonal
+    // operands as the G tile above, with this layer's own taps.  The depthwise-kernel gradient ddw[t][c] = sum_p X[p + t][c]
+    // dDW[p][c] is the diagonal of X_t^T dDW with K = pixel: one MFMA per tap for channels 0..15 (A = X shifted by the tap,
+    // B = dDW, both read transposed from their [pixel][24] LDS images), and for channels 16..23 two taps share an MFMA (rows
+    // 0..7 / 8..15 of A, B = those eight dDW channels twice): 14 MFMAs per 32 pixels whose diagonals are the 216 sums --
+    // instead of 108 half-empty v_dot2c per 16 pixels (phase 2 was issue-bound: ~210 instructions per 16-pixel row).
+    constexpr bool M2 = (CIN == UBD_C);
+    u32x4 wa0[M2 ? 5 : 1], wa1[M2 ? 3 : 1];
+    int xo0[M2 ? 5 : 1], xo1[M2 ? 3 : 1];                     // B operand byte offsets inside the X patch for tile row 0
+    // The 14 ddw accumulators are OWNED by waves (unit u = tap 0..8 for channels 0..15, 9..13 = tap pairs for channels
+    // 16..23; wave w owns units w, w + 4, w + 8, w + 12): every wave runs its units over ALL k-blocks of the tile after a
+    // block barrier, so a wave holds 4 accumulators instead of 14 (56 VGPRs do not fit beside the rest at 3 waves per SIMD)
+    // and its sums are complete -- no cross-wave reduction at the end.
+    f32x4 accdw[M2 ? 4 : 1] = {};
+    int uo[M2 ? 4 : 1];                                        // per slot: tap offset + this lane's segment inside the pixel
+    if constexpr (M2) {
+        static_assert(!M2 || C::TH == 2 * C::NW, "one k-block (two tile rows) per wave");
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int u = wid + 4 * sl, p4 = lane & 3;
+            if (u < 9) uo[sl] = 8 * p4 + ((u / 3) * C::PW + u % 3) * 48;
+            else {
+                const int jj = u - 9, t0 = jj < 3 ? 3 * jj : (jj == 3 ? 2 : 8);
+                uo[sl] = 32 + 8 * (p4 & 1) + (p4 >= 2 ? (jj == 3 ? C::PW : 1) * 48 : 0) + ((t0 / 3) * C::PW + t0 % 3) * 48;
+            }
+        }
+        auto wown = [&](int t, int ch) { return (unsigned)__builtin_bit_cast(unsigned short, (T)dw_own[t * UBD_C + ch]); };
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ts = 2 * j + (q >> 1), t = ts < 9 ? ts : 8;
+            const int e = i - 8 * (q & 1);
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && e >= 0 && e < 8) w[e >> 1] = wown(t, i) << (16 * (e & 1));
+            wa0[j] = u32x4{w[0], w[1], w[2], w[3]};
+            const int ky = t / 3, kx = t - 3 * ky;
+            xo0[j] = (ky * C::PW + i * STRIDE + kx) * 48 + 16 * (q & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ts = 4 * j + q, t = ts < 9 ? ts : 8;
+            const int qq4 = i >> 2, r = i & 3, e = 2 * qq4 + r;
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && r < 2) w[e >> 1] = wown(t, 16 + e) << (16 * (e & 1));
+            wa1[j] = u32x4{w[0], w[1], w[2], w[3]};
+            const int ky = t / 3, kx = t - 3 * ky;
+            xo1[j] = (ky * C::PW + i * STRIDE + kx) * 48 + 32;
+        }
+    }
     // A operand of the dDW product (K = output channel co, 24 padded to 32): lane (m = i, kg = q) holds
     // pw[ch(m, tile)][8q .. 8q+7] in T (zero for q = 3); the result rows 4q + r then are this lane's own channels:
     // tile 0 -> 4q + r, tile 1 (r < 2) -> 16 + 2q + r; 1/3 channels: tile 0 only, row 4q -> channel q
@@ -273,9 +323,9 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
     }
 
-    float ddw[9][CPL];
+    float ddw[M2 ? 1 : 9][CPL];                                 // 1/3 channels: per-lane sums (VALU)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < (M2 ? 1 : 9); ++t)
 #pragma unroll
         for (int s = 0; s < CPL; ++s) ddw[t][s] = 0.f;
     f32x4 accpw[MT_PW][2] = {};
@@ -481,6 +531,43 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #pragma unroll 1
         for (int rp = 0; rp < C::TH / (2 * C::NW); ++rp) {
             const int r0 = wid + C::NW * (2 * rp), r1 = r0 + C::NW;
+            if constexpr (M2) {
+#pragma unroll 1
+            for (int hr = 0; hr < 2; ++hr) {
+                const int r = hr ? r1 : r0;
+                const int oy = oy0 + r, ox = ox0 + i;
+                // dDW[pixel i][ch] = sum_co G[i][co] pw[ch][co] (rows = this lane's channels), stored and kept in T
+                u32x4 gb = *(const u32x4 *)(g16 + (r * 16 + i) * 48 + 16 * (q < 3 ? q : 0));
+                if (q == 3) gb = u32x4{0u, 0u, 0u, 0u};
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 dA = mfma16<T>(apwb[0], gb, z4), dB = mfma16<T>(apwb[1], gb, z4);
+                // depthwise recompute: sum_taps diag(w_tap) X^T, taps folded into K (8 reads + 8 MFMAs)
+                const char *rowb = xraw + r * (STRIDE * C::PW * 48);
+                u32x4 b0[5], b1[3];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) b0[j] = *(const u32x4 *)(rowb + xo0[j]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) b1[j] = *(const u32x4 *)(rowb + xo1[j]);
+                f32x4 c0 = z4, c1 = z4;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) c0 = mfma16<T>(wa0[j], b0[j], c0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) c1 = mfma16<T>(wa1[j], b1[j], c1);
+                const u32x2 d4 = {pack2b<T>(dA[0], dA[1]), pack2b<T>(dA[2], dA[3])};
+                const unsigned d2 = pack2b<T>(dB[0], dB[1]);
+                char *pdd = sdd + (hr * 16 + i) * 48;
+                *(u32x2 *)(pdd + 8 * q) = d4;
+                *(unsigned *)(pdd + 32 + 4 * q) = d2;
+                if (dDW != nullptr && oy < OH && ox < OW) {            // 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
+                    char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
+                    *(u32x2 *)(pd + 8 * q) = d4;
+                    *(unsigned *)(pd + 32 + 4 * q) = d2;
+                }
+                char *ps = sdw + (hr * 16 + i) * 48;                   // depthwise output in T (as the forward pass stored it)
+                *(u32x2 *)(ps + 8 * q) = u32x2{pack2b<T>(c0[0], c0[1]), pack2b<T>(c0[2], c0[3])};
+                *(unsigned *)(ps + 32 + 4 * q) = pack2b<T>(c1[0], c1[1]);
+            }
+            } else {
 #pragma unroll HR_UNROLL
             for (int hr = 0; hr < 2; ++hr) {
                 const int r = hr ? r1 : r0;
@@ -549,6 +636,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                     if (ch_ok) ((unsigned short *)sdw)[(hr * 16 + i) * C::SDW_W + cb] = __builtin_bit_cast(unsigned short, (T)dwv[0]);
                 }
             }
+            }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // dpw[ch][co] += sum over the 32 pixels DW[pixel][ch] G[pixel][co]; an all-ones column of the A operand gives db.
@@ -587,7 +675,50 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        SBSTAMP(7);
+        if constexpr (M2) {
+            // ddw: B = dDW^T of a k-block (channels 0..15; channels 16..23 twice), A = X^T shifted by the unit's tap; pixel k of
+            // k-block kb sits at patch pixel ((k < 16 ? kb : kb + NW) * STRIDE + ky) * PW + (k & 15) * STRIDE + kx.  Channels
+            // 16..23: tap pairs (0,1) (3,4) (6,7) (2,5) (8,-): segments pp < 2 read the first tap, pp >= 2 the second (one pixel
+            // to the right, or one patch row down for (2,5); the partner of tap 8 reads finite padding and is never used).
+            SBSTAMP(7);
+            __syncthreads();                                           // every wave's dDW image is complete
+            SBSTAMP(8);
+            int ka[2];                                                 // this lane's pixel of read j, relative to the k-block's first row
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = 8 * grp + 4 * j + qq;
+                ka[j] = ((k < 16 ? 0 : C::NW * STRIDE * C::PW) + (k & 15) * STRIDE) * 48;
+            }
+#pragma unroll 1
+            for (int kb = 0; kb < C::NW; ++kb) {
+                const char *sddk = lds + C::OFF_SDD + kb * C::SDW_BYTES;
+                u32x4 bd[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    s16x4 h[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = 8 * grp + 4 * j + qq;
+                        const char *pb = sddk + k * 48 + (nt == 0 ? 8 * pp : 32 + 8 * (pp & 1));
+                        h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
+                    }
+                    bd[nt] = __builtin_bit_cast(u32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                const char *xr0 = xraw + kb * (STRIDE * C::PW * 48);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (sl == 3 && wid >= 2) break;                    // wave-uniform: units 14, 15 do not exist
+                    s16x4 h[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        h[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(xr0 + ka[j] + uo[sl]));
+                    const bool low = sl < 2 || (sl == 2 && wid == 0);  // wave-uniform: unit < 9 -> channels 0..15
+                    const u32x4 bsel = low ? bd[0] : bd[1];
+                    accdw[sl] = mfma16<T>(__builtin_bit_cast(u32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7)), bsel, accdw[sl]);
+                }
+            }
+        }
+        SBSTAMP(9);
 #ifdef UBD_STAMPS
         ++stamp_it;
 #endif
@@ -600,21 +731,36 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     float *red = (float *)lds;
     for (int t = threadIdx.x; t < C::PART; t += blockDim.x) red[t] = 0.f;
     __syncthreads();
+    if constexpr (!M2) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) {
-            float v = ddw[t][s];
+        for (int t = 0; t < 9; ++t) {
+            float v = ddw[t][0];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            ddw[t][s] = v;
+            ddw[t][0] = v;
         }
+    }
     for (int ph = 0; ph < C::NW; ++ph) {
         if (wid == ph) {
+            if constexpr (M2) {
+                // diagonals of this wave's ddw accumulators: column i, row i sits in lane (i, q = i >> 2), element i & 3
+                if (q == (i >> 2)) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int u = wid + 4 * sl;
+                        const float v = (i & 3) == 0 ? accdw[sl][0] : ((i & 3) == 1 ? accdw[sl][1] : ((i & 3) == 2 ? accdw[sl][2] : accdw[sl][3]));
+                        if (u < 9) red[u * UBD_C + i] += v;
+                        else if (u < 14) {
+                            const int jj = u - 9, t0 = jj < 3 ? 3 * jj : (jj == 3 ? 2 : 8), t1 = jj < 3 ? 3 * jj + 1 : (jj == 3 ? 5 : -1);
+                            const int t = i < 8 ? t0 : t1;
+                            if (t >= 0) red[t * UBD_C + 16 + (i & 7)] += v;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int s = 0; s < CPL; ++s)
-                    if (i == 0 && ch_ok) red[t * CIN + ((CIN == UBD_C) ? (s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4)) : cb)] += ddw[t][s];
+                for (int t = 0; t < 9; ++t)
+                    if (i == 0 && ch_ok) red[t * CIN + cb] += ddw[t][0];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT_PW; ++mt)
 #pragma unroll
