@@ -311,15 +311,17 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // GSRC 2 (stride-2 transposed conv): the taps that reach this lane's pixel column have kx = par, par + 2
     const int par = (i + pad_up) & 1;
 
-    int ld_rel[C::XREGS];                                                       // 1/3 channels: element offsets
+    // 1/3 channels: element e = threadIdx.x + 256 k of the [PH][PW * CIN] patch as (row << 16 | column-in-floats); the
+    // address is image base (scalar registers) + a 32-bit element offset -- the size_t index arithmetic of round 1 cost five
+    // quarter-rate v_mad_u64_u32 per element on border tiles
+    int xpk[C::XREGS];
     if constexpr (CIN != UBD_C) {
 #pragma unroll
         for (int k = 0; k < C::XREGS; ++k) {
             int e = k * C::NT + (int)threadIdx.x;
             e = e < C::XPIX * CIN ? e : C::XPIX * CIN - 1;
-            const int pix = e / CIN, ch = e - pix * CIN;
-            const int pr = pix / C::PW, pc = pix - pr * C::PW;
-            ld_rel[k] = (pr * W + pc) * CIN + ch;
+            const int pr = e / (C::PW * CIN);
+            xpk[k] = (pr << 16) | (e - pr * (C::PW * CIN));
         }
     }
 
@@ -366,29 +368,24 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // preprocessing) held in registers across phase 2
     unsigned xreg[C::XREGS];
     auto load_x = [&](const geom &g) {
-        if (!g.xborder) {
-            const size_t origin = (((size_t)g.img * H + g.iy0) * W + g.ix0) * CIN;
+        const int WC = W * CIN;
+        const unsigned char *img8 = (const unsigned char *)xin + (size_t)g.img * H * WC * (IN_U8 ? 1 : 4);   // wave-uniform
+        const int fx0 = g.ix0 * CIN;
+        if (!g.xborder) {                                             // block-uniform
+            const unsigned o0 = (unsigned)(g.iy0 * WC + fx0);
 #pragma unroll
             for (int k = 0; k < C::XREGS; ++k) {
-                if constexpr (IN_U8) xreg[k] = ((const unsigned char *)xin)[origin + ld_rel[k]];
-                else xreg[k] = ((const unsigned *)xin)[origin + ld_rel[k]];
+                const unsigned off = o0 + (unsigned)__umul24(xpk[k] >> 16, WC) + (unsigned)(xpk[k] & 0xFFFF);
+                if constexpr (IN_U8) xreg[k] = img8[off];
+                else xreg[k] = ((const unsigned *)img8)[off];
             }
-        } else {
-#pragma unroll
+        } else {                                                      // clamped address; the elements outside the image are replaced
+#pragma unroll                                                        // where the registers are consumed (a select here would wait for the loads)
             for (int k = 0; k < C::XREGS; ++k) {
-                const int e = k * C::NT + (int)threadIdx.x;
-                unsigned v = IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);
-                if (e < C::XPIX * CIN) {
-                    const int pix = e / CIN, ch = e - pix * CIN;
-                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                    const int gy = g.iy0 + pr, gx = g.ix0 + pc;
-                    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                        const size_t ge = (((size_t)g.img * H + gy) * W + gx) * CIN + ch;
-                        if constexpr (IN_U8) v = ((const unsigned char *)xin)[ge];
-                        else v = ((const unsigned *)xin)[ge];
-                    }
-                }
-                xreg[k] = v;
+                const int gy = g.iy0 + (xpk[k] >> 16), gf = fx0 + (xpk[k] & 0xFFFF);
+                const unsigned off = (unsigned)(min(max(gy, 0), H - 1) * WC + min(max(gf, 0), WC - 1));
+                if constexpr (IN_U8) xreg[k] = img8[off];
+                else xreg[k] = ((const unsigned *)img8)[off];
             }
         }
     };
@@ -418,6 +415,14 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             if constexpr (!X_AHEAD) stage_x(g, 0);
         } else {
             const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;      // already preprocessed fp32 input: a copy (no 12-instruction division)
+            if (xborder) {                                             // block-uniform: outside the image = exactly 0 after the preprocessing
+#pragma unroll
+                for (int k = 0; k < C::XREGS; ++k) {
+                    const int gy = iy0 + (xpk[k] >> 16), gf = ix0 * CIN + (xpk[k] & 0xFFFF);
+                    const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gf < (unsigned)(W * CIN);
+                    xreg[k] = inside ? xreg[k] : (IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub));
+                }
+            }
 #pragma unroll
             for (int k = 0; k < C::XREGS; ++k) {
                 const int e = k * C::NT + (int)threadIdx.x;
