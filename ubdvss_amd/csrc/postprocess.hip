@@ -815,15 +815,21 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const size_t pbase = (size_t)img * hw;
     const int hw64 = (hw + 63) & ~63;
+    // pixel -> (row, column) without an integer division by the run-time width (~25 vector instructions each, once per pixel
+    // and phase on a kernel that is issue-bound at 16 waves per CU): floor((loc + 0.5) * (1 / w)) is exact for loc < hw <= 2^14
+    // (the quotient's distance to the next integer is >= 0.5 / w, i.e. >= 2^-15 relative, against 2^-22 of rounding)
+    const float rcp_w = 1.0f / (float)w;
+    auto row_of = [&](int loc) { return (int)(((float)loc + 0.5f) * rcp_w); };
 
     // ---- init (pp_init_kernel); the thread's logits are requested up front, PP_LDS_MAX_HW / PP_LDS_THREADS at most
     if (tid < 2) ctr[tid] = 0;
     constexpr int PER_THREAD = PP_LDS_MAX_HW / PP_LDS_THREADS;
-    float lg[PER_THREAD];
-#pragma unroll
+    float lg[PER_THREAD], lgl[PER_THREAD];                     // lgl: logit left of the wave's first pixel (lane 0 only), requested with the
+#pragma unroll                                               // rest: fetched inside the loop it was one dependent memory round trip per iteration
     for (int it = 0; it < PER_THREAD; ++it) {
         const int loc = tid + it * PP_LDS_THREADS;
         lg[it] = loc < hw ? logits[(pbase + loc) * k_out] : 0.f;
+        lgl[it] = (lane == 0 && loc < hw && loc > 0) ? logits[(pbase + loc - 1) * k_out] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < PER_THREAD; ++it) {
@@ -832,13 +838,13 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         const bool valid = loc < hw;
         int f = 0, x = 0;
         if (valid) {
-            x = loc % w;
+            x = loc - row_of(loc) * w;
             f = lg[it] > thr ? 1 : 0;                                               // strict >, model_runner.py:124
             m[loc] = (unsigned char)f;
             if (binary_map) binary_map[pbase + loc] = f;
         }
         int fl = __shfl_up(f, 1, 64);
-        if (lane == 0 && valid && x > 0) fl = logits[(pbase + loc - 1) * k_out] > thr ? 1 : 0;
+        if (lane == 0 && valid && x > 0) fl = lgl[it] > thr ? 1 : 0;
         const bool same_left = valid && x > 0 && fl == f;
         const unsigned long long breaks = __ballot(!same_left);
         if (valid) {
@@ -851,33 +857,62 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     __syncthreads();
     PPSTAMP();
 
-    // ---- merge (pp_merge_kernel)
-    for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
-        const int y = loc / w, x = loc - y * w;
-        const int me = loc + 1;
-        const int c = m[loc];
-        const bool W = x > 0 && m[loc - 1] == c;
-        if (c) {
-            if (y > 0) {
-                const bool N = m[loc - w];
-                const bool NW = x > 0 && m[loc - w - 1];
-                if (N) {
-                    if (!(W && NW)) uf_union_wg(lab, me, me - w);
+    // ---- merge (pp_merge_kernel).  Only a few lanes of a wave have a link to make at any pixel, and a union is a chain of
+    // dependent LDS round trips: executed in place, every iteration of the pixel loop cost one union latency (~3 k cycles x 16
+    // iterations = 50 k of the kernel's 122 k cycles).  Two passes instead: the wave first queues its links as 16-bit jobs
+    // (pixel << 2 | direction; compacted with ballots into a wave-private slice of the still unused owner / root-slot arrays),
+    // then runs them 64 at a time, one job per lane.  The forest and its roots do not depend on the order of the unions.
+    {
+        const int iters = (hw + PP_LDS_THREADS - 1) / PP_LDS_THREADS;
+        const bool queued = (size_t)iters * 4096 <= (size_t)hw * 4;       // 2 jobs per pixel fit the slice (hw a multiple of 1024)
+        unsigned short *queue = (unsigned short *)own16 + (size_t)(tid >> 6) * iters * 128;
+        int njobs = 0;                                                    // wave-uniform
+        for (int loc = tid; loc - lane < hw; loc += PP_LDS_THREADS) {     // wave-uniform trip count
+            int ja = -1, jb = -1;                                         // direction of the first / second link: 0 N, 1 NW, 2 NE, 3 frame
+            if (loc < hw) {
+                const int y = row_of(loc), x = loc - y * w;
+                const int c = m[loc];
+                const bool W = x > 0 && m[loc - 1] == c;
+                if (c) {
+                    if (y > 0) {
+                        const bool N = m[loc - w];
+                        const bool NW = x > 0 && m[loc - w - 1];
+                        if (N) {
+                            if (!(W && NW)) ja = 0;
+                        } else {
+                            if (NW && !W) ja = 1;
+                            const bool NE = x < w - 1 && m[loc - w + 1];
+                            const bool E = x < w - 1 && m[loc + 1];
+                            if (NE && !E) jb = 2;
+                        }
+                    }
                 } else {
-                    if (NW && !W) uf_union_wg(lab, me, me - w - 1);
-                    const bool NE = x < w - 1 && m[loc - w + 1];
-                    const bool E = x < w - 1 && m[loc + 1];
-                    if (NE && !E) uf_union_wg(lab, me, me - w + 1);
+                    if (y > 0 && !m[loc - w]) {
+                        const bool NW = x > 0 && !m[loc - w - 1];
+                        if (!(W && NW)) ja = 0;
+                    }
+                    const bool row_edge = (y == 0 || y == h - 1) && !W;
+                    if (row_edge || x == 0 || x == w - 1) jb = 3;
                 }
             }
-        } else {
-            if (y > 0 && !m[loc - w]) {
-                const bool NW = x > 0 && !m[loc - w - 1];
-                if (!(W && NW)) uf_union_wg(lab, me, me - w);
+            if (queued) {
+                const unsigned long long ba = __ballot(ja >= 0), bb = __ballot(jb >= 0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (ja >= 0) queue[njobs + __popcll(ba & below)] = (unsigned short)((loc << 2) | ja);
+                njobs += __popcll(ba);
+                if (jb >= 0) queue[njobs + __popcll(bb & below)] = (unsigned short)((loc << 2) | jb);
+                njobs += __popcll(bb);
+            } else {
+                const int me = loc + 1;
+                if (ja >= 0) uf_union_wg(lab, me, ja == 0 ? me - w : me - w - 1);
+                if (jb >= 0) uf_union_wg(lab, me, jb == 2 ? me - w + 1 : 0);
             }
-            const bool row_edge = (y == 0 || y == h - 1) && !W;
-            if (row_edge || x == 0 || x == w - 1) uf_union_wg(lab, me, 0);
         }
+        if (queued)
+            for (int j = lane; j < njobs; j += 64) {
+                const int job = queue[j], me = (job >> 2) + 1, dir = job & 3;
+                uf_union_wg(lab, me, dir == 0 ? me - w : (dir == 1 ? me - w - 1 : (dir == 2 ? me - w + 1 : 0)));
+            }
     }
     __syncthreads();
     PPSTAMP();
@@ -928,7 +963,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
         int key = -1, val = 0;
         if (loc < hw) {
-            const int y = loc / w, x = loc - y * w;
+            const int y = row_of(loc), x = loc - y * w;
             if (x < w - 1 && y < h - 1) {
                 const int o0 = own16[loc], o1 = own16[loc + 1], o2 = own16[loc + w], o3 = own16[loc + w + 1];
                 const int o = max(max(o0, o1), max(o2, o3));
@@ -939,7 +974,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
                 }
             }
         }
-        if (val != 0) atomicAdd(&area2[key], val);                                  // LDS atomic
+        if (val != 0) atomicAdd(&area2[key], val);                                  // LDS atomic (a wave-level pre-reduction of equal keys measured slower: 14 k -> 20 k cycles)
     }
     __syncthreads();
     PPSTAMP();
@@ -982,7 +1017,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
         const int o = own16[loc];
         if (o < 0) continue;
-        const int y = loc / w, x = loc - y * w;
+        const int y = row_of(loc), x = loc - y * w;
         const bool left_end = (x == 0) || own16[loc - 1] != o;
         const bool right_end = (x == w - 1) || own16[loc + 1] != o;
         const bool bottom = (y == h - 1) || own16[loc + w] != o;
