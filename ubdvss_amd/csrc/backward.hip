@@ -1007,8 +1007,17 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         unsigned short *g16[2] = {(unsigned short *)gq[0], (unsigned short *)gq[0] + (size_t)npix * UBD_C};
         unsigned *frag16t = (unsigned *)(bfrag + UBD_BWD_DIRECT_FLOATS);
         ubd_launch_pack16(h, params, frag16t, 1, st);
-        hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
-        if (launch_head_wgrad<TX>(h, acts[6], dlogits, grads, &rq, npix, st)) return -1;
+        if (h->k_out == 1) {                                   // one pass over A9 for both head gradients
+            int g1 = (int)((npix * 3 + 255) / 256);
+            if (g1 > h->num_cus * 6) g1 = h->num_cus * 6;
+            g1 = (g1 + 2) / 3 * 3;                             // 256 g1 = 0 (mod 3): a thread keeps its channel group
+            float *partials = rp_add(&rq, g1, UBD_C + 1, grads + h->off_head_k, UBD_C, grads + h->off_head_b, 1, nullptr, st);
+            if (!partials) return -1;
+            hipLaunchKernelGGL((head_bwd1_16_kernel<TX>), dim3(g1), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], partials, npix);
+        } else {
+            hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
+            if (launch_head_wgrad<TX>(h, acts[6], dlogits, grads, &rq, npix, st)) return -1;
+        }
         for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];

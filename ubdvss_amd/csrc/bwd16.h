@@ -52,6 +52,56 @@ __global__ __launch_bounds__(256) void head_dx16_kernel(const float *__restrict_
     }
 }
 
+// k_out == 1 (detection only, the benchmark configuration): head data gradient AND head weight gradient in one pass over A9 --
+// the two kernels each read the 48 bytes per pixel (19 + 16 us at 64 images).  Thread = one 16-byte chunk (8 channels) of a
+// pixel; the launch has a multiple of 3 threads, so a thread keeps its channel group for the whole grid-stride loop and carries
+// eight fp32 sums hk-gradient sums (+ the bias-gradient sum in group 0).  Block reduction in a fixed order (deterministic):
+// partial row [24 | 1] per block, summed by reduce_partials_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd1_16_kernel(const float *__restrict__ dlogits, const unsigned short *__restrict__ a9,
+                                                           const float *__restrict__ hk, unsigned short *__restrict__ g,
+                                                           float *__restrict__ partials, long npix)
+{
+    __shared__ float s_acc[256][9];
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = (int)(t0 % 3);                                  // constant per thread: gridDim.x * 256 is a multiple of 3
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = hk[c8 * 8 + e];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, accb = 0.f;
+    const u32x4 *pa = (const u32x4 *)a9;
+    u32x4 *pg = (u32x4 *)g;
+    for (long t = t0; t < npix * 3; t += (long)gridDim.x * blockDim.x) {
+        const long p = t / 3;
+        const float dl = dlogits[p];
+        const u32x4 av = pa[t];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const short a_lo = (short)(av[e] & 0xFFFFu), a_hi = (short)(av[e] >> 16);
+            const unsigned lo = a_lo > 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)(dl * w[2 * e])) : 0u;
+            const unsigned hi = a_hi > 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)(dl * w[2 * e + 1])) : 0u;
+            o[e] = lo | (hi << 16);
+            acc[2 * e] = fmaf((float)__builtin_bit_cast(T, (unsigned short)(av[e] & 0xFFFFu)), dl, acc[2 * e]);
+            acc[2 * e + 1] = fmaf((float)__builtin_bit_cast(T, (unsigned short)(av[e] >> 16)), dl, acc[2 * e + 1]);
+        }
+        pg[t] = o;
+        accb += dl;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_acc[threadIdx.x][e] = acc[e];
+    s_acc[threadIdx.x][8] = accb;
+    __syncthreads();
+    if (threadIdx.x <= UBD_C) {
+        const int c = threadIdx.x, grp = c < UBD_C ? c >> 3 : 0, e = c < UBD_C ? c & 7 : 8;
+        // threads of this block with channel group grp: tid = first, first + 3, ...
+        const int first = (int)(((grp - (long)blockIdx.x * blockDim.x) % 3 + 3) % 3);
+        float v = 0.f;
+        for (int tid = first; tid < 256; tid += 3) v += s_acc[tid][e];
+        partials[(size_t)blockIdx.x * (UBD_C + 1) + c] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------ dilated wgrad, bf16 MFMA
 // Work items as in dil_wgrad_kernel: (image, phase (ry, rx) of the d x d sub-grid, 8 x 16 tile of that sub-grid).
 // LDS per buffer: X tile with halo, 10 x 18 pixels x 48 B, then the G tile, 8 x 16 pixels x 48 B (LDS-DMA, chunk c at
