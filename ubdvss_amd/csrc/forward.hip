@@ -786,7 +786,12 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
         const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
         int *ticket = (int *)(ws + L.off_tickets);                // strip tickets of the one-kernel stem, zeroed per pass
         UBD_CHECK_HIP(hipMemsetAsync(ticket, 0, 256, st));
-#define UBD_LAUNCH_S123(CINV, U8V) hipLaunchKernelGGL((stem123_kernel<CINV, U8V>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket)
+#ifdef UBD_STAMPS
+#define S123_STAMP_ARG , g_ubd_stamps
+#else
+#define S123_STAMP_ARG
+#endif
+#define UBD_LAUNCH_S123(CINV, U8V) hipLaunchKernelGGL((stem123_kernel<CINV, U8V>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket S123_STAMP_ARG)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1); else UBD_LAUNCH_S123(1, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1); else UBD_LAUNCH_S123(3, 0); }
 #undef UBD_LAUNCH_S123

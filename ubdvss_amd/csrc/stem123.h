@@ -38,7 +38,11 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                                                                 const float *__restrict__ frag2, const float *__restrict__ bias2,
                                                                 const float *__restrict__ frag3, const float *__restrict__ bias3,
                                                                 int n, int H, int W, int H2, int W2, int H4, int W4,
-                                                                float pre_sub, float pre_div, int *__restrict__ ticket)
+                                                                float pre_sub, float pre_div, int *__restrict__ ticket
+#ifdef UBD_STAMPS
+                                                                , unsigned long long *__restrict__ stamps
+#endif
+                                                                )
 {
     using C = s23_cfg;
     using X = s123_cfg<CIN>;
@@ -118,23 +122,38 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // (512 / RW, 512 % RW) with a carry -- no divisions in the loop
     constexpr int RWF = X::XW * CIN;                                                 // floats per patch row
     const int e0_row = (int)threadIdx.x / RWF, e0_col = (int)threadIdx.x - e0_row * RWF;
-    auto load_x = [&](tpos p) {
+    // Addresses: image base in scalar registers + a 32-bit element offset (the size_t index arithmetic of the first version cost
+    // ~20 vector instructions per element: phase 0a was 2.5 k of the tile's 11.5 k cycles in the stamps).  Interior tiles
+    // (block-uniform) load unconditionally; border tiles load from the clamped position and the elements outside the image
+    // are replaced where the registers are consumed (a select next to the load would wait for it).
+    auto tile_interior = [&](tpos p) {
         const int iy0 = 4 * p.ty * C::TH3 - 5, ix0 = 64 * p.tx - 3;
-        const bool interior = (iy0 >= 0) && (ix0 >= 0) && (iy0 + X::XH <= H) && (ix0 + X::XW <= W);   // block-uniform
-        const size_t img_base = (size_t)p.img * H * W * CIN;
+        return (iy0 >= 0) && (ix0 >= 0) && (iy0 + X::XH <= H) && (ix0 + X::XW <= W);
+    };
+    auto load_x = [&](tpos p) {
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+        const unsigned char *img8 = (const unsigned char *)xin + (size_t)p.img * H * WC * (IN_U8 ? 1 : 4);   // wave-uniform
+        const bool interior = tile_interior(p);                                      // block-uniform
         int pr = e0_row, pcf = e0_col;
 #pragma unroll
         for (int k = 0; k < X::XREGS; ++k) {
-            const bool live = k * C::NT + (int)threadIdx.x < X::XE;
-            unsigned v = IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);
-            const int gy = iy0 + pr, gxf = ix0 * CIN + pcf;                          // gxf = gx * C_in + channel
-            const bool ok = live && (interior || (gy >= 0 && gy < H && gxf >= 0 && gxf < W * CIN));
-            if (ok) {
-                const size_t ge = img_base + (size_t)gy * (W * CIN) + gxf;
-                if constexpr (IN_U8) v = ((const unsigned char *)xin)[ge];
-                else v = ((const unsigned *)xin)[ge];
-            }
-            xreg[k] = v;
+            int gy = iy0 + pr, gf = fx0 + pcf;                                       // gf = gx * C_in + channel
+            if (!interior) { gy = min(max(gy, 0), H - 1); gf = min(max(gf, 0), WC - 1); }
+            else if (k == X::XREGS - 1) gy = min(gy, H - 1);                         // the last round runs past the patch (never stored)
+            const unsigned off = (unsigned)__umul24(gy, WC) + (unsigned)gf;
+            if constexpr (IN_U8) xreg[k] = img8[off];
+            else xreg[k] = ((const unsigned *)img8)[off];
+            pr += C::NT / RWF; pcf += C::NT % RWF;
+            if (pcf >= RWF) { pcf -= RWF; ++pr; }
+        }
+    };
+    auto fix_border = [&](tpos p) {                                                  // outside the image = exactly 0 after the preprocessing
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+        int pr = e0_row, pcf = e0_col;
+#pragma unroll
+        for (int k = 0; k < X::XREGS; ++k) {
+            const bool inside = (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(fx0 + pcf) < (unsigned)WC;
+            xreg[k] = inside ? xreg[k] : (IN_U8 ? 0x100u : __builtin_bit_cast(unsigned, pre_sub));
             pr += C::NT / RWF; pcf += C::NT % RWF;
             if (pcf >= RWF) { pcf -= RWF; ++pr; }
         }
@@ -182,7 +201,13 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     tpos nx1 = advance(cur);
     load_x(cur);
     int pending = 0;                                                                 // ticket in flight (thread 0)
+#ifdef UBD_STAMPS   // diagnostic build only: s_memtime at the phase boundaries, lane 0 of every wave, first 16 tiles of the block
+#define S123_STAMP(k) do { if (stamps && it < 16 && lane == 0) stamps[(((size_t)blockIdx.x * 8 + wid) * 16 + it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S123_STAMP(k) do {} while (0)
+#endif
     for (int it = 0;; ++it) {
+        S123_STAMP(0);
         const bool new_strip = cur.tx == 0;                                          // block-uniform
         if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
@@ -192,6 +217,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
 
         // ---- phase 0a: input patch -> LDS (fp32, preprocessed); request the next tile's
         const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;              // already preprocessed fp32 input: a copy
+        if (!tile_interior(cur)) fix_border(cur);                                    // block-uniform
 #pragma unroll
         for (int k = 0; k < X::XREGS; ++k) {
             const int e = k * C::NT + (int)threadIdx.x;
@@ -201,7 +227,9 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             }
         }
         if (has_next) load_x(nx1);
+        S123_STAMP(1);
         __syncthreads();                                                             // patch complete; phase B of the previous tile is over
+        S123_STAMP(2);
 
         // ---- phase 0b: L1 -> a1 patch image
         float dwk1[9], pwf1[2];
@@ -245,7 +273,9 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             if (cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);
             *(f32x4 *)(l2 + (row * C::LC) * C::LP + 4 * ch4) = v;
         }
+        S123_STAMP(3);
         __syncthreads();
+        S123_STAMP(4);
 
         // ---- phase A: L2 on positions (0..8, 1..32)
         const bool mask_needed = (R0 < 0) || (R0 + C::LR > H2) || (C0 + C::LC > W2);
@@ -306,7 +336,9 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 }
             }
         }
+        S123_STAMP(5);
         __syncthreads();
+        S123_STAMP(6);
 
         // ---- phase B, waves 0-3: L3 output row oy0 + wid
         if (wid < 4) {
@@ -336,6 +368,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             }
             store_tile_relu_t(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1, z4, z4);   // bias already in
         }
+        S123_STAMP(7);
         if (!has_next) break;
         if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;   // visible after the next tile's barriers
         cur = nx1;
