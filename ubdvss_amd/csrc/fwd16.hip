@@ -285,21 +285,28 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             }
             return;
         }
+        // border tile: every element from the clamped position (image base in scalar registers + a 32-bit offset; the size_t index
+        // arithmetic under per-element branches cost five quarter-rate v_mad_u64_u32 each), all loads in flight, then the elements
+        // outside the image are replaced (exactly 0 after the preprocessing below)
+        const int WC = W * CIN;
+        const unsigned char *img8 = (const unsigned char *)xin + (size_t)img * H * WC * ((IN_MODE == 1) ? 1 : 4);
 #pragma unroll
         for (int k = 0; k < C::STAGE_REGS; ++k) {
-            const int e = k * 256 + threadIdx.x;
-            unsigned v = (IN_MODE == 1) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub);   // out-of-image: exactly 0 after the preprocessing below
-            if (e < C::ELEMS) {
-                const int pix = e / CIN, ch = e - pix * CIN;
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                const int gy = iy0 + pr, gx = ix0 + pc;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
-                    if constexpr (IN_MODE == 1) v = ((const unsigned char *)xin)[ge];
-                    else v = ((const unsigned *)xin)[ge];
-                }
-            }
-            st[k] = v;
+            int e = k * 256 + threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
+            const int pr = e / (C::PW * CIN), pf = e - pr * (C::PW * CIN);
+            const int gy = min(max(iy0 + pr, 0), H - 1), gf = min(max(ix0 * CIN + pf, 0), WC - 1);
+            const unsigned off = (unsigned)(gy * WC + gf);
+            if constexpr (IN_MODE == 1) st[k] = img8[off];
+            else st[k] = ((const unsigned *)img8)[off];
+        }
+#pragma unroll
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            int e = k * 256 + threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
+            const int pr = e / (C::PW * CIN), pf = e - pr * (C::PW * CIN);
+            const bool inside = (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(ix0 * CIN + pf) < (unsigned)WC;
+            st[k] = inside ? st[k] : ((IN_MODE == 1) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub));
         }
     };
 
