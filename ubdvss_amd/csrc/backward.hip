@@ -836,8 +836,10 @@ static unsigned long long *g_sepb_stamps = nullptr;
 static int g_sepb_stamps_cin = 0, g_sepb_stamps_stride = 0;
 extern "C" void ubd_debug_set_stamps_sepb(void *p, int cin, int stride) { g_sepb_stamps = (unsigned long long *)p; g_sepb_stamps_cin = cin; g_sepb_stamps_stride = stride; }
 #define SB_STAMP_ARG , ((CIN == g_sepb_stamps_cin && STRIDE == g_sepb_stamps_stride) ? g_sepb_stamps : nullptr)
+#define WG_STAMP_ARG , ((g_sepb_stamps_cin == -1 && g_sepb_stamps_stride == dd) ? g_sepb_stamps : nullptr)      // cin = -1: dil_wgrad16 of dilation `stride`
 #else
 #define SB_STAMP_ARG
+#define WG_STAMP_ARG
 #endif
 #include "sepbwd16.h"
 
@@ -1022,16 +1024,16 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];
             const int sw = (W4 + dd - 1) / dd, tw = sw <= 8 ? 8 : 16;              // narrow sub-grids: 8-wide tiles
-            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH - 1) / W16_TH) * ((sw + tw - 1) / tw);
-            int gw = h->num_cus * 3;
+            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH(tw) - 1) / W16_TH(tw)) * ((sw + tw - 1) / tw);
+            int gw = h->num_cus * (tw == 8 ? 3 : 2);                // 16 x 16 tiles: 56 KB of LDS per block, two blocks per CU
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
             if (!partials) return -1;
             if (tw == 8)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd WG_STAMP_ARG);
             else
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd WG_STAMP_ARG);
             ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }

@@ -112,28 +112,41 @@ __global__ __launch_bounds__(256) void head_bwd1_16_kernel(const float *__restri
 // flat (tap, ci) index rho = 16 mt + i, so segment p of M-tile mt starts at rho0 = 16 mt + 4p: tap t = rho0 / 24 shifts the
 // pixel, ci = rho0 % 24 the channel (24 = 6 x 4: a segment never straddles a tap).  rho = 216 is the all-ones column
 // (bias gradient), 217.. are zero: those segments read 8-byte constants kept behind the tile buffers.
-#define W16_TH 8
+#define W16_TH(TW) ((TW) == 16 ? 16 : 8)     // tile rows: 16 x 16 tiles (two k-blocks per wave and item: the per-item barriers and DMA
+                                              // bookkeeping cost as much as one k-block of MFMAs); 8 x 8 sub-grids (dilation 16 on 128-wide maps) keep 8 rows
 // TW = 16 (default) or 8 (sub-grids at most 8 columns wide, i.e. dilation 16 on 128-wide maps: half of a 16-wide tile
 // would be padding).  k-block = 32 sub-pixels = 2 rows x 16 or 4 rows x 8.
 template <int TW> struct w16_cfg {
     static constexpr int XW = TW + 2;
-    static constexpr int XPIX = (W16_TH + 2) * XW;           // 180 / 100
-    static constexpr int GPIX = W16_TH * TW;                 // 128 / 64
-    static constexpr int XBYTES = XPIX * UBD_C * 2;
-    static constexpr int CHUNKS = (XPIX + GPIX) * 3;
-    static constexpr int ROUNDS = (CHUNKS + 255) / 256;
-    static constexpr int BUF_BYTES = ROUNDS * 256 * 16;      // 16 KiB / 8 KiB
+    static constexpr int XPIX = (W16_TH(TW) + 2) * XW;           // 180 / 100
+    static constexpr int GPIX = W16_TH(TW) * TW;                 // 128 / 64
+    // DMA pieces (one wave-instruction = 64 chunks of 16 bytes): the X tile is padded to whole pieces so that a piece is
+    // either X or G -- its tensor base then sits in scalar registers and the lanes add a 32-bit offset
+    static constexpr int XR = (XPIX * 3 + 63) / 64, GR = (GPIX * 3 + 63) / 64;   // 9 + 6 / 5 + 3 pieces
+    static constexpr int GOFF = XR * 1024;                   // byte offset of the G tile in a buffer
+    static constexpr int ROUNDS = (XR + GR + 3) / 4;         // pieces per wave
+    static constexpr int BUF_BYTES = ROUNDS * 4 * 1024;      // 16 KiB / 8 KiB
     static constexpr int KROWS = 32 / TW;                    // tile rows per k-block
 };
 #define W16_BUF_BYTES_MAX (w16_cfg<16>::BUF_BYTES)
 
 template <typename T, int TW>
-__global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
-                                                             float *__restrict__ partials, int n, int h, int w, int d)
+__global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
+                                                             float *__restrict__ partials, int n, int h, int w, int d
+#ifdef UBD_STAMPS
+                                                             , unsigned long long *__restrict__ stamps
+#endif
+                                                             )
 {
+#ifdef UBD_STAMPS   // diagnostic build only: s_memtime of lane 0 of every wave at the phase boundaries of its first 8 items
+#define WGSTAMP(k) do { if (stamps && iter < 8 && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + iter) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WGSTAMP(k) do {} while (0)
+#endif
     using C = w16_cfg<TW>;
-    constexpr int CONST_OFF = 2 * W16_BUF_BYTES_MAX;                          // [0,8): {1,0,0,0}   [8,16): zeros
-    __shared__ __attribute__((aligned(16))) char smem[2 * W16_BUF_BYTES_MAX + 64];   // ONE LDS object (see fwd16.hip)
+    constexpr int TILES_BYTES = 2 * C::BUF_BYTES > 28672 ? 2 * C::BUF_BYTES : 28672;   // two tile buffers; the block reduction needs 28 KiB
+    constexpr int CONST_OFF = TILES_BYTES;                                    // [0,8): {1,0,0,0}   [8,16): zeros
+    __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 64];      // ONE LDS object (see fwd16.hip)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
@@ -151,44 +164,70 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
     // pixel of this lane inside a k-block (2 tile rows x 16 columns or 4 x 8): k = 8 grp + 4 j + qq, j = 0, 1
     const int krow = TW == 16 ? grp >> 1 : grp, kcol = TW == 16 ? 8 * (grp & 1) + qq : qq;
 
-    // DMA chunk -> (tile row, tile column, 16-byte part, X or G) of this lane, per round
+    // DMA chunk -> (tile row, tile column, 16-byte part) of this lane, per piece of this wave (piece = 4 rd + wid: X pieces
+    // first, then G pieces)
     int cinfo[C::ROUNDS];
 #pragma unroll
     for (int rd = 0; rd < C::ROUNDS; ++rd) {
-        int c = rd * 256 + wid * 64 + lane;
-        c = c < C::CHUNKS ? c : C::CHUNKS - 1;
-        int sy, sx, part, isx;
-        if (c < C::XPIX * 3) { const int pix = c / 3; part = c - pix * 3; sy = pix / C::XW; sx = pix - sy * C::XW; isx = 1; }   // sy, sx include the +1 halo shift
-        else { const int cg = c - C::XPIX * 3; const int gp = cg / 3; part = cg - gp * 3; sy = gp / TW + 1; sx = gp % TW + 1; isx = 0; }
-        cinfo[rd] = sy | (sx << 8) | (part << 16) | (isx << 24);
+        const int piece = rd * 4 + wid;
+        int sy, sx, part;
+        if (piece < C::XR) {
+            int c = piece * 64 + lane;
+            c = c < C::XPIX * 3 ? c : C::XPIX * 3 - 1;
+            const int pix = c / 3; part = c - pix * 3; sy = pix / C::XW; sx = pix - sy * C::XW;      // sy, sx include the +1 halo shift
+        } else {
+            int cg = (piece - C::XR) * 64 + lane;
+            cg = cg < C::GPIX * 3 ? cg : C::GPIX * 3 - 1;
+            const int gp = cg / 3; part = cg - gp * 3; sy = gp / TW + 1; sx = gp % TW + 1;
+        }
+        cinfo[rd] = sy | (sx << 8) | (part << 16);
     }
 
+    // border fix: pixels of the staged tiles owned by this thread, (row + 1) | (column + 1) << 8 | byte offset << 16
+    constexpr int ZP = (C::XPIX + C::GPIX + 255) / 256;
+    int zinfo[ZP];
+#pragma unroll
+    for (int k = 0; k < ZP; ++k) {
+        const int pix = (int)threadIdx.x + 256 * k;
+        int sy, sx, boff;
+        if (pix < C::XPIX) { sy = pix / C::XW; sx = pix % C::XW; boff = pix * (UBD_C * 2); }
+        else { sy = (pix - C::XPIX) / TW + 1; sx = (pix - C::XPIX) % TW + 1; boff = C::GOFF + (pix - C::XPIX) * (UBD_C * 2); }
+        zinfo[k] = pix < C::XPIX + C::GPIX ? (sy | (sx << 8) | (boff << 16)) : -1;
+    }
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
-    const int tiles_y = (sh + W16_TH - 1) / W16_TH, tiles_x = (sw + TW - 1) / TW;
+    const int tiles_y = (sh + W16_TH(TW) - 1) / W16_TH(TW), tiles_x = (sw + TW - 1) / TW;
     const int items = n * d * d * tiles_y * tiles_x;
     struct item_t { int img, ry, rx, sy0, sx0; };
+    // item index -> (image, phase, tile) with magic-number divisions (wave-uniform: s_mul_hi; exact while it * divisor < 2^32)
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d);
+    auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {
         item_t r;
-        const int tx = (int)((unsigned)it % (unsigned)tiles_x); it = (int)((unsigned)it / (unsigned)tiles_x);
-        const int ty = (int)((unsigned)it % (unsigned)tiles_y); it = (int)((unsigned)it / (unsigned)tiles_y);
-        r.rx = (int)((unsigned)it % (unsigned)d); it = (int)((unsigned)it / (unsigned)d);
-        r.ry = (int)((unsigned)it % (unsigned)d);
-        r.img = (int)((unsigned)it / (unsigned)d);
-        r.sy0 = ty * W16_TH; r.sx0 = tx * TW;
+        unsigned a = (unsigned)it, b;
+        b = divm(a, (unsigned)tiles_x, m_tx); const int tx = (int)(a - b * (unsigned)tiles_x); a = b;
+        b = divm(a, (unsigned)tiles_y, m_ty); const int ty = (int)(a - b * (unsigned)tiles_y); a = b;
+        b = divm(a, (unsigned)d, m_d); r.rx = (int)(a - b * (unsigned)d); a = b;
+        b = divm(a, (unsigned)d, m_d); r.ry = (int)(a - b * (unsigned)d);
+        r.img = (int)b;
+        r.sy0 = ty * W16_TH(TW); r.sx0 = tx * TW;
         return r;
     };
-    auto dma_item = [&](int it, char *buf) {
-        const item_t I = decode(it);
+    const unsigned lds_smem = ubd_lds_addr(smem);
+    auto dma_item = [&](const item_t &I, int bufoff) {
+        const size_t imgoff = (size_t)I.img * h * w * (UBD_C * 2);
+        const char *bx = (const char *)x + imgoff, *bg = (const char *)gz + imgoff;       // wave-uniform bases
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
+            const int piece = rd * 4 + wid;
+            if (piece >= C::XR + C::GR) break;                        // wave-uniform
             const int ci = cinfo[rd];
             int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;
             int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
-            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                 // clamped; out-of-image pixels are zeroed later
-            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-            const size_t pixel = ((size_t)I.img * h + gy) * w + gx;
-            const char *src = (const char *)((ci >> 24) ? x : gz) + pixel * (UBD_C * 2) + ((ci >> 16) & 0xFF) * 16;
-            ubd_glds16(src, buf + (rd * 256 + wid * 64) * 16);     // asm form (common.h): hipcc drained the builtin in front of the tr reads
+            gy = min(max(gy, 0), h - 1);                              // clamped; out-of-image pixels are zeroed later
+            gx = min(max(gx, 0), w - 1);
+            const unsigned off = (unsigned)((gy * w + gx) * (UBD_C * 2)) + (unsigned)((ci >> 16) & 0xFF) * 16u;
+            ubd_glds16_sbase(piece < C::XR ? bx : bg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
 
@@ -202,23 +241,28 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
     const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
     f32x4 acc[14][2] = {};
     int it = it_begin + (int)(blockIdx.x >> 3);
-    if (it < it_end) dma_item(it, smem);
+    item_t I = decode(it < it_end ? it : it_begin);
+    if (it < it_end) dma_item(I, 0);
     for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         char *buf = smem + (iter & 1) * C::BUF_BYTES;
-        const item_t I = decode(it);
+        WGSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's DMA (issued one item ago, as asm) has landed
+        WGSTAMP(1);
         __syncthreads();                              // ... for every wave; everyone left the other buffer
-        if (it + nblk_x < it_end) dma_item(it + nblk_x, smem + ((iter + 1) & 1) * C::BUF_BYTES);
+        WGSTAMP(2);
+        item_t Inext = I;
+        if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * C::BUF_BYTES); }
+        WGSTAMP(3);
         const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
-                            (I.ry + (I.sy0 + W16_TH) * d >= h) || (I.rx + (I.sx0 + TW) * d >= w);   // block-uniform
+                            (I.ry + (I.sy0 + W16_TH(TW)) * d >= h) || (I.rx + (I.sx0 + TW) * d >= w);   // block-uniform
         if (ragged) {
-            for (int pix = threadIdx.x; pix < C::XPIX + C::GPIX; pix += 256) {
-                int sy, sx;
-                if (pix < C::XPIX) { sy = pix / C::XW - 1; sx = pix % C::XW - 1; }
-                else { sy = (pix - C::XPIX) / TW; sx = (pix - C::XPIX) % TW; }
-                const int gy = I.ry + (I.sy0 + sy) * d, gx = I.rx + (I.sx0 + sx) * d;
+#pragma unroll
+            for (int k = 0; k < ZP; ++k) {            // this thread's tile pixels (sub-grid offsets precomputed: most items of a dilated
+                const int zi = zinfo[k];              // layer touch the border of their sub-grid, and the divisions cost 1 k cycles per item)
+                if (zi < 0) continue;
+                const int gy = I.ry + (I.sy0 + (zi & 0xFF) - 1) * d, gx = I.rx + (I.sx0 + ((zi >> 8) & 0xFF) - 1) * d;
                 if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
-                    u32x4 *z = (u32x4 *)(buf + pix * (UBD_C * 2));
+                    u32x4 *z = (u32x4 *)(buf + (zi >> 16));
                     const u32x4 zero = {0u, 0u, 0u, 0u};
                     z[0] = zero; z[1] = zero; z[2] = zero;
                 }
@@ -226,11 +270,13 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();             // raw barrier: the next item's DMA stays in flight
         }
-        const int rows_eff = min(W16_TH, sh - I.sy0);
-        if (C::KROWS * wid < rows_eff) {              // wave-uniform: this wave's tile rows hold real sub-pixels
-            const int py = C::KROWS * wid + krow;
+        WGSTAMP(4);
+        const int rows_eff = min(W16_TH(TW), sh - I.sy0);
+#pragma unroll 1
+        for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
+            const int py = C::KROWS * kb + krow;
             const char *xb = buf + (py * C::XW + kcol) * (UBD_C * 2);
-            const char *gb = buf + C::XBYTES + (py * TW + kcol) * (UBD_C * 2);
+            const char *gb = buf + C::GOFF + (py * TW + kcol) * (UBD_C * 2);
             // B operand: segments of the two N tiles (co 0..15, 16..23 + zero padding)
             u32x4 b[2];
             {
@@ -255,6 +301,9 @@ __global__ __launch_bounds__(256, 3) void dil_wgrad16_kernel(const unsigned shor
                 acc[mt][1] = mfma16<T>(a, b[1], acc[mt][1]);
             }
         }
+        WGSTAMP(5);
+        I = Inext;
     }
+#undef WGSTAMP
     wgrad_block_reduce(acc, (float *)smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
 }
