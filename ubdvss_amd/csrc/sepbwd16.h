@@ -10,16 +10,19 @@
 //   GSRC 1  (L1)  G = dwT(dDW of L2; stride 1, pad 1)            * (a1 > 0)
 //   GSRC 2  (L2)  G = dwT(dDW of L3; stride 2, pad_up top/left)  * (a2 > 0)
 //
-// Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers) and of the raw bf16 D tile
-// (G3 tile, or dDW-above tile with halo); clamped addresses, out-of-map pixels zero-fixed.  The ReLU mask (used once per
-// pixel) is not staged: every lane fetches the words of its own pixels while the DMA is in flight.
+// Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers one tile ahead), of the raw bf16 D
+// tile (G3 tile, or dDW-above tile with halo) and of the ReLU-mask tile (this layer's saved output; GSRC 1, 2): clamped
+// addresses, out-of-map pixels zero-fixed.  D and mask of the NEXT tile are requested right after phase 1; the stride-1
+// 24-channel layer double-buffers its X patch and requests the next one under phase 2.
 // Phase 1 (L1, L2): the G tile [pixel][24] in T from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q,
-// 17+2q}); every G tensor of the bf16 train step is a bf16 tensor, these two just never leave LDS.
-// Phase 2, two row tiles (= 32 pixels = one k-block of the 16-bit MFMA) per step: dDW = G pw^T as ONE
+// 17+2q}); every G tensor of the bf16 train step is a bf16 tensor, these two just never leave LDS.  L1 (stride-1
+// transposed conv): on the matrix pipe, taps folded into the K of the MFMA (diagonal weight matrices); L2 (stride 2): v_dot2c.
+// Phase 2, two row tiles (= 32 pixels = one k-block of the 16-bit MFMA) per wave: dDW = G pw^T as ONE
 // v_mfma_f32_16x16x32 per tile of channels (K = output channel, B operand = 16 bytes of a G row; the result lands in
-// the depthwise lane layout), one pass over the taps (depthwise recompute + ddw on the VALU), the depthwise output
-// rounded to T into a per-wave [32 pixels][channels] LDS image, then dpw / db = DW^T G with K = pixel: both operands
-// read with ds_read_b64_tr_b16 (as dil_wgrad16_kernel), an all-ones column gives the bias gradient.
+// the depthwise lane layout); the depthwise recompute (24 channels: tap-folded MFMAs; 1/3 channels: VALU) rounded to T into
+// a per-wave [32 pixels][channels] LDS image; dpw / db = DW^T G with K = pixel, both operands read with
+// ds_read_b64_tr_b16 (as dil_wgrad16_kernel), an all-ones column gives the bias gradient; the depthwise-kernel gradient
+// (24 channels) as the diagonals of X_t^T dDW, 14 MFMAs per k-block whose accumulators are owned by waves (see M2 below).
 #pragma once
 
 // NW = waves per block: the 1/3-channel layer needs few registers, so 6 waves share one tile's LDS (3 waves per SIMD at two
@@ -56,8 +59,7 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int SDW_W = (CIN == UBD_C) ? UBD_C : 4;           // columns per pixel ([ch.., 1, 0..] for 1/3 channels)
     static constexpr int SDW_BYTES = 32 * SDW_W * 2;                   // two row tiles per wave
     static constexpr int OFF_SDD = OFF_SDW + NW * SDW_BYTES;       // per-wave dDW images [32 pixels][24] in T (24-channel layers)
-    static constexpr int OFF_WT = OFF_SDD + (CIN == UBD_C ? NW * SDW_BYTES : 0);   // (unused since the depthwise recompute moved to the matrix pipe)
-    static constexpr int OFF_UT = OFF_WT + 9 * UBD_C * 4;              // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros)
+    static constexpr int OFF_UT = OFF_SDD + (CIN == UBD_C ? NW * SDW_BYTES : 0);   // taps of the layer above [3][4][24], packed 16-bit pairs (kx = 3: zeros; GSRC 2)
     static constexpr int OFF_CONST = OFF_UT + 12 * UBD_C * 4;          // [0,8): {1,0,0,0} in T   [8,32): zeros ([16,32): a 16-byte zero operand)
     static constexpr int LDS_BYTES = OFF_CONST + 32;
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
@@ -187,17 +189,11 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
     }
     const unsigned lds_dma = ubd_lds_addr(dma);
-    unsigned *wtp = (unsigned *)(lds + C::OFF_WT);                          // own taps [9][24], packed like utp
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
     // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
-    if constexpr (CIN == UBD_C)
-        for (int t = threadIdx.x; t < 9 * UBD_C; t += C::NT) {                               // Keras (3,3,C,1): [tap][ch]; kernels are used in T
-            const unsigned wb = (unsigned)__builtin_bit_cast(unsigned short, (T)dw_own[t]);
-            wtp[t] = ((t % UBD_C) & 1) ? (wb << 16) : wb;
-        }
     if constexpr (GSRC != 0)
         for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
@@ -574,72 +570,26 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
             }
             } else {
 #pragma unroll HR_UNROLL
-            for (int hr = 0; hr < 2; ++hr) {
+            for (int hr = 0; hr < 2; ++hr) {                           // 1/3 channels: VALU tap pass (27 products per pixel)
                 const int r = hr ? r1 : r0;
-                const int oy = oy0 + r, ox = ox0 + i;
-                // dDW[pixel i][ch] = sum_co G[i][co] pw[ch][co] first (rows = this lane's channels), then ONE pass over the
-                // taps feeds both the depthwise recompute (for dpw) and the depthwise kernel gradient
+                // dDW[pixel i][channel q] = sum_co G[i][co] pw[q][co] (row 4q of the product), then ONE pass over the taps feeds
+                // both the depthwise recompute (for dpw) and the depthwise-kernel gradient
                 u32x4 gb = *(const u32x4 *)(g16 + (r * 16 + i) * 48 + 16 * (q < 3 ? q : 0));
                 if (q == 3) gb = u32x4{0u, 0u, 0u, 0u};
                 const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 dA = mfma16<T>(apwb[0], gb, z4);
-                float ddwv[CPL];
-                if constexpr (CIN == UBD_C) {
-                    const f32x4 dB = mfma16<T>(apwb[1], gb, z4);
-                    ddwv[0] = dA[0]; ddwv[1] = dA[1]; ddwv[2] = dA[2]; ddwv[3] = dA[3]; ddwv[4] = dB[0]; ddwv[5] = dB[1];
-                } else {
-                    ddwv[0] = dA[0];
-                }
-                // dDW in T (what is stored and what the depthwise-kernel gradient multiplies, as in the oracle), one value per
-                // dword in the half that matches the channel's position in its pair
-                unsigned dp[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-                if constexpr (CIN == UBD_C) {
-                    const unsigned p01 = pack2b<T>(ddwv[0], ddwv[1]), p23 = pack2b<T>(ddwv[2], ddwv[3]), p45 = pack2b<T>(ddwv[4], ddwv[5]);
-                    dp[0] = p01 & 0xFFFFu; dp[1] = p01 & 0xFFFF0000u;
-                    dp[2] = p23 & 0xFFFFu; dp[3] = p23 & 0xFFFF0000u;
-                    dp[4] = p45 & 0xFFFFu; dp[5] = p45 & 0xFFFF0000u;
-                }
-                float dwv[CPL];
-#pragma unroll
-                for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+                const float ddwv = mfma16<T>(apwb[0], gb, z4)[0];
+                float dwv = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int t = ky * 3 + kx;
-                        const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
-                        if constexpr (CIN == UBD_C) {
-                            // raw 16-bit activation pairs x packed taps -> depthwise output; x packed dDW pairs -> ddw
-                            const char *px = xraw + pix * 48;
-                            const u32x2 a = *(const u32x2 *)(px + 8 * q);
-                            const unsigned b = *(const unsigned *)(px + 32 + 4 * q);
-                            const u32x4 w4 = *(const u32x4 *)(wtp + t * UBD_C + 4 * q);
-                            const u32x2 w2 = *(const u32x2 *)(wtp + t * UBD_C + 16 + 2 * q);
-                            dwv[0] = dot2b<T>(a[0], w4[0], dwv[0]); dwv[1] = dot2b<T>(a[0], w4[1], dwv[1]);
-                            dwv[2] = dot2b<T>(a[1], w4[2], dwv[2]); dwv[3] = dot2b<T>(a[1], w4[3], dwv[3]);
-                            dwv[4] = dot2b<T>(b, w2[0], dwv[4]);    dwv[5] = dot2b<T>(b, w2[1], dwv[5]);
-                            ddw[t][0] = dot2b<T>(a[0], dp[0], ddw[t][0]); ddw[t][1] = dot2b<T>(a[0], dp[1], ddw[t][1]);
-                            ddw[t][2] = dot2b<T>(a[1], dp[2], ddw[t][2]); ddw[t][3] = dot2b<T>(a[1], dp[3], ddw[t][3]);
-                            ddw[t][4] = dot2b<T>(b, dp[4], ddw[t][4]);    ddw[t][5] = dot2b<T>(b, dp[5], ddw[t][5]);
-                        } else {
-                            const float v = xf32[pix * CIN + cb];
-                            dwv[0] = fmaf(v, dwk1[t], dwv[0]);          // dwk1 is zero for lanes without a channel
-                            ddw[t][0] = fmaf(v, ddwv[0], ddw[t][0]);
-                        }
+                        const float v = xf32[((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * CIN + cb];
+                        dwv = fmaf(v, dwk1[t], dwv);                    // dwk1 is zero for lanes without a channel
+                        ddw[t][0] = fmaf(v, ddwv, ddw[t][0]);
                     }
-                // depthwise output in T (as the forward pass stored it) into this wave's [32 pixels][channels] image
-                if constexpr (CIN == UBD_C) {
-                    char *ps = sdw + (hr * 16 + i) * 48;
-                    *(u32x2 *)(ps + 8 * q) = u32x2{pack2b<T>(dwv[0], dwv[1]), pack2b<T>(dwv[2], dwv[3])};
-                    *(unsigned *)(ps + 32 + 4 * q) = pack2b<T>(dwv[4], dwv[5]);
-                    if (dDW != nullptr && oy < OH && ox < OW) {        // 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
-                        char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
-                        *(u32x2 *)(pd + 8 * q) = u32x2{pack2b<T>(ddwv[0], ddwv[1]), pack2b<T>(ddwv[2], ddwv[3])};
-                        *(unsigned *)(pd + 32 + 4 * q) = pack2b<T>(ddwv[4], ddwv[5]);
-                    }
-                } else {
-                    if (ch_ok) ((unsigned short *)sdw)[(hr * 16 + i) * C::SDW_W + cb] = __builtin_bit_cast(unsigned short, (T)dwv[0]);
-                }
+                // depthwise output in T (as the forward pass stored it) into this wave's [32 pixels][channel, 1, 0 ..] image
+                if (ch_ok) ((unsigned short *)sdw)[(hr * 16 + i) * C::SDW_W + cb] = __builtin_bit_cast(unsigned short, (T)dwv);
             }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
