@@ -513,6 +513,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         delta[c] = t < 9 ? (dy * w + dx) * (UBD_C * 2) + (g - 3 * t) * 16 : (1 << 30);
         dxc[c] = t < 9 ? dx : 0;
     }
+    const int i48 = i * (UBD_C * 2);
     const unsigned tiles_x = (unsigned)(w + 15) >> 4;
     const int total = n * h * (int)tiles_x;
     const int xcd = blockIdx.x & 7;
@@ -532,7 +533,10 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
         tc.yy = tc.rowid - tc.img * h;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)tc.img * h * w * UBD_C), 0, (int)img_bytes, 0x00020000);
         const int px = tc.xt * 16 + i;
-        const int base = (tc.yy * w + px) * (UBD_C * 2);
+        // byte offset of the centre pixel: wave-uniform part in scalar registers + the lane's constant i * 48 (the kernel is bound by
+        // vector-instruction issue -- 85 VALU + 14 MFMA per 16-pixel tile in the PMC counters --, not by memory)
+        const int sbase = (tc.yy * w + tc.xt * 16) * (UBD_C * 2);
+        const int base = sbase + i48;
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
             const bool xok = (unsigned)(px + dxc[c]) < (unsigned)w;
