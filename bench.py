@@ -362,11 +362,27 @@ def main():
         ty = torch.from_numpy(tlabels).to(dev)
         tcfg = cfg if n_cls == 0 else NetConfig(class_names=[f"class{i}" for i in range(n_cls)], grey=False)
         tmodel = Model(tcfg, dtype=dtype, seed=1)
+        comm_kind = "single GPU"
         if dist is not None:
             # the handle's own RCCL communicator (include/ubd.h ubd_comm_*): the gradient all-reduce runs inside ubd_train_step,
-            # the dilated + head segment on a communication stream under the stem layers' backward pass
+            # the dilated + head segment on a communication stream under the stem layers' backward pass.  Every rank must take
+            # the same path: a rank whose communicator cannot be created makes all of them fall back to torch.distributed's
+            # all-reduce of the flat gradient vector (same arithmetic, one more launch) instead of losing the bench line.
             from ubdvss_amd import distributed as ubd_dist
-            ubd_dist.attach_native_comm(tmodel, fused=True)
+            ok = 1
+            try:
+                ubd_dist.attach_native_comm(tmodel, fused=True)
+            except Exception as e:                       # noqa: BLE001 -- reported in the JSON line
+                ok = 0
+                sys.stderr.write(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); torch.distributed all-reduce instead\n")
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                tmodel._native_comm = None
+                comm_kind = f"dp{world}: per-replica loss, flat-gradient all-reduce per step through torch.distributed (RCCL)"
+            else:
+                comm_kind = (f"dp{world}: per-replica loss, flat-gradient all-reduce per step through the C-ABI RCCL communicator, "
+                             f"fused into the train step under the stem backward")
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
@@ -387,8 +403,7 @@ def main():
         res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
                "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb,
                "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
-               "parallelism": (f"dp{world}: per-replica loss, flat-gradient all-reduce per step through the C-ABI RCCL communicator, "
-                               f"fused into the train step under the stem backward") if dist is not None else "single GPU",
+               "parallelism": comm_kind,
                "loss_last": round(float(trainer.loss[0]), 5),
                "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
         del trainer, tmodel, tx, ty

@@ -71,14 +71,25 @@ def attach_native_comm(model, fused=True, group=None, global_loss=False):
     lib = _lib.load()
     w, r = world_size(group), rank(group)
     buf = (ctypes.c_char * _lib.UBD_UNIQUE_ID_BYTES)()
+    err = None
     if r == 0:
-        _lib.check(lib.ubd_comm_unique_id(buf), "ubd_comm_unique_id")
+        try:
+            _lib.check(lib.ubd_comm_unique_id(buf), "ubd_comm_unique_id")
+        except Exception as e:                          # noqa: BLE001 -- re-raised below, on every rank
+            err = e
     if w > 1:
-        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        # the id plus one status byte: the other ranks are already waiting in this broadcast, so rank 0 takes part in it even
+        # when it could not create the id, and then every rank raises
+        t = torch.frombuffer(bytearray(bytes(buf) + bytes([0 if err is None else 1])), dtype=torch.uint8).clone()
         if dist.get_backend(group) == "nccl":
             t = t.to(model.device)
         dist.broadcast(t, src=0, group=group)
-        ctypes.memmove(buf, bytes(t.cpu().numpy().tobytes()), _lib.UBD_UNIQUE_ID_BYTES)
+        raw = bytes(t.cpu().numpy().tobytes())
+        ctypes.memmove(buf, raw[:_lib.UBD_UNIQUE_ID_BYTES], _lib.UBD_UNIQUE_ID_BYTES)
+        if raw[_lib.UBD_UNIQUE_ID_BYTES] != 0 and err is None:
+            err = RuntimeError("attach_native_comm: rank 0 could not create the RCCL unique id")
+    if err is not None:
+        raise err
     with torch.cuda.device(model.device):
         flags = (_lib.UBD_COMM_FUSED if fused else 0) | (_lib.UBD_COMM_GLOBAL_LOSS if global_loss else 0)
         _lib.check(lib.ubd_comm_init(model._h, buf, r, w, flags), "ubd_comm_init")
