@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
     }
     const unsigned lds_dma = ubd_lds_addr(dma);
+    __amdgpu_buffer_rsrc_t ddw_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dDW, 0, dDW ? (int)((unsigned)n * OH * OW * (UBD_C * 2)) : 0, 0x00020000);   // <= 2^31 bytes (ubd.h size limits)
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
@@ -431,7 +432,11 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         // The DMA is issued as asm (ubd_glds16, common.h): hipcc neither waits for it here nor drains the NEXT tile's D
         // DMA in front of phase 2's LDS accesses (it did with the builtin: every tile waited a full fetch latency there).
         SBSTAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this tile's DMA has landed
+        // this tile's DMA has landed.  X_AHEAD kernels: it was requested in front of the previous tile's phase 2, whose four dDW
+        // stores per wave are younger and need not be waited for (the counter retires in order; round 2 stamps: 1.1 k cycles
+        // of every 10.6 k-cycle tile went into draining them)
+        if (X_AHEAD && tile != (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // ... for every wave; LDS writes visible
         {
             if ((CIN == UBD_C && xborder) || dborder || mborder) {     // block-uniform
@@ -559,10 +564,13 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                 char *pdd = sdd + (hr * 16 + i) * 48;
                 *(u32x2 *)(pdd + 8 * q) = d4;
                 *(unsigned *)(pdd + 32 + 4 * q) = d2;
-                if (dDW != nullptr && oy < OH && ox < OW) {            // 8 bytes at channel 4q, 4 bytes at channel 16 + 2q
-                    char *pd = (char *)(dDW + (((size_t)img * OH + oy) * OW + ox) * UBD_C);
-                    *(u32x2 *)(pd + 8 * q) = d4;
-                    *(unsigned *)(pd + 32 + 4 * q) = d2;
+                {
+                    // 8 bytes at channel 4q, 4 bytes at channel 16 + 2q.  Buffer stores: pixels outside the map get an offset past the
+                    // tensor and are dropped, so every wave issues exactly FOUR stores per tile -- the wait at the top of the next
+                    // tile counts on that (vmcnt(4): the DMA has landed, the stores may still be on their way)
+                    const unsigned po = (oy < OH && ox < OW) ? (unsigned)(((img * OH + oy) * OW + ox) * (UBD_C * 2)) : 0xFFFFFF00u;
+                    __builtin_amdgcn_raw_buffer_store_b64(d4, ddw_rsrc, (int)(po + 8u * q), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(d2, ddw_rsrc, (int)(po + 32u + 4u * q), 0, 0);
                 }
                 char *ps = sdw + (hr * 16 + i) * 48;                   // depthwise output in T (as the forward pass stored it)
                 *(u32x2 *)(ps + 8 * q) = u32x2{pack2b<T>(c0[0], c0[1]), pack2b<T>(c0[2], c0[3])};
