@@ -181,20 +181,40 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
     // v_mfma_f32_16x16x32_{bf16,f16} per N tile: k-slot 8q + e holds channel chs(q, e) for e < 6, zero for e = 6, 7.
     // 1/3 channels: fp32 image x rounded taps on the VALU, rounded depthwise output, fp32 MFMA (K = 4).
     float dwk[9][CPL], pwf[CPL][2];
-    unsigned dwp[9][CPL];                              // 24 channels: packed tap pairs
     u32x4 pwb[2];                                      // 24 channels: B operands of the two N tiles
+    // 24 channels: the depthwise convolution runs on the matrix pipe.  A depthwise tap is a diagonal weight matrix, so the K = 32
+    // of one 16-bit MFMA carries several taps: two taps x 16 channels for channels 0..15 (five MFMAs for nine taps; the spare
+    // slot re-reads tap 8 with zero weights) and four taps x 8 channels for channels 16..23 (three MFMAs, rows permuted so that
+    // lane (pixel, q) receives channels 16 + 2q, 17 + 2q): the B operand is 16 raw bytes of the LDS patch at the tap's pixel.
+    // 8 ds_read_b128 + 8 MFMAs per 16-pixel row instead of 18 reads + 54 v_dot2c (the kernel is bound by vector-instruction issue).
+    u32x4 wa0[5], wa1[3];
+    int xo0[5], xo1[3];                                // B operand byte offsets inside the patch for tile row 0
     if constexpr (CIN == UBD_C) {
+        // the fragments are packed for channel 6q'+s' (forward.hip): entry of tap t, channel ch
+        auto wdw = [&](int t, int ch) { return to_bits<T>(dwlane[(t * 6 + ch % 6) * 64 + 16 * (ch / 6)]); };
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ts = 2 * j + (q >> 1), t = ts < 9 ? ts : 8;
+            const int e = i - 8 * (q & 1);                         // k = 8q + e <-> channel 8 (q & 1) + e == row i
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && e >= 0 && e < 8) w[e >> 1] = wdw(t, i) << (16 * (e & 1));
+            wa0[j] = u32x4{w[0], w[1], w[2], w[3]};
+            xo0[j] = ((t / 3) * C::PW + i * STRIDE + t % 3) * (UBD_C * 2) + 16 * (q & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ts = 4 * j + q, t = ts < 9 ? ts : 8;         // k-group q <-> tap 4j + q, channels 16..23
+            const int r = i & 3, e = 2 * (i >> 2) + r;             // row i = 4 qq + r <-> channel 16 + 2 qq + r (r < 2)
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && r < 2) w[e >> 1] = wdw(t, 16 + e) << (16 * (e & 1));
+            wa1[j] = u32x4{w[0], w[1], w[2], w[3]};
+            xo1[j] = ((t / 3) * C::PW + i * STRIDE + t % 3) * (UBD_C * 2) + 32;
+        }
         float pw6[6][2];
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-            // the fragments are packed for channel 6q'+s' (forward.hip); fetch the entry of this lane's channel
-            const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+            const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);      // this lane's channels
             const int src_lane = 16 * (ch / 6) + i, ss = ch % 6;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const unsigned wbits = to_bits<T>(dwlane[(t * 6 + ss) * 64 + src_lane]);
-                dwp[t][s] = (s & 1) ? (wbits << 16) : wbits;
-            }
             pw6[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
             pw6[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
         }
@@ -372,85 +392,47 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             if (has_next) load_regs(nxt, stage);
         }
 
-        if constexpr (CIN == UBD_C && STRIDE == 1) {
-            // stride 1: wave `wid` owns NR consecutive rows and slides over NR + 2 patch rows: every patch row is read
-            // from LDS once (3 x (b64 + b32)) and feeds up to three output rows
-            const int rb = wid * NR;
-            float dwv[NR][6];
+        if constexpr (CIN == UBD_C) {
 #pragma unroll
-            for (int o = 0; o < NR; ++o)
+            for (int k = 0; k < NR; ++k) {
+                const int r = STRIDE == 1 ? wid * NR + k : wid + 4 * k;
+                const int oy = oy0 + r;
+                const char *rowb = patch + r * (STRIDE * C::PW * UBD_C * 2);
+                u32x4 b0[5], b1[3];
 #pragma unroll
-                for (int s = 0; s < 6; ++s) dwv[o][s] = 0.f;
+                for (int j = 0; j < 5; ++j) b0[j] = *(const u32x4 *)(rowb + xo0[j]);
 #pragma unroll
-            for (int yy = 0; yy < NR + 2; ++yy) {
-                u32x2 a[3];
-                unsigned b[3];
+                for (int j = 0; j < 3; ++j) b1[j] = *(const u32x4 *)(rowb + xo1[j]);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 c0 = z4, c1 = z4;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const char *p = patch + ((rb + yy) * C::PW + i + kx) * (UBD_C * 2);
-                    a[kx] = *(const u32x2 *)(p + 8 * q);
-                    b[kx] = *(const unsigned *)(p + 32 + 4 * q);
-                }
+                for (int j = 0; j < 5; ++j) c0 = h16<T>::mfma(wa0[j], b0[j], c0);
 #pragma unroll
-                for (int o = 0; o < NR; ++o) {
-                    const int ky = yy - o;
-                    if (ky < 0 || ky > 2) continue;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int t = ky * 3 + kx;
-                        dwv[o][0] = dot2_16<T>(a[kx][0], dwp[t][0], dwv[o][0]); dwv[o][1] = dot2_16<T>(a[kx][0], dwp[t][1], dwv[o][1]);
-                        dwv[o][2] = dot2_16<T>(a[kx][1], dwp[t][2], dwv[o][2]); dwv[o][3] = dot2_16<T>(a[kx][1], dwp[t][3], dwv[o][3]);
-                        dwv[o][4] = dot2_16<T>(b[kx], dwp[t][4], dwv[o][4]);    dwv[o][5] = dot2_16<T>(b[kx], dwp[t][5], dwv[o][5]);
-                    }
-                }
-                if (yy >= 2) {                               // output row yy - 2 is complete
-                    const int o = yy - 2, oy = oy0 + rb + o;
-                    const u32x4 av = {pack2<T>(dwv[o][0], dwv[o][1]), pack2<T>(dwv[o][2], dwv[o][3]), pack2<T>(dwv[o][4], dwv[o][5]), 0u};
-                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 acc0 = h16<T>::mfma(pwb[0], av, z4);     // weights as the A operand: D = [channel][pixel]
-                    const f32x4 acc1 = h16<T>::mfma(pwb[1], av, z4);
-                    int npx = OW - ox0 < 16 ? OW - ox0 : 16;
-                    npx = (oy < OH) ? npx : 0;
-                    const u32x2 nomask = {0u, 0u};
-                    store_tile16_t<T, 0>(y, ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
-                }
+                for (int j = 0; j < 3; ++j) c1 = h16<T>::mfma(wa1[j], b1[j], c1);
+                // depthwise output rounded to T (as the oracle stores it) = B operand of the pointwise product
+                const u32x4 av = {pack2<T>(c0[0], c0[1]), pack2<T>(c0[2], c0[3]), pack2<T>(c1[0], c1[1]), 0u};
+                const f32x4 acc0 = h16<T>::mfma(pwb[0], av, z4);     // weights as the A operand: D = [channel][pixel]
+                const f32x4 acc1 = h16<T>::mfma(pwb[1], av, z4);
+                int npx = OW - ox0 < 16 ? OW - ox0 : 16;
+                npx = (oy < OH) ? npx : 0;
+                const u32x2 nomask = {0u, 0u};
+                store_tile16_t<T, 0>(y, ((size_t)img * OH + (oy < OH ? oy : 0)) * OW + ox0, npx, lane, acc0, acc1, bA, bB, nomask, nomask);
             }
         } else {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int r = wid + 4 * k;
             const int oy = oy0 + r;
-            float dwv[CPL];
+            float dwv = 0.f;
 #pragma unroll
-            for (int s = 0; s < CPL; ++s) dwv[s] = 0.f;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int t = ky * 3 + kx;
-                    const int pix = (r * STRIDE + ky) * C::PW + i * STRIDE + kx;
-                    if constexpr (CIN == UBD_C) {
-                        const char *p = patch + pix * (UBD_C * 2);
-                        const u32x2 a = *(const u32x2 *)(p + 8 * q);
-                        const unsigned b = *(const unsigned *)(p + 32 + 4 * q);
-                        dwv[0] = dot2_16<T>(a[0], dwp[t][0], dwv[0]); dwv[1] = dot2_16<T>(a[0], dwp[t][1], dwv[1]);
-                        dwv[2] = dot2_16<T>(a[1], dwp[t][2], dwv[2]); dwv[3] = dot2_16<T>(a[1], dwp[t][3], dwv[3]);
-                        dwv[4] = dot2_16<T>(b, dwp[t][4], dwv[4]);    dwv[5] = dot2_16<T>(b, dwp[t][5], dwv[5]);
-                    } else {
-                        dwv[0] = fmaf(((const float *)patch)[pix * CIN + cb], dwk[t][0], dwv[0]);
-                    }
-                }
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (CIN == UBD_C) {
-                const u32x4 av = {pack2<T>(dwv[0], dwv[1]), pack2<T>(dwv[2], dwv[3]), pack2<T>(dwv[4], dwv[5]), 0u};
-                acc0 = h16<T>::mfma(pwb[0], av, acc0);               // weights as the A operand: D = [channel][pixel]
-                acc1 = h16<T>::mfma(pwb[1], av, acc1);
-            } else {
-                const float dr = round16<T>(dwv[0]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][0], dr, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][1], dr, acc1, 0, 0, 0);
-            }
+                for (int kx = 0; kx < 3; ++kx)
+                    dwv = fmaf(((const float *)patch)[((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * CIN + cb], dwk[ky * 3 + kx][0], dwv);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const float dr = round16<T>(dwv);
+            const f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][0], dr, z4, 0, 0, 0);
+            const f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf[0][1], dr, z4, 0, 0, 0);
             int npx = OW - ox0 < 16 ? OW - ox0 : 16;
             npx = (oy < OH) ? npx : 0;
             const u32x2 nomask = {0u, 0u};
