@@ -183,17 +183,6 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         cinfo[rd] = sy | (sx << 8) | (part << 16);
     }
 
-    // border fix: pixels of the staged tiles owned by this thread, (row + 1) | (column + 1) << 8 | byte offset << 16
-    constexpr int ZP = (C::XPIX + C::GPIX + 255) / 256;
-    int zinfo[ZP];
-#pragma unroll
-    for (int k = 0; k < ZP; ++k) {
-        const int pix = (int)threadIdx.x + 256 * k;
-        int sy, sx, boff;
-        if (pix < C::XPIX) { sy = pix / C::XW; sx = pix % C::XW; boff = pix * (UBD_C * 2); }
-        else { sy = (pix - C::XPIX) / TW + 1; sx = (pix - C::XPIX) % TW + 1; boff = C::GOFF + (pix - C::XPIX) * (UBD_C * 2); }
-        zinfo[k] = pix < C::XPIX + C::GPIX ? (sy | (sx << 8) | (boff << 16)) : -1;
-    }
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
     const int tiles_y = (sh + W16_TH(TW) - 1) / W16_TH(TW), tiles_x = (sw + TW - 1) / TW;
     const int items = n * d * d * tiles_y * tiles_x;
@@ -214,20 +203,24 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         return r;
     };
     const unsigned lds_smem = ubd_lds_addr(smem);
+    // One buffer descriptor per image and tensor: pixels above / below the image fall out of its range by themselves, pixels left /
+    // right of it get an out-of-range offset, and the LDS-DMA writes ZEROS for them -- the 'same' padding of X and the ragged
+    // border of a sub-grid tile cost neither clamped addresses nor the fix-up pass + second barrier per item that most items of a
+    // dilated layer needed (round-2 stamps: ~1 k of 5.5 k cycles per item).
+    const unsigned img_bytes = (unsigned)h * (unsigned)w * (UBD_C * 2);
     auto dma_item = [&](const item_t &I, int bufoff) {
         const size_t imgoff = (size_t)I.img * h * w * (UBD_C * 2);
-        const char *bx = (const char *)x + imgoff, *bg = (const char *)gz + imgoff;       // wave-uniform bases
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)x + imgoff), 0, (int)img_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)gz + imgoff), 0, (int)img_bytes, 0x00020000);
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int piece = rd * 4 + wid;
             if (piece >= C::XR + C::GR) break;                        // wave-uniform
             const int ci = cinfo[rd];
-            int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;
-            int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
-            gy = min(max(gy, 0), h - 1);                              // clamped; out-of-image pixels are zeroed later
-            gx = min(max(gx, 0), w - 1);
-            const unsigned off = (unsigned)((gy * w + gx) * (UBD_C * 2)) + (unsigned)((ci >> 16) & 0xFF) * 16u;
-            ubd_glds16_sbase(piece < C::XR ? bx : bg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
+            const int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;      // < 0 or >= h: the offset leaves the descriptor's range
+            const int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
+            const unsigned off = (unsigned)gx < (unsigned)w ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + (unsigned)((ci >> 16) & 0xFF) * 16u : 0x80000000u;
+            ubd_blds16(piece < C::XR ? rx : rg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
 
@@ -253,23 +246,6 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * C::BUF_BYTES); }
         WGSTAMP(3);
-        const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
-                            (I.ry + (I.sy0 + W16_TH(TW)) * d >= h) || (I.rx + (I.sx0 + TW) * d >= w);   // block-uniform
-        if (ragged) {
-#pragma unroll
-            for (int k = 0; k < ZP; ++k) {            // this thread's tile pixels (sub-grid offsets precomputed: most items of a dilated
-                const int zi = zinfo[k];              // layer touch the border of their sub-grid, and the divisions cost 1 k cycles per item)
-                if (zi < 0) continue;
-                const int gy = I.ry + (I.sy0 + (zi & 0xFF) - 1) * d, gx = I.rx + (I.sx0 + ((zi >> 8) & 0xFF) - 1) * d;
-                if (gy < 0 || gy >= h || gx < 0 || gx >= w) {
-                    u32x4 *z = (u32x4 *)(buf + (zi >> 16));
-                    const u32x4 zero = {0u, 0u, 0u, 0u};
-                    z[0] = zero; z[1] = zero; z[2] = zero;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();             // raw barrier: the next item's DMA stays in flight
-        }
         WGSTAMP(4);
         const int rows_eff = min(W16_TH(TW), sh - I.sy0);
 #pragma unroll 1

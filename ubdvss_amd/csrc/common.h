@@ -62,6 +62,15 @@ __device__ __forceinline__ void ubd_glds16_sbase(const void *base_uniform, unsig
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base_uniform), "s"(lds_dst) : "memory");
 }
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): lanes whose byte offset lies outside the descriptor's
+// range land as ZEROS in LDS -- 'same' padding and ragged tile borders need no clamped address and no fix-up pass afterwards
+// (checked on gfx950 by tools/ubench/buflds.hip: offsets past the end and wrapped negative offsets both zero-fill)
+__device__ __forceinline__ void ubd_blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned ubd_lds_addr(const void *lds_generic)
 {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);
