@@ -265,6 +265,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
                                                  (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 16), 16, 0, 0);
             return;
         }
+        // border tile: the same pieces through a buffer descriptor that covers exactly the image -- rows above / below it fall out
+        // of range by themselves, columns left / right of it get an out-of-range offset, and the LDS-DMA writes ZEROS for them
+        // (the 'same' padding; no clamped addresses, no zero-fix pass and no extra barrier afterwards)
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(src + (size_t)img * H * W * (UBD_C * 2)), 0,
+                                                                        (int)((unsigned)H * W * (UBD_C * 2)), 0x00020000);
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int cbase = rd * 256 + wid * 64;
@@ -272,12 +277,9 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             c = c < C::CHUNKS ? c : C::CHUNKS - 1;
             const int pix = c / 3, sp = c - pix * 3;
             const int pr = pix / C::PW, pc = pix - pr * C::PW;
-            int gy = iy0 + pr, gx = ix0 + pc;
-            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);                 // clamped; out-of-image pixels are zeroed afterwards
-            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-            const char *g = src + (((size_t)img * H + gy) * W + gx) * (UBD_C * 2) + sp * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(buf + cbase * 16), 16, 0, 0);
+            const int gy = iy0 + pr, gx = ix0 + pc;
+            const unsigned off = (unsigned)gx < (unsigned)W ? (unsigned)((gy * W + gx) * (UBD_C * 2) + sp * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + cbase * 16), 16, (int)off, 0, 0, 0);
         }
     };
     int ld_rel[C::STAGE_REGS];
@@ -361,21 +363,6 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
             {
                 const int ahead_tile = tile + AHEAD * (int)gridDim.x;
                 if (ahead_tile < total) dma_tile(ahead_tile, patch_mem + ((it + AHEAD) % NBUF) * C::BUF_BYTES);
-            }
-            const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
-            const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
-            if (border) {                                            // block-uniform
-                for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
-                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                    const int gy = iy0 + pr, gx = ix0 + pc;
-                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                        u32x4 *z = (u32x4 *)(patch + pix * (UBD_C * 2));
-                        const u32x4 zero = {0u, 0u, 0u, 0u};
-                        z[0] = zero; z[1] = zero; z[2] = zero;
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_s_barrier();
             }
         } else {
             __builtin_amdgcn_s_barrier();
