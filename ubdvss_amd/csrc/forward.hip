@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
                                                  (__attribute__((address_space(3))) void *)(buf + (rd * 256 + wid * 64) * 4), 16, 0, 0);
             return;
         }
+        // border tile: the same pieces through a buffer descriptor that covers exactly the image -- rows above / below it fall out
+        // of range by themselves, columns left / right of it get an out-of-range offset, and the LDS-DMA writes ZEROS for them
+        // (the 'same' padding; no clamped addresses, no zero-fix pass and no extra barrier afterwards)
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(src + (size_t)img * H * W * (UBD_C * sizeof(float))), 0,
+                                                                        (int)((unsigned)H * W * (unsigned)(UBD_C * sizeof(float))), 0x00020000);
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int cbase = rd * 256 + wid * 64;                   // wave-uniform first chunk of this piece
@@ -252,12 +257,9 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
             const int pr = pix / C::PW, pc = pix - pr * C::PW;
             int part = sp + 3 * ((pc >> 3) & 1);
             part = part >= 6 ? part - 6 : part;
-            int gy = iy0 + pr, gx = ix0 + pc;
-            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
-            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-            const char *g = src + ((((size_t)img * H + gy) * W + gx) * UBD_C + part * 4) * sizeof(float);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, 0, 0);
+            const int gy = iy0 + pr, gx = ix0 + pc;
+            const unsigned off = (unsigned)gx < (unsigned)W ? (unsigned)(((gy * W + gx) * UBD_C + part * 4) * (int)sizeof(float)) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, (int)off, 0, 0, 0);
         }
     };
     // 1 / 3 channels: plain loads into registers (converted / preprocessed), stored to LDS later
@@ -334,22 +336,6 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
             else { static_assert(NSTORE == 2, "counted vmcnt"); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             __builtin_amdgcn_s_barrier();    // + everyone left the other buffer
             if (has_next) dma_tile(nxt, patch_mem + ((it + 1) & 1) * C::BUF_FLOATS);
-            const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
-            const bool border = (iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W);
-            if (border) {                                            // block-uniform
-                for (int pix = threadIdx.x; pix < C::PH * C::PW; pix += 256) {
-                    const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                    const int gy = iy0 + pr, gx = ix0 + pc;
-                    if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                        f32x4 *z = (f32x4 *)(patch + pix * UBD_C);
-                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) z[k] = zero;
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): zeros written
-                __builtin_amdgcn_s_barrier();                        // raw barrier: must not drain the DMA in flight
-            }
         } else {
             __builtin_amdgcn_s_barrier();                            // previous tile's readers are done (no memory drain)
 #pragma unroll
