@@ -71,6 +71,13 @@ __device__ __forceinline__ void ubd_blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
+// the 4-byte form (64 lanes x 4 B land at lds_dst + 4 * lane): rows of fp32 pixels that are only 4-byte aligned
+__device__ __forceinline__ void ubd_blds4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned ubd_lds_addr(const void *lds_generic)
 {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);

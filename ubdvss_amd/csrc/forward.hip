@@ -784,9 +784,10 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #else
 #define S123_STAMP_ARG
 #endif
-#define UBD_LAUNCH_S123(CINV, U8V) hipLaunchKernelGGL((stem123_kernel<CINV, U8V>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket S123_STAMP_ARG)
-        if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1); else UBD_LAUNCH_S123(1, 0); }
-        else { if (u8) UBD_LAUNCH_S123(3, 1); else UBD_LAUNCH_S123(3, 0); }
+#define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket S123_STAMP_ARG)
+        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 31);   // fp32 fed as it is: LDS-DMA path
+        if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
+        else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
 #undef UBD_LAUNCH_S123
     } else if (h->cfg.c_in == 1)
         launch_sep<1, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);

@@ -23,7 +23,8 @@ template <int CIN> struct s123_cfg {
     static constexpr int XH = 2 * B::PH + 1, XW = 2 * AC + 1;      // input patch 23 x 69
     static constexpr int XE = XH * XW * CIN;                       // elements
     static constexpr int XREGS = (XE + NT - 1) / NT;
-    static constexpr int XP_FLOATS = (XE + 3) / 4 * 4;
+    static constexpr int XPIECES = (XE + 63) / 64;                 // PLAIN: 256-byte LDS-DMA pieces of the patch
+    static constexpr int XP_FLOATS = XPIECES * 64;                 // whole pieces (the last one runs past the patch)
     static constexpr int A1_FLOATS = B::PH * B::PW * UBD_C;        // a1 patch, stem23's layout
     static constexpr int NPIX = B::PH * AC;                        // 374 L1 outputs per tile
     static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
@@ -32,7 +33,10 @@ template <int CIN> struct s123_cfg {
     static constexpr int SMEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
 };
 
-template <int CIN, int IN_U8>
+// PLAIN: fp32 input that is fed as it is (no preprocessing): the patch goes straight from memory into LDS by 4-byte LDS-DMA through a
+// buffer descriptor (zeros outside the image = L1's padding), requested right after phase 0b of the previous tile -- no staging
+// registers and no phase 0a.
+template <int CIN, int IN_U8, int PLAIN>
 __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                                 const float *__restrict__ frag1, const float *__restrict__ bias1,
                                                                 const float *__restrict__ frag2, const float *__restrict__ bias2,
@@ -159,6 +163,23 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
     };
 
+    const unsigned lds_xp = ubd_lds_addr(xp);
+    auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, 256 bytes per piece
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)p.img * H * WC * 4), 0,
+                                                                        (int)((unsigned)H * WC * 4u), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (X::XPIECES + C::NW - 1) / C::NW; ++k) {
+            const int piece = k * C::NW + wid;
+            if (piece >= X::XPIECES) break;                                          // wave-uniform
+            const unsigned e = (unsigned)(piece * 64 + lane);                        // row-major [23][69 * C_in]; the last piece runs into row 23 (never read)
+            const unsigned row = e / (unsigned)RWF, col = e - row * (unsigned)RWF;
+            const int gy = iy0 + (int)row, gf = fx0 + (int)col;
+            const unsigned off = (unsigned)gf < (unsigned)WC ? (unsigned)((gy * WC + gf) * 4) : 0x80000000u;   // rows outside fall out of range by themselves
+            ubd_blds4(rsrc, off, lds_xp + piece * 256);
+        }
+    };
+
     // ---- phase 0b: this wave's L1 units (flat pixel p = 16 u + i of the 11 x 34 needed a1 pixels), constant per launch
     int u_rd[X::UPW], u_wr[X::UPW], u_rc[X::UPW];                  // input-patch read offset, a1-patch write offset, (row << 8 | col)
 #pragma unroll
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     tpos cur = strip_pos(0, 0);
     if (cur.ls >= strips) return;                                                    // block-uniform: nothing left
     tpos nx1 = advance(cur);
-    load_x(cur);
+    if constexpr (PLAIN) dma_x(cur); else load_x(cur);
     int pending = 0;                                                                 // ticket in flight (thread 0)
 #ifdef UBD_STAMPS   // diagnostic build only: s_memtime at the phase boundaries, lane 0 of every wave, first 16 tiles of the block
 #define S123_STAMP(k) do { if (stamps && it < 16 && lane == 0) stamps[(((size_t)blockIdx.x * 8 + wid) * 16 + it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -216,6 +237,12 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         const int A0y = R0 - 1, A0x = C0 - 1;                                        // a1 pixel of patch (0, 0)
 
         // ---- phase 0a: input patch -> LDS (fp32, preprocessed); request the next tile's
+        if constexpr (PLAIN) {
+            // the patch was requested by LDS-DMA after phase 0b of the previous tile; waves 0-3 leave the two output stores of that
+            // tile's phase B (younger than the DMA) in flight
+            if (wid < 4 && it > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
         const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;              // already preprocessed fp32 input: a copy
         if (!tile_interior(cur)) fix_border(cur);                                    // block-uniform
 #pragma unroll
@@ -227,6 +254,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             }
         }
         if (has_next) load_x(nx1);
+        }
         S123_STAMP(1);
         __syncthreads();                                                             // patch complete; phase B of the previous tile is over
         S123_STAMP(2);
@@ -276,6 +304,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         S123_STAMP(3);
         __syncthreads();
         S123_STAMP(4);
+        if constexpr (PLAIN) { if (has_next) dma_x(nx1); }                           // phase 0b has read the patch: the next tile's may land
 
         // ---- phase A: L2 on positions (0..8, 1..32)
         const bool mask_needed = (R0 < 0) || (R0 + C::LR > H2) || (C0 + C::LC > W2);
