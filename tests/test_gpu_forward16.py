@@ -193,3 +193,27 @@ def test_bf16_train_full_size_batch_is_deterministic():
     assert abs(float(t16.loss[0]) - float(t32.loss[0])) <= 2e-2 * abs(float(t32.loss[0]))
     cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
     assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("n,hh,ww", [(2, 256, 256), (3, 72, 104)])
+def test_bf16_dilated_backward_fused_equals_split(monkeypatch, n, hh, ww):
+    """The bf16 dilated backward computes a layer's data gradient inside its weight-gradient kernel (same staged tiles, same
+    MFMA order as the stand-alone data-gradient kernel): the gradients must be BIT-IDENTICAL to the two-kernel path
+    (UBD_DILBWD=split, read when the handle is created) -- on maps with several 16 x 16 sub-grid tiles per phase and on ragged ones."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(grey=False)
+    labels = synthetic.rectangle_maps(5, n, hh // 4, ww // 4)
+    x = torch.from_numpy(synthetic.textured_images(6, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads = {}
+    for mode in ("fused", "split"):
+        if mode == "split":
+            monkeypatch.setenv("UBD_DILBWD", "split")
+        else:
+            monkeypatch.delenv("UBD_DILBWD", raising=False)
+        m = Model(cfg, dtype="bfloat16", seed=9)
+        t = Trainer(m, Adam())
+        t.backward_on_device(x, y)
+        grads[mode] = t.grads.clone()
+        assert torch.isfinite(grads[mode]).all()
+    assert torch.equal(grads["fused"], grads["split"])

@@ -1030,11 +1030,17 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
             if (!partials) return -1;
+            // 16-wide tiles: weight gradient AND data gradient of the layer from the same staged tiles (bwd16.h); UBD_DILBWD=split (a
+            // diagnostic / test switch) and the 8-wide tiles of narrow sub-grids keep the separate data-gradient kernel
+            const unsigned *wt = frag16t + (size_t)k * UBD_DIL16_FRAG_U32;
+            const bool fuse_dx = tw == 16 && !h->split_dilbwd;
             if (tw == 8)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr WG_STAMP_ARG);
+            else if (fuse_dx)
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1] WG_STAMP_ARG);
             else
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd WG_STAMP_ARG);
-            ubd_launch_dilconv16(h, 1, frag16t + (size_t)k * UBD_DIL16_FRAG_U32, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr WG_STAMP_ARG);
+            if (!fuse_dx) ubd_launch_dilconv16(h, 1, wt, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }
         rp_flush(&rq, st);

@@ -116,23 +116,47 @@ __global__ __launch_bounds__(256) void head_bwd1_16_kernel(const float *__restri
                                               // bookkeeping cost as much as one k-block of MFMAs); 8 x 8 sub-grids (dilation 16 on 128-wide maps) keep 8 rows
 // TW = 16 (default) or 8 (sub-grids at most 8 columns wide, i.e. dilation 16 on 128-wide maps: half of a 16-wide tile
 // would be padding).  k-block = 32 sub-pixels = 2 rows x 16 or 4 rows x 8.
-template <int TW> struct w16_cfg {
+template <int TW, bool DX = false> struct w16_cfg {
     static constexpr int XW = TW + 2;
-    static constexpr int XPIX = (W16_TH(TW) + 2) * XW;           // 180 / 100
-    static constexpr int GPIX = W16_TH(TW) * TW;                 // 128 / 64
+    static constexpr int XPIX = (W16_TH(TW) + 2) * XW;           // 324 / 100
+    // DX (the data gradient of the same layer is computed from the same tiles, see dil_wgrad16_kernel): the G tile carries its
+    // one-pixel halo too and has the X tile's geometry
+    static constexpr int GW = DX ? XW : TW;                      // G tile row pitch in pixels
+    static constexpr int GPIX = DX ? XPIX : W16_TH(TW) * TW;     // 324 / 256 / 64
     // DMA pieces (one wave-instruction = 64 chunks of 16 bytes): the X tile is padded to whole pieces so that a piece is
-    // either X or G -- its tensor base then sits in scalar registers and the lanes add a 32-bit offset
-    static constexpr int XR = (XPIX * 3 + 63) / 64, GR = (GPIX * 3 + 63) / 64;   // 9 + 6 / 5 + 3 pieces
+    // either X or G -- its tensor's descriptor then sits in scalar registers and the lanes add a 32-bit offset
+    static constexpr int XR = (XPIX * 3 + 63) / 64, GR = (GPIX * 3 + 63) / 64;   // 16 + 12 (16 with halo) / 5 + 3 pieces
     static constexpr int GOFF = XR * 1024;                   // byte offset of the G tile in a buffer
     static constexpr int ROUNDS = (XR + GR + 3) / 4;         // pieces per wave
-    static constexpr int BUF_BYTES = ROUNDS * 4 * 1024;      // 16 KiB / 8 KiB
+    static constexpr int BUF_BYTES = ROUNDS * 4 * 1024;      // 28 KiB (32 with halo) / 8 KiB
     static constexpr int KROWS = 32 / TW;                    // tile rows per k-block
 };
 #define W16_BUF_BYTES_MAX (w16_cfg<16>::BUF_BYTES)
 
-template <typename T, int TW>
+// 16 x 16 two-bit helpers of the fused data gradient (the separable-layer header has its own)
+template <typename T> __device__ __forceinline__ unsigned wg_pack2(float lo, float hi)
+{
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
+}
+// g (two 16-bit values) with each half zeroed where the matching half of the saved activation m (never negative) is +0 / -0
+__device__ __forceinline__ unsigned wg_relu_mask2(unsigned g, unsigned m)
+{
+    unsigned k, r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(m & 0x7FFF7FFFu), "v"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(g), "v"(k));
+    return r;
+}
+
+// DX: the DATA gradient of the layer, G' = conv(G, flipped / transposed kernels) * (X > 0), is computed from the same staged tiles
+// right after the weight-gradient MFMAs of an item (its mask is the X tile the weight gradient reads anyway, its input the G tile
+// with a one-pixel halo): the separate data-gradient kernel read G and X once more (100 MB per layer and 64 images) and spent most
+// of its instructions on addresses.  Same arithmetic in the same order as dilconv16_kernel<T, 1> (bit-identical results).
+template <typename T, int TW, bool DX>
 __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
-                                                             float *__restrict__ partials, int n, int h, int w, int d
+                                                             float *__restrict__ partials, int n, int h, int w, int d,
+                                                             const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout
 #ifdef UBD_STAMPS
                                                              , unsigned long long *__restrict__ stamps
 #endif
@@ -143,15 +167,16 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
 #else
 #define WGSTAMP(k) do {} while (0)
 #endif
-    using C = w16_cfg<TW>;
+    using C = w16_cfg<TW, DX>;
     constexpr int TILES_BYTES = 2 * C::BUF_BYTES > 28672 ? 2 * C::BUF_BYTES : 28672;   // two tile buffers; the block reduction needs 28 KiB
-    constexpr int CONST_OFF = TILES_BYTES;                                    // [0,8): {1,0,0,0}   [8,16): zeros
-    __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 64];      // ONE LDS object (see fwd16.hip)
+    constexpr int CONST_OFF = TILES_BYTES;                                    // [0,8): {1,0,0,0}   [8,32): zeros
+    constexpr int WT_OFF = CONST_OFF + 64;                                    // DX: the layer's transposed fragments [7][2][64 lanes] x 16 B
+    __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 64 + (DX ? 7 * 2 * 64 * 16 : 0)];   // ONE LDS object (see fwd16.hip)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
     if (threadIdx.x < 16)
-        ((unsigned *)(smem + CONST_OFF))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;
+        ((unsigned *)(smem + CONST_OFF))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;   // 64 bytes: {1,0,0,0} then zeros
 
     // A operand: byte offset of segment p of M-tile mt relative to the X-tile pixel of the output position
     int aoff[14];
@@ -160,6 +185,16 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         const int rho0 = 16 * mt + 4 * p;
         const int t = rho0 / UBD_C, ci = rho0 - t * UBD_C;
         aoff[mt] = ((t / 3) * C::XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below)
+    }
+    // DX: this lane's K-slice of chunk c (as dilconv16_kernel): k0 = 32c + 8 grp -> tap (4c + grp) / 3, channel group (4c + grp) % 3
+    int doff[DX ? 7 : 1];
+    if constexpr (DX) {
+        for (int t = threadIdx.x; t < 7 * 2 * 64; t += 256) ((u32x4 *)(smem + WT_OFF))[t] = wfrag_t[t];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            const int g = 4 * c + grp, t = g / 3;
+            doff[c] = t < 9 ? ((t / 3 - 1) * C::GW + (t % 3 - 1)) * (UBD_C * 2) + (g - 3 * t) * 16 : -(1 << 20);   // chunk 6, k-group 3 lies beyond K: zeros
+        }
     }
     // pixel of this lane inside a k-block (2 tile rows x 16 columns or 4 x 8): k = 8 grp + 4 j + qq, j = 0, 1
     const int krow = TW == 16 ? grp >> 1 : grp, kcol = TW == 16 ? 8 * (grp & 1) + qq : qq;
@@ -178,7 +213,9 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         } else {
             int cg = (piece - C::XR) * 64 + lane;
             cg = cg < C::GPIX * 3 ? cg : C::GPIX * 3 - 1;
-            const int gp = cg / 3; part = cg - gp * 3; sy = gp / TW + 1; sx = gp % TW + 1;
+            const int gp = cg / 3; part = cg - gp * 3;
+            if constexpr (DX) { sy = gp / C::GW; sx = gp % C::GW; }         // with halo: the X tile's geometry
+            else { sy = gp / TW + 1; sx = gp % TW + 1; }
         }
         cinfo[rd] = sy | (sx << 8) | (part << 16);
     }
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
         for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
             const int py = C::KROWS * kb + krow;
             const char *xb = buf + (py * C::XW + kcol) * (UBD_C * 2);
-            const char *gb = buf + C::GOFF + (py * TW + kcol) * (UBD_C * 2);
+            const char *gb = buf + C::GOFF + ((py + (DX ? 1 : 0)) * C::GW + kcol + (DX ? 1 : 0)) * (UBD_C * 2);
             // B operand: segments of the two N tiles (co 0..15, 16..23 + zero padding)
             u32x4 b[2];
             {
@@ -275,6 +312,40 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
                 const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(va0, va1, 0, 1, 2, 3, 4, 5, 6, 7));
                 acc[mt][0] = mfma16<T>(a, b[0], acc[mt][0]);
                 acc[mt][1] = mfma16<T>(a, b[1], acc[mt][1]);
+            }
+        }
+        if constexpr (DX) {
+            const int i16 = lane & 15;
+            __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)gout + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
+            const char *zero16 = smem + CONST_OFF + 16;
+#pragma unroll 1
+            for (int nt = 0; nt < 2; ++nt) {                      // output channels 0..15, then 16..23 (one half of the fragments in registers at a time)
+                u32x4 wr[7];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) wr[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2 + nt) * 64 + lane];
+#pragma unroll 1
+                for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {
+#pragma unroll 1
+                    for (int rr = 0; rr < C::KROWS; ++rr) {
+                        const int r = C::KROWS * kb + rr;
+                        if (r >= rows_eff) break;                                 // wave-uniform
+                        const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + i16 + 1) * (UBD_C * 2);
+                        u32x4 a[7];
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
+                        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) acc1 = mfma16<T>(wr[c], a[c], acc1);      // weights as the A operand: D = [channel][pixel]
+                        // ReLU mask = the saved activation X of this pixel (centre of the X tile), same channels as the result rows
+                        const char *xpix = buf + ((r + 1) * C::XW + i16 + 1) * (UBD_C * 2);
+                        const bool lanes = nt == 0 || grp < 2;                    // second half: channels 16 + 4 grp + r exist for grp < 2
+                        const u32x2 m = *(const u32x2 *)(xpix + (nt == 0 ? 8 * grp : (grp < 2 ? 32 + 8 * grp : 0)));
+                        const u32x2 o = {wg_relu_mask2(wg_pack2<T>(acc1[0], acc1[1]), m[0]), wg_relu_mask2(wg_pack2<T>(acc1[2], acc1[3]), m[1])};
+                        const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i16) * d;
+                        const unsigned off = (lanes && gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + (nt == 0 ? 8u * grp : 32u + 8u * grp) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rout, (int)off, 0, 0);
+                    }
+                }
             }
         }
         WGSTAMP(5);
