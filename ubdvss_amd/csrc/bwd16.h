@@ -318,33 +318,36 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
             const int i16 = lane & 15;
             __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)gout + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
             const char *zero16 = smem + CONST_OFF + 16;
-#pragma unroll 1
-            for (int nt = 0; nt < 2; ++nt) {                      // output channels 0..15, then 16..23 (one half of the fragments in registers at a time)
-                u32x4 wr[7];
+            // both halves of the fragments (output channels 0..15 / 16..23) live in registers for the duration of this phase only
+            u32x4 wr0[7], wr1[7];
 #pragma unroll
-                for (int c = 0; c < 7; ++c) wr[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2 + nt) * 64 + lane];
+            for (int c = 0; c < 7; ++c) { wr0[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2) * 64 + lane]; wr1[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2 + 1) * 64 + lane]; }
 #pragma unroll 1
-                for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {
+            for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {
 #pragma unroll 1
-                    for (int rr = 0; rr < C::KROWS; ++rr) {
-                        const int r = C::KROWS * kb + rr;
-                        if (r >= rows_eff) break;                                 // wave-uniform
-                        const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + i16 + 1) * (UBD_C * 2);
-                        u32x4 a[7];
+                for (int rr = 0; rr < C::KROWS; ++rr) {
+                    const int r = C::KROWS * kb + rr;
+                    if (r >= rows_eff) break;                                 // wave-uniform
+                    const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + i16 + 1) * (UBD_C * 2);
+                    u32x4 a[7];
 #pragma unroll
-                        for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
-                        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < 7; ++c) acc1 = mfma16<T>(wr[c], a[c], acc1);      // weights as the A operand: D = [channel][pixel]
-                        // ReLU mask = the saved activation X of this pixel (centre of the X tile), same channels as the result rows
-                        const char *xpix = buf + ((r + 1) * C::XW + i16 + 1) * (UBD_C * 2);
-                        const bool lanes = nt == 0 || grp < 2;                    // second half: channels 16 + 4 grp + r exist for grp < 2
-                        const u32x2 m = *(const u32x2 *)(xpix + (nt == 0 ? 8 * grp : (grp < 2 ? 32 + 8 * grp : 0)));
-                        const u32x2 o = {wg_relu_mask2(wg_pack2<T>(acc1[0], acc1[1]), m[0]), wg_relu_mask2(wg_pack2<T>(acc1[2], acc1[3]), m[1])};
-                        const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i16) * d;
-                        const unsigned off = (lanes && gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + (nt == 0 ? 8u * grp : 32u + 8u * grp) : 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b64(o, rout, (int)off, 0, 0);
+                    for (int c = 0; c < 7; ++c) {                              // weights as the A operand: D = [channel][pixel]
+                        acc0 = mfma16<T>(wr0[c], a[c], acc0);
+                        acc1 = mfma16<T>(wr1[c], a[c], acc1);
                     }
+                    // ReLU mask = the saved activation X of this pixel (centre of the X tile), same channels as the result rows
+                    const char *xpix = buf + ((r + 1) * C::XW + i16 + 1) * (UBD_C * 2);
+                    const u32x2 m0 = *(const u32x2 *)(xpix + 8 * grp);
+                    const u32x2 m1 = *(const u32x2 *)(xpix + (grp < 2 ? 32 + 8 * grp : 0));
+                    const u32x2 o0 = {wg_relu_mask2(wg_pack2<T>(acc0[0], acc0[1]), m0[0]), wg_relu_mask2(wg_pack2<T>(acc0[2], acc0[3]), m0[1])};
+                    const u32x2 o1 = {wg_relu_mask2(wg_pack2<T>(acc1[0], acc1[1]), m1[0]), wg_relu_mask2(wg_pack2<T>(acc1[2], acc1[3]), m1[1])};
+                    const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i16) * d;
+                    const unsigned off = (gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + 8u * grp : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b64(o0, rout, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(grp < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4 grp + r exist for grp < 2
                 }
             }
         }
