@@ -154,7 +154,7 @@ __device__ __forceinline__ unsigned wg_relu_mask2(unsigned g, unsigned m)
 // with a one-pixel halo): the separate data-gradient kernel read G and X once more (100 MB per layer and 64 images) and spent most
 // of its instructions on addresses.  Same arithmetic in the same order as dilconv16_kernel<T, 1> (bit-identical results).
 template <typename T, int TW, bool DX>
-__global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
+__global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d,
                                                              const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout
 #ifdef UBD_STAMPS
@@ -324,11 +324,15 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
             for (int c = 0; c < 7; ++c) { wr0[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2) * 64 + lane]; wr1[c] = ((const u32x4 *)(smem + WT_OFF))[(c * 2 + 1) * 64 + lane]; }
 #pragma unroll 1
             for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {
+                // one MFMA column tile = 16 pixels = one tile row of a 16-wide tile, two rows of an 8-wide one
+                constexpr int RSTEP = 16 / TW;
+                const int prow = TW == 16 ? 0 : i16 >> 3, pcol = TW == 16 ? i16 : i16 & 7;
 #pragma unroll 1
-                for (int rr = 0; rr < C::KROWS; ++rr) {
-                    const int r = C::KROWS * kb + rr;
-                    if (r >= rows_eff) break;                                 // wave-uniform
-                    const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + i16 + 1) * (UBD_C * 2);
+                for (int rr = 0; rr < C::KROWS; rr += RSTEP) {
+                    const int r0 = C::KROWS * kb + rr;
+                    if (r0 >= rows_eff) break;                                // wave-uniform
+                    const int r = r0 + prow;
+                    const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + pcol + 1) * (UBD_C * 2);
                     u32x4 a[7];
 #pragma unroll
                     for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
@@ -339,12 +343,12 @@ __global__ __launch_bounds__(256, (TW == 8 ? 3 : 2)) void dil_wgrad16_kernel(con
                         acc1 = mfma16<T>(wr1[c], a[c], acc1);
                     }
                     // ReLU mask = the saved activation X of this pixel (centre of the X tile), same channels as the result rows
-                    const char *xpix = buf + ((r + 1) * C::XW + i16 + 1) * (UBD_C * 2);
+                    const char *xpix = buf + ((r + 1) * C::XW + pcol + 1) * (UBD_C * 2);
                     const u32x2 m0 = *(const u32x2 *)(xpix + 8 * grp);
                     const u32x2 m1 = *(const u32x2 *)(xpix + (grp < 2 ? 32 + 8 * grp : 0));
                     const u32x2 o0 = {wg_relu_mask2(wg_pack2<T>(acc0[0], acc0[1]), m0[0]), wg_relu_mask2(wg_pack2<T>(acc0[2], acc0[3]), m0[1])};
                     const u32x2 o1 = {wg_relu_mask2(wg_pack2<T>(acc1[0], acc1[1]), m1[0]), wg_relu_mask2(wg_pack2<T>(acc1[2], acc1[3]), m1[1])};
-                    const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i16) * d;
+                    const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + pcol) * d;
                     const unsigned off = (gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + 8u * grp : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b64(o0, rout, (int)off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(grp < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4 grp + r exist for grp < 2
