@@ -217,3 +217,23 @@ def test_bf16_dilated_backward_fused_equals_split(monkeypatch, n, hh, ww):
         grads[mode] = t.grads.clone()
         assert torch.isfinite(grads[mode]).all()
     assert torch.equal(grads["fused"], grads["split"])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n,hh,ww", [(2, 256, 256), (3, 72, 104), (1, 512, 384)])
+def test_forward16_staged_dilated_kernel_equals_direct(monkeypatch, dtype, n, hh, ww):
+    """The 16-bit forward dilated layers run on tiles of the dilation sub-grids staged in LDS (hardware zero fill = padding);
+    same MFMA order and epilogue as the direct kernel (UBD_DILCONV16=direct, read when the handle is created): bit-identical
+    logits, on maps with several tiles per phase, ragged ones and non-square ones."""
+    cfg = NetConfig(grey=False)
+    x = torch.from_numpy(synthetic.noise_images(3, n, hh, ww, 3)).cuda()
+    out = {}
+    for mode in ("staged", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("UBD_DILCONV16", "direct")
+        else:
+            monkeypatch.delenv("UBD_DILCONV16", raising=False)
+        m = Model(cfg, dtype=dtype, seed=11)
+        out[mode] = m.predict_on_device(x).clone()
+        assert torch.isfinite(out[mode]).all()
+    assert torch.equal(out["staged"], out["direct"])

@@ -49,6 +49,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         if (s && strcmp(s, "fused123") == 0) { h->fuse_stem = 2; h->fuse_force = 1; }   // forced at any launch size (tests)
         if (s && strcmp(s, "unfused") == 0) h->fuse_stem = 0;
         { const char *b = getenv("UBD_DILBWD"); h->split_dilbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
+        { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }
     }
     // Keras model.get_weights() order
     size_t off = 0;

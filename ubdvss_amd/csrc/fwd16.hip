@@ -565,6 +565,121 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
     }
 }
 
+// ------------------------------------------------------------------------------------ dilated layer, staged in LDS
+// The same product on tiles of the dilation sub-grids (items = (image, phase of the d x d sub-grid, 16 x 16 tile), as the bf16
+// weight-gradient kernel): the 18 x 18 input tile arrives by descriptor-addressed LDS-DMA (ubd_blds16: rows / columns outside the
+// image land as zeros = the 'same' padding), double-buffered one item ahead; a wave takes four tile rows, per row seven
+// ds_read_b128 (A fragments at the tap offsets, constant per lane) + 14 MFMAs + the epilogue.  The direct kernel above spends
+// 159 instructions per 16 pixels (PMC: waves wait for an issue slot half of their time), 28 of them on per-load column checks
+// and most of the scalar ones on per-tile bookkeeping; here the bookkeeping is per 256 pixels.  EPI 0 (bias + ReLU) only.
+#define D16S_PIX (18 * 18)
+#define D16S_PIECES ((D16S_PIX * 3 + 63) / 64)               // 16 pieces of 1 KiB (the last one runs past the tile)
+#define D16S_BUF (D16S_PIECES * 1024)
+template <typename T>
+__global__ __launch_bounds__(256, 3) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
+                                                            const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
+                                                            int w, int d)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * D16S_BUF + 64];     // ONE LDS object; [2 BUF, +64): zeros
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, q = lane >> 4;
+    if (threadIdx.x < 16) ((unsigned *)(smem + 2 * D16S_BUF))[threadIdx.x] = 0u;
+    u32x4 wr[7][2];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { wr[c][0] = wfrag[(c * 2 + 0) * 64 + lane]; wr[c][1] = wfrag[(c * 2 + 1) * 64 + lane]; }
+    const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
+    const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c + q) / 3, channel group (4c + q) % 3; chunk 6, q = 3 lies beyond K
+    int doff[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const int g = 4 * c + q, t = g / 3;
+        doff[c] = t < 9 ? ((t / 3 - 1) * 18 + (t % 3 - 1)) * (UBD_C * 2) + (g - 3 * t) * 16 : -(1 << 20);
+    }
+    // DMA chunk -> (tile row, tile column, 16-byte part) of this lane, per piece of this wave (piece = 4 rd + wid)
+    int cinfo[D16S_PIECES / 4];
+#pragma unroll
+    for (int rd = 0; rd < D16S_PIECES / 4; ++rd) {
+        int c = (rd * 4 + wid) * 64 + lane;
+        c = c < D16S_PIX * 3 ? c : D16S_PIX * 3 - 1;
+        const int pix = c / 3, sy = pix / 18;
+        cinfo[rd] = sy | ((pix - sy * 18) << 8) | ((c - pix * 3) << 16);
+    }
+    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
+    const int tiles_y = (sh + 15) >> 4, tiles_x = (sw + 15) >> 4;
+    const int items = n * d * d * tiles_y * tiles_x;
+    struct item_t { int img, ry, rx, sy0, sx0; };
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d);
+    auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
+    auto decode = [&](int it) {
+        item_t r;
+        unsigned a = (unsigned)it, b;
+        b = divm(a, (unsigned)tiles_x, m_tx); const int tx = (int)(a - b * (unsigned)tiles_x); a = b;
+        b = divm(a, (unsigned)tiles_y, m_ty); const int ty = (int)(a - b * (unsigned)tiles_y); a = b;
+        b = divm(a, (unsigned)d, m_d); r.rx = (int)(a - b * (unsigned)d); a = b;
+        b = divm(a, (unsigned)d, m_d); r.ry = (int)(a - b * (unsigned)d);
+        r.img = (int)b;
+        r.sy0 = ty * 16; r.sx0 = tx * 16;
+        return r;
+    };
+    const unsigned lds_smem = ubd_lds_addr(smem);
+    const unsigned img_bytes = (unsigned)h * (unsigned)w * (UBD_C * 2);
+    auto dma_item = [&](const item_t &I, int bufoff) {
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)x + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int rd = 0; rd < D16S_PIECES / 4; ++rd) {
+            const int ci = cinfo[rd];
+            const int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;      // < 0 or >= h: the offset leaves the descriptor's range
+            const int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
+            const unsigned off = (unsigned)gx < (unsigned)w ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + (unsigned)((ci >> 16) & 0xFF) * 16u : 0x80000000u;
+            ubd_blds16(rx, off, lds_smem + bufoff + (rd * 4 + wid) * 1024);
+        }
+    };
+    // XCD-aware item ranges (the d x d phases of an image interleave inside the same cache lines: one L2 per image)
+    const int xcd = blockIdx.x & 7;
+    const int nblk_x = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int chunk = (items + 7) >> 3;
+    const int it_begin = xcd * chunk;
+    const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
+    int it = it_begin + (int)(blockIdx.x >> 3);
+    item_t I = decode(it < it_end ? it : it_begin);
+    if (it < it_end) dma_item(I, 0);
+    const char *zero16 = smem + 2 * D16S_BUF;
+    for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
+        const char *buf = smem + (iter & 1) * D16S_BUF;
+        // this item's tile has landed; the eight output stores of the previous item (younger than its DMA) stay in flight
+        if (iter > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // ... for every wave; everyone left the other buffer
+        item_t Inext = I;
+        if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * D16S_BUF); }
+        __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)y + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
+#pragma unroll 2
+        for (int rr = 0; rr < 4; ++rr) {              // fixed trip count: rows outside the sub-grid only lose their stores
+            const int r = 4 * wid + rr;
+            const char *gpix = buf + ((r + 1) * 18 + i + 1) * (UBD_C * 2);
+            u32x4 a[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {             // weights as the A operand: D = [channel][pixel]
+                acc0 = h16<T>::mfma(wr[c][0], a[c], acc0);
+                acc1 = h16<T>::mfma(wr[c][1], a[c], acc1);
+            }
+            acc0 += bA; acc1 += bB;                   // bias added last (the order the oracle uses), ReLU on the packed values
+            const u32x2 o0 = {relu_pk16(pack2<T>(acc0[0], acc0[1])), relu_pk16(pack2<T>(acc0[2], acc0[3]))};
+            const u32x2 o1 = {relu_pk16(pack2<T>(acc1[0], acc1[1])), relu_pk16(pack2<T>(acc1[2], acc1[3]))};
+            const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i) * d;
+            const unsigned off = (gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + 8u * q : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b64(o0, rout, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(q < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4q + r exist for q < 2
+        }
+        I = Inext;
+    }
+}
+
 // ------------------------------------------------------------------------------------ head
 template <typename T>
 __global__ __launch_bounds__(256) void head16_kernel(const unsigned short *__restrict__ x, float *__restrict__ logits,
@@ -654,7 +769,16 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     int grid = ubd_grid_for(tiles, h->num_cus, 4, 4);
     grid = (grid + 7) / 8 * 8;
     const unsigned mg_tx = magic_u32(tiles_x), mg_h = magic_u32((unsigned)H4);
-    if (epi == 0)
+    // forward layers whose dilation sub-grids are wider than 8 pixels: the LDS-staged kernel (UBD_DILCONV16=direct keeps the direct one)
+    const int sw = (W4 + d - 1) / d, sh = (H4 + d - 1) / d;
+    if (epi == 0 && sw > 8 && !h->direct_dil16) {
+        const long items = (long)n * d * d * ((sh + 15) / 16) * ((sw + 15) / 16);
+        int g2 = h->num_cus * 3;
+        if (g2 > items) g2 = (int)items;
+        g2 = (g2 + 7) / 8 * 8;                                     // the item ranges are cut per XCD: all eight need a block
+        hipLaunchKernelGGL((dilconv16s_kernel<T>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                           (const u32x4 *)frag, bias, n, H4, W4, d);
+    } else if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
     else if (epi == 2)      // out = fp32 logits (n, H4, W4, 1), mask = fp32 head (24 weights + bias)
