@@ -180,22 +180,20 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
     };
 
-    // ---- phase 0b: this wave's L1 units (flat pixel p = 16 u + i of the 11 x 34 needed a1 pixels), constant per launch
-    int u_rd[X::UPW], u_wr[X::UPW], u_rc[X::UPW];                  // input-patch read offset, a1-patch write offset, (row << 8 | col)
+    // ---- phase 0b: this wave's L1 units (flat pixel p = 16 u + i of the 11 x 34 needed a1 pixels), constant per launch.
+    // Phase 0b of tile t + 1 shares a barrier interval with phase B of tile t (below), which only waves 0-3 run: they take two
+    // units each, waves 4-7 four.
+    constexpr int UPW = 4;
+    int u_rc[UPW];                                                 // a1 patch (row << 8 | column 1..34) of this lane's pixel, -1: none (the read / write offsets are rebuilt from it: registers)
 #pragma unroll
-    for (int k = 0; k < X::UPW; ++k) {
-        const int u = wid + C::NW * k;
-        int p = u * 16 + i;
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wid >= 4 ? (wid - 4) + 4 * k : (k < 2 ? 16 + wid + 4 * k : X::UNITS);
+        const int p = u * 16 + i;
         const bool live = u < X::UNITS && p < X::NPIX;
-        p = live ? p : 0;
-        const int ar = p / X::AC, ac = p - ar * X::AC + 1;         // a1 patch (row, column 1..34)
-        u_rd[k] = ((2 * ar) * X::XW + 2 * (ac - 1)) * CIN + (q < CIN ? q : 0);
-        const int rot = 3 * ((ac >> 3) & 1);
-        int s4 = q + rot;
-        s4 = s4 >= 6 ? s4 - 6 : s4;
-        u_wr[k] = (ar * C::PW + ac) * UBD_C + 4 * s4;              // chunk q; chunk 4 + q (q < 2) sits 16 floats further, modulo the rotation
+        const int ar = (live ? p : 0) / X::AC, ac = (live ? p : 0) - ar * X::AC + 1;
         u_rc[k] = live ? ((ar << 8) | ac) : -1;
     }
+    const int qc = q < CIN ? q : 0;
     // ---- phase A constants (stem23.h, CARRY variant)
     const int half = wid & 1, rg = wid >> 1;
     const int rb = rg == 0 ? 0 : 2 * rg + 1, rw = rg == 0 ? 3 : 2;
@@ -220,31 +218,16 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     tpos cur = strip_pos(0, 0);
     if (cur.ls >= strips) return;                                                    // block-uniform: nothing left
     tpos nx1 = advance(cur);
-    if constexpr (PLAIN) dma_x(cur); else load_x(cur);
     int pending = 0;                                                                 // ticket in flight (thread 0)
 #ifdef UBD_STAMPS   // diagnostic build only: s_memtime at the phase boundaries, lane 0 of every wave, first 16 tiles of the block
 #define S123_STAMP(k) do { if (stamps && it < 16 && lane == 0) stamps[(((size_t)blockIdx.x * 8 + wid) * 16 + it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define S123_STAMP(k) do {} while (0)
 #endif
-    for (int it = 0;; ++it) {
-        S123_STAMP(0);
-        const bool new_strip = cur.tx == 0;                                          // block-uniform
-        if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
-        const bool has_next = nx1.ls < strips;                                       // block-uniform
-        const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
-        const int A0y = R0 - 1, A0x = C0 - 1;                                        // a1 pixel of patch (0, 0)
-
-        // ---- phase 0a: input patch -> LDS (fp32, preprocessed); request the next tile's
-        if constexpr (PLAIN) {
-            // the patch was requested by LDS-DMA after phase 0b of the previous tile; waves 0-3 leave the two output stores of that
-            // tile's phase B (younger than the DMA) in flight
-            if (wid < 4 && it > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
+    // ---- phase 0a of tile p (non-PLAIN): the patch, requested a phase ago into registers, goes to LDS (preprocessed)
+    auto convert_x = [&](tpos p) {
         const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;              // already preprocessed fp32 input: a copy
-        if (!tile_interior(cur)) fix_border(cur);                                    // block-uniform
+        if (!tile_interior(p)) fix_border(p);                                        // block-uniform
 #pragma unroll
         for (int k = 0; k < X::XREGS; ++k) {
             const int e = k * C::NT + (int)threadIdx.x;
@@ -253,13 +236,10 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 else xp[e] = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
             }
         }
-        if (has_next) load_x(nx1);
-        }
-        S123_STAMP(1);
-        __syncthreads();                                                             // patch complete; phase B of the previous tile is over
-        S123_STAMP(2);
-
-        // ---- phase 0b: L1 -> a1 patch image
+    };
+    // ---- phase 0b of tile p: L1 -> a1 patch image
+    auto phase0b = [&](tpos p) {
+        const int A0y = 2 * p.ty * C::TH3 - 2, A0x = 32 * p.tx - 2;                  // a1 pixel of patch (0, 0)
         float dwk1[9], pwf1[2];
         {
             const f32x4 wa = *(const f32x4 *)(w1t + lane * 12), wb = *(const f32x4 *)(w1t + lane * 12 + 4), wc = *(const f32x4 *)(w1t + lane * 12 + 8);
@@ -268,13 +248,16 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
         const f32x4 b1A = *(const f32x4 *)(bt + 4 * q), b1B = *(const f32x4 *)(bt + 16 + 4 * q);      // zeros beyond channel 23
 #pragma unroll
-        for (int k = 0; k < X::UPW; ++k) {
-            if (wid + C::NW * k >= X::UNITS) continue;                               // wave-uniform
+        for (int k = 0; k < UPW; ++k) {
+            if (wid < 4 && k >= 2) continue;                                         // wave-uniform: waves 0-3 own two units
+            const int rc0 = u_rc[k] < 0 ? 1 : u_rc[k];                               // lanes without a pixel compute on pixel (0, 1) and store nothing
+            const int ar0 = rc0 >> 8, ac0 = rc0 & 255;
+            const int u_rd = ((2 * ar0) * X::XW + 2 * (ac0 - 1)) * CIN + qc;
             float dv = 0.f;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd[k] + (ky * X::XW + kx) * CIN], dwk1[ky * 3 + kx], dv);
+                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd + (ky * X::XW + kx) * CIN], dwk1[ky * 3 + kx], dv);
             f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv, b1A, 0, 0, 0);
             f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv, b1B, 0, 0, 0);
 #pragma unroll
@@ -284,7 +267,10 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             const bool inside = rc >= 0 && (unsigned)(A0y + ar) < (unsigned)H2 && (unsigned)(A0x + ac) < (unsigned)W2;
             if (!inside) { acc0 = z4; acc1 = z4; }                                   // L2's zero padding
             if (rc >= 0) {
-                float *dst = a1p + u_wr[k];
+                const int rot0 = 3 * ((ac >> 3) & 1);
+                int s4 = q + rot0;
+                s4 = s4 >= 6 ? s4 - 6 : s4;
+                float *dst = a1p + (ar * C::PW + ac) * UBD_C + 4 * s4;               // chunk q; chunk 4 + q (q < 2) sits 16 floats further, modulo the rotation
                 *(f32x4 *)dst = acc0;
                 if (q < 2) {                                                         // chunk 4 + q: slot (4 + q + 3f) % 6
                     const int rot = 3 * ((ac >> 3) & 1);
@@ -294,6 +280,26 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 }
             }
         }
+    };
+
+    // ---- first tile: patch -> LDS, L1
+    if constexpr (PLAIN) { dma_x(cur); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else { load_x(cur); convert_x(cur); }
+    __syncthreads();
+    phase0b(cur);
+    __syncthreads();
+    // Per tile t (two block barriers): [request the input patch of t + 1] -> phase A(t) -> [patch of t + 1 complete in LDS] -> barrier
+    // -> phase B(t) on waves 0-3 beside phase 0b(t + 1) (waves 4-7 take twice the units) -> barrier.  Phase 0b of the next tile
+    // touches nothing phase B reads (the inherited L2 column is moved at the start of phase A instead), so the four waves that
+    // have no L3 row do not idle through phase B.
+    for (int it = 0;; ++it) {
+        S123_STAMP(0);
+        const bool new_strip = cur.tx == 0;                                          // block-uniform
+        if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
+        const bool has_next = nx1.ls < strips;                                       // block-uniform
+        const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
+        if (has_next) { if constexpr (PLAIN) dma_x(nx1); else load_x(nx1); }        // phase 0b(t) has read the patch: the next tile's may land
         if (wid == C::NW - 1 && lane < C::LR * 6) {
             // L2 position 0 (column 2*ox0 - 1): the previous tile's position 32, or L3's zero padding at the left image edge
             const int row = lane / 6, ch4 = lane - row * 6;
@@ -301,10 +307,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             if (cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);
             *(f32x4 *)(l2 + (row * C::LC) * C::LP + 4 * ch4) = v;
         }
-        S123_STAMP(3);
-        __syncthreads();
-        S123_STAMP(4);
-        if constexpr (PLAIN) { if (has_next) dma_x(nx1); }                           // phase 0b has read the patch: the next tile's may land
+        S123_STAMP(1);
 
         // ---- phase A: L2 on positions (0..8, 1..32)
         const bool mask_needed = (R0 < 0) || (R0 + C::LR > H2) || (C0 + C::LC > W2);
@@ -365,9 +368,14 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 }
             }
         }
-        S123_STAMP(5);
-        __syncthreads();
-        S123_STAMP(6);
+        S123_STAMP(2);
+        if (has_next) {
+            if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch has landed (requested a whole phase A ago)
+            else convert_x(nx1);
+        }
+        S123_STAMP(3);
+        __syncthreads();                                                             // L2 tile and the next input patch are complete
+        S123_STAMP(4);
 
         // ---- phase B, waves 0-3: L3 output row oy0 + wid
         if (wid < 4) {
@@ -397,9 +405,13 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             }
             store_tile_relu_t(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1, z4, z4);   // bias already in
         }
-        S123_STAMP(7);
+        S123_STAMP(5);
         if (!has_next) break;
-        if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;   // visible after the next tile's barriers
+        phase0b(nx1);
+        S123_STAMP(6);
+        if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;       // visible after the barrier below and the next tile's
+        __syncthreads();                                                             // a1 patch of the next tile complete; phase B is over
+        S123_STAMP(7);
         cur = nx1;
         nx1 = advance(nx1);
     }
