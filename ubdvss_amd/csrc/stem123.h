@@ -7,13 +7,16 @@
 // batch of 32 at fp32) ever exists in memory: the stem reads 100 MB (25 MB for uint8) and writes 50 MB.  Price: L1 is
 // recomputed on the 11 x 34 halo patch of every tile (1.46x its arithmetic -- L1 is the cheap layer: 3 input channels) and L2 on
 // 9 x 32 (1.125x).  The per-tile phases:
-//   0a  the tile's 23 x 69 x C_in input patch, requested a tile ago into registers, goes to LDS (preprocessing / uint8
-//       conversion on the way, 0 outside the image = L1's zero padding); the next tile's loads are issued
+//   0a  the tile's 23 x 69 x C_in input patch goes to LDS: fp32 input that is fed as it is (PLAIN) by 4-byte LDS-DMA through a
+//       buffer descriptor (zeros outside the image = L1's zero padding), requested a whole phase A ahead; uint8 / preprocessed
+//       input through registers (requested at the start of phase A, converted right after it)
 //   0b  L1 on the 374 patch pixels as 24 units of 16 (flat index -> (row, col)): depthwise on the VALU (lane = pixel x input
 //       channel), pointwise = 2 fp32 MFMAs, bias + ReLU, 0 outside L1's map (= L2's zero padding), into the a1 patch image
-//       (the chunk-rotated layout stem23's phase A reads); wave 7 also moves the inherited 33rd L2 column into place
-//   A   L2 on 9 x 32 positions (as stem23.h, CARRY variant);   B   L3 (waves 0-3), 16-byte stores.
-// Three block barriers per tile, one 8-wave block per CU.  Training keeps the separate kernels (it needs a1 and a2).
+//       (the chunk-rotated layout stem23's phase A reads)
+//   A   L2 on 9 x 32 positions (as stem23.h, CARRY variant; wave 7 first moves the inherited 33rd L2 column into place);
+//   B   L3 (waves 0-3), 16-byte stores.
+// Two block barriers per tile, one 8-wave block per CU: phase B of tile t shares its barrier interval with phase 0b of tile
+// t + 1 (waves 4-7, which have no L3 row, take twice the L1 units).  Training keeps the separate kernels (it needs a1 and a2).
 #pragma once
 
 template <int CIN> struct s123_cfg {
