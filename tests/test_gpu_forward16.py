@@ -107,7 +107,7 @@ def test_bf16_full_batch_property_and_postprocess():
 
 @pytest.mark.parametrize("dtype,tol64", [("bfloat16", 4e-2), ("float16", 3e-2)])
 @pytest.mark.parametrize("cin,ncls,fml,n,hh,ww", [(3, 0, True, 2, 64, 64), (1, 2, True, 2, 64, 96), (3, 2, False, 1, 128, 64),
-                                                   (3, 0, True, 3, 72, 104)])
+                                                   (3, 0, True, 3, 72, 104), (3, 0, True, 2, 100, 140), (1, 0, False, 1, 132, 68)])
 def test_train_step_16bit(dtype, tol64, cin, ncls, fml, n, hh, ww):
     """configs[2] (bf16 train step) on small shapes: 16-bit activations, kernels and depthwise intermediates, 16-bit
     MFMA forward, fp32 accumulation / weight gradients / master weights; bf16 mode also keeps the gradient tensors

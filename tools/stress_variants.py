@@ -1,0 +1,39 @@
+"""Shape sweep of the kernel variants that must agree BIT FOR BIT (run on the GPU box):
+  * bf16 / fp16 forward: LDS-staged dilated kernel vs direct kernel (UBD_DILCONV16=direct)
+  * bf16 train step: data gradient fused into the weight-gradient kernel vs the two-kernel path (UBD_DILBWD=split)
+  * fp32 inference: one-kernel stem vs three kernels (UBD_STEM=fused123 / unfused), fp32 and uint8 input
+on ragged and non-square shapes (sides are multiples of 4, maps not multiples of 16, narrow sub-grids)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
+torch.cuda.set_device(0)
+shapes = [(1, 68, 140), (2, 100, 76), (1, 132, 260), (1, 516, 36), (2, 36, 516), (3, 200, 328), (1, 1028, 68), (2, 260, 260), (1, 64, 64), (5, 128, 192)]
+bad = 0
+def model(env, **kw):
+    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM"): os.environ.pop(k, None)
+    os.environ.update(env)
+    return Model(NetConfig(grey=False), seed=7, **kw)
+for (n, h, w) in shapes:
+    x = torch.from_numpy(synthetic.noise_images(n + h, n, h, w, 3)).cuda()
+    for dt in ("bfloat16", "float16"):
+        a = model({}, dtype=dt).predict_on_device(x).clone()
+        b = model({"UBD_DILCONV16": "direct"}, dtype=dt).predict_on_device(x).clone()
+        ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
+        print(f"{n}x{h}x{w} {dt:9s} forward staged == direct: {ok}", flush=True)
+    lab = synthetic.rectangle_maps(n + w, n, h // 4, w // 4)
+    xt = torch.from_numpy(synthetic.textured_images(h, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(lab).cuda()
+    g = []
+    for env in ({}, {"UBD_DILBWD": "split"}):
+        t = Trainer(model(env, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y); g.append(t.grads.clone())
+    ok = torch.equal(g[0], g[1]) and bool(torch.isfinite(g[0]).all()); bad += not ok
+    print(f"{n}x{h}x{w} bf16 train fused == split: {ok}", flush=True)
+    x8 = torch.from_numpy(np.random.default_rng(n * h).integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+    for name, inp in (("fp32", x), ("uint8", x8)):
+        a = model({"UBD_STEM": "fused123"}).predict_on_device(inp).clone()
+        b = model({"UBD_STEM": "unfused"}).predict_on_device(inp).clone()
+        ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
+        print(f"{n}x{h}x{w} fp32 net, {name} input, stem fused123 == unfused: {ok}", flush=True)
+print("MISMATCHES:", bad)
+sys.exit(1 if bad else 0)
