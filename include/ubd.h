@@ -56,6 +56,9 @@ void ubd_destroy(ubd_handle *h);
  * (SURVEY.md 9.2): per separable layer [depthwise(3,3,C,1), pointwise(1,1,C,24), bias],
  * per Conv2D [kernel HWIO, bias]; head last. */
 size_t ubd_param_count(const ubd_handle *h);
+/* Compute units the handle sizes its persistent grids for: the device's count, or UBD_TEST_NUM_CUS when that is set at
+ * ubd_create (tests walk many tiles per block on small shapes with it; no reference counterpart). */
+int ubd_num_cus(const ubd_handle *h);
 
 /* Bytes of caller-provided device workspace needed by ubd_forward / ubd_train_step
  * for a batch of n images of height x width (multiples of 4). */

@@ -269,7 +269,9 @@ def test_fused_stem_path(monkeypatch):
             w = onet.init_weights(400 + cin + ncls, cin, ncls, bias_scale=0.25)
             x = synthetic.noise_images(19, n, hh, ww, cin)
             ref = onet.forward(x.astype(np.float64), w, fml)
-            lg = _model(cin, ncls, fml, w).predict(x)
+            mdl = _model(cin, ncls, fml, w)
+            assert (mdl.num_cus == 2) == mode.endswith("few_cus")        # the override reached ubd_create
+            lg = mdl.predict(x)
             _check(lg, ref)
             outs[(mode, cin, ncls, fml, n, hh, ww)] = lg
         # uint8 input, preprocessing fused into the first layer

@@ -26,6 +26,7 @@ def test_forward_many_tiles_per_block(one_cu, dtype, tol):
     cin, ncls, n, hh, ww = 3, 2, 3, 136, 200
     cfg = NetConfig(class_names=["a", "b"], grey=False)
     m = Model(cfg, dtype=dtype, seed=0)
+    assert m.num_cus == 1                                    # the override reached ubd_create: grids are sized for one CU
     w = onet.init_weights(5, cin, ncls, bias_scale=0.2)
     m.set_weights(w)
     x = synthetic.noise_images(6, n, hh, ww, cin)
@@ -40,6 +41,7 @@ def test_train_step_many_tiles_per_block(one_cu, dtype):
     cin, ncls, n, hh, ww = 3, 0, 2, 160, 224
     cfg = NetConfig(grey=False)
     model = Model(cfg, dtype=dtype, seed=0)
+    assert model.num_cus == 1
     w = onet.init_weights(93, cin, ncls, bias_scale=0.2)
     w[-2] = (w[-2] * 4).astype(np.float32)
     model.set_weights(w)

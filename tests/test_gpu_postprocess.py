@@ -218,3 +218,106 @@ def test_pipelined_runner_matches_serial():
     for k in (3, 4):
         for a, r in zip([t for t in got[k] if t is not None], ref[k]):
             assert torch.equal(a, r)
+
+
+# ---------------------------------------------------------------------------------------------- stress / determinism
+STRESS_LAUNCHES = int(os.environ.get("UBD_PP_STRESS_LAUNCHES", "500"))
+
+
+def _stress_inputs(golden_dir):
+    """The batch that exposed the round-2 flatten race, the golden rectangles and 128 x 128 noise maps."""
+    rng = np.random.default_rng(77)
+    cases = []
+    maps = synthetic.rectangle_maps(21, 16, 128, 128)
+    cases.append(("rect21", synthetic.logits_from_maps(maps, 0, seed=22), 256))
+    gmaps = np.load(os.path.join(golden_dir, "post_rect.npz"))["maps"].astype(np.int32)
+    cases.append(("golden", synthetic.logits_from_maps(gmaps, 0, seed=5, noise=0.0), 256))
+    noise = rng.random((4, 128, 128)) < 0.55
+    noise[1] = ndi.binary_closing(noise[1]); noise[2] = rng.random((128, 128)) < 0.5
+    cases.append(("noise", np.where(noise[..., None], 1.5, -1.5).astype(np.float32), 4200))
+    return cases
+
+
+def _oracle_lists(lg, min_area, cap):
+    det = (lg[..., 0] > 0).astype(np.int32)
+    quads = np.zeros((lg.shape[0], cap, 8), np.int32)
+    counts = np.zeros((lg.shape[0],), np.int32)
+    for i in range(lg.shape[0]):
+        q, _ = ocv.postprocess(det[i], None, 4, min_area)
+        counts[i] = len(q)
+        if len(q):
+            quads[i, :len(q)] = np.asarray(q).reshape(-1, 8)
+    return quads, counts
+
+
+@pytest.mark.parametrize("mode", ["alone", "concurrent_forward", "poison"])
+def test_postprocess_stress_deterministic(golden_dir, front_end, mode, monkeypatch):
+    """>= 500 launches per input through each front end; EVERY launch must reproduce the oracle's lists (a rare race in the
+    union-find phases shows up as one wrong quad in one launch -- round 2's driver run).  `concurrent_forward`: a forward
+    pass of another batch runs on a second stream the whole time, as in the pipelined runner (blocks of both kernels share
+    CUs, LDS contents of earlier blocks differ).  `poison`: the one-launch front end starts from poisoned LDS and checks that the
+    forest is flat and every slot it reads was written (an integrity failure makes counts impossible)."""
+    if mode == "poison":
+        if front_end == "global":
+            pytest.skip("the poison hook belongs to the one-launch LDS front end")
+        monkeypatch.setenv("UBD_PP_POISON", "1")
+    model = _model(0)
+    side = torch.cuda.Stream()
+    fwd_in = torch.from_numpy(synthetic.noise_images(3, 8, 512, 512, 3)).cuda() if mode == "concurrent_forward" else None
+    for name, lg, cap in _stress_inputs(golden_dir):
+        ref_q, ref_c = _oracle_lists(lg, 5, cap)
+        ref_q, ref_c = torch.from_numpy(ref_q).cuda(), torch.from_numpy(ref_c).cuda()
+        lt = torch.from_numpy(lg).cuda()
+        outs = model.alloc_postprocess_outputs(lg.shape[0], lg.shape[1], lg.shape[2], cap)
+        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+        first_bad = None
+        for it in range(STRESS_LAUNCHES):
+            if fwd_in is not None and it % 4 == 0:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    model.predict_on_device(fwd_in)
+            outs[1].fill_(-7)                                            # stale results of the previous launch cannot pass
+            _, quads, _, counts = model.postprocess_on_device(lt, 0.0, 4, 5, cap=cap, outputs=outs)
+            ok = torch.equal(counts, ref_c)
+            if ok:
+                live = torch.arange(cap, device="cuda")[None, :, None] < ref_c[:, None, None]
+                ok = bool(((quads == ref_q) | ~live).all())
+            if not ok and first_bad is None:
+                first_bad = (it, counts.cpu().numpy().copy(), quads.cpu().numpy().copy())
+            bad += 0 if ok else 1
+        torch.cuda.synchronize()
+        assert int(bad) == 0, (name, front_end, mode, int(bad), first_bad[0], first_bad[1], ref_c.cpu().numpy())
+
+
+def test_postprocess_stress_in_pipelined_runner():
+    """The same check inside ModelRunner(pipelined=True): the postprocess of batch k on the side stream under the forward
+    pass of batch k+1 (the bench's headline path), 300 steps over a ring of batches at the headline map size; every step's
+    lists equal the serial runner's lists of that batch."""
+    cfg = NetConfig(grey=False)
+    model = Model(cfg, seed=5)
+    w = onet.init_weights(41, 3, 0, bias_scale=0.3)
+    model.set_weights(w)
+    serial, piped = ModelRunner(cfg, max_objects_per_image=4200), ModelRunner(cfg, pipelined=True, max_objects_per_image=4200)
+    batches, ref = [], []
+    for k in range(4):
+        labels = synthetic.rectangle_maps(170 + k, 8, 128, 128)
+        b = torch.from_numpy(synthetic.textured_images(180 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+        batches.append(b)
+        _, bmap, quads, _, counts = serial.predict_on_device(model, b)
+        ref.append((bmap.clone(), quads.clone(), counts.clone()))
+    torch.cuda.synchronize()
+    pending = None
+    bad = []
+    for it in range(300):
+        k = it % 4
+        out = piped.predict_on_device(model, batches[k])
+        if pending is not None:                                   # results of the previous step: complete once its event fired
+            pk, pout, pev = pending
+            pev.synchronize()
+            _, bmap, quads, _, counts = pout
+            live = torch.arange(quads.shape[1], device="cuda")[None, :, None] < ref[pk][2][:, None, None]
+            if not (torch.equal(bmap, ref[pk][0]) and torch.equal(counts, ref[pk][2]) and bool(((quads == ref[pk][1]) | ~live).all())):
+                bad.append(it - 1)
+        pending = (k, out, piped.last_event)
+    torch.cuda.synchronize()
+    assert not bad, bad[:10]

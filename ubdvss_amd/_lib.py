@@ -29,6 +29,7 @@ SIGNATURES = {
     "ubd_create": (_i, [ctypes.POINTER(UbdConfig), ctypes.POINTER(_vp)]),
     "ubd_destroy": (None, [_vp]),
     "ubd_param_count": (_sz, [_vp]),
+    "ubd_num_cus": (_i, [_vp]),
     "ubd_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_train_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_postprocess_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),

@@ -48,6 +48,9 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         if (s && strcmp(s, "fused") == 0) { h->fuse_stem = 1; h->fuse_force = 1; }      // 1: L1, then L2 -> L3 fused (stem23.h)
         if (s && strcmp(s, "fused123") == 0) { h->fuse_stem = 2; h->fuse_force = 1; }   // forced at any launch size (tests)
         if (s && strcmp(s, "unfused") == 0) h->fuse_stem = 0;
+        // test hooks: pretend the device has fewer CUs, so that every persistent kernel walks many tiles per block even on
+        // the small shapes the CPU oracle can check (tests/test_gpu_persistent.py; ubd_num_cus reports what was taken)
+        { const char *c = getenv("UBD_TEST_NUM_CUS"); if (c && atoi(c) > 0) h->num_cus = atoi(c); }
         { const char *b = getenv("UBD_DILBWD"); h->split_dilbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }
     }
@@ -78,3 +81,4 @@ extern "C" void ubd_destroy(ubd_handle *h)
 }
 
 extern "C" size_t ubd_param_count(const ubd_handle *h) { return h ? h->n_params : 0; }
+extern "C" int ubd_num_cus(const ubd_handle *h) { return h ? h->num_cus : 0; }

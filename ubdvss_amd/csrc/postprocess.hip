@@ -761,6 +761,17 @@ __device__ __forceinline__ int uf_find_wg(int *lab, int a)
     return curr;
 }
 
+// read-only find (no stores at all)
+__device__ __forceinline__ int uf_find_ro_wg(const int *lab, int a)
+{
+    int p = __hip_atomic_load(&lab[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != a) {
+        a = p;
+        p = __hip_atomic_load(&lab[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return a;
+}
+
 __device__ __forceinline__ void uf_union_wg(int *lab, int a, int b)
 {
     for (;;) {
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     const float *__restrict__ logits, int k_out, float thr, int h, int w, float min_area, int cap, int n_cls, int root_cap,
     int *__restrict__ binary_map, int *__restrict__ g_nroots, int *__restrict__ g_nkept, int *__restrict__ g_owner,
     int *__restrict__ g_roots, int *__restrict__ g_kept, int *__restrict__ stage, int *__restrict__ ymax,
-    int *__restrict__ rows, float *__restrict__ vote
+    int *__restrict__ rows, float *__restrict__ vote, int poison
 #ifdef UBD_STAMPS
     , unsigned long long *__restrict__ stamps
 #endif
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     short *own16 = (short *)((char *)smem + (((size_t)lab_ints * 4 + 15) & ~(size_t)15));
     short *rs16 = own16 + hw;
     unsigned char *m = (unsigned char *)(rs16 + hw);
-    int *ctr = (int *)(m + ((hw + 15) & ~15));               // [0] roots, [1] kept
+    int *ctr = (int *)(m + ((hw + 15) & ~15));               // [0] roots, [1] kept, [2] integrity flag (UBD_PP_POISON)
     int *area2 = lab, *kept = lab + root_cap;                  // aliases, valid after the owner phase
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const size_t pbase = (size_t)img * hw;
@@ -821,8 +832,15 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     const float rcp_w = 1.0f / (float)w;
     auto row_of = [&](int loc) { return (int)(((float)loc + 0.5f) * rcp_w); };
 
+    // UBD_PP_POISON (tests): every LDS word the kernel uses starts as 0x7fff7fff instead of whatever the previous block left
+    // there, so that a read of a never-written entry gives an impossible node / slot instead of a plausible small integer
+    if (poison) {
+        const int words = (int)(((char *)(ctr + 4) - (char *)smem) / 4);
+        for (int i = tid; i < words; i += PP_LDS_THREADS) smem[i] = 0x7fff7fff;
+        __syncthreads();
+    }
     // ---- init (pp_init_kernel); the thread's logits are requested up front, PP_LDS_MAX_HW / PP_LDS_THREADS at most
-    if (tid < 2) ctr[tid] = 0;
+    if (tid < 3) ctr[tid] = 0;                                 // [2]: integrity flag of the test mode
     constexpr int PER_THREAD = PP_LDS_MAX_HW / PP_LDS_THREADS;
     float lg[PER_THREAD], lgl[PER_THREAD];                     // lgl: logit left of the wave's first pixel (lane 0 only), requested with the
 #pragma unroll                                               // rest: fetched inside the loop it was one dependent memory round trip per iteration
@@ -917,10 +935,20 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     __syncthreads();
     PPSTAMP();
 
-    // ---- flatten (pp_flatten_kernel)
+    // ---- flatten (pp_flatten_kernel).  READ-ONLY find: the only stores of this phase are true roots into the thread's own
+    // node.  (The compressing find of the merge phase must not be used here: its `lab[prev] = next` stores re-point OTHER
+    // nodes at a grandparent read earlier and can land after the owner of that node has stored its final root, leaving a
+    // stale non-root there -- the round-2 wrong-quad defect.)  Any value a concurrent reader sees in lab[x] is an ancestor
+    // of x or its root, so the walks stay correct while the stores land.
     for (int node = tid; node <= hw; node += PP_LDS_THREADS) {
-        const int r = uf_find_wg(lab, node);
+        const int r = uf_find_ro_wg(lab, node);
         __hip_atomic_store(&lab[node], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the owner / root-slot arrays were the union job queue until the barrier above: no entry is valid yet.  -1 = "no slot", so
+    // a read of an entry this launch never wrote cannot return a plausible slot (stale queue jobs are small integers).
+    {
+        int *z = (int *)own16;                                   // own16 [hw] | rs16 [hw] = hw ints from a 16-byte-aligned base
+        for (int i = tid; i < hw; i += PP_LDS_THREADS) z[i] = -1;
     }
     __syncthreads();
     PPSTAMP();
@@ -939,9 +967,12 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
 
     // ---- owner (pp_owner_kernel)
     for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+        // the forest is flat (every entry is a root: checked by tests/test_gpu_postprocess.py under UBD_PP_POISON through the
+        // slot of a non-root being -1), and a slot is read only at a root's own raster-first pixel
         int node = lab[loc + 1];
         int own = -1;
         for (int guard = 0; guard < 4096; ++guard) {
+            if (poison && lab[node] != node) atomicOr(&ctr[2], 1);          // test mode: a non-root survived the flatten phase
             if (node == 0) break;
             const int r = node - 1;
             if (r < w) { if (m[r]) own = rs16[r]; break; }
@@ -949,6 +980,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
             if (m[r] && up == 0) { own = rs16[r]; break; }
             node = up;
         }
+        if (poison && (own < -1 || own >= ctr[0])) atomicOr(&ctr[2], 1);   // test mode: a slot that no root wrote
         own16[loc] = (short)own;
         if (g_owner) g_owner[pbase + loc] = own;
     }
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         if (right_end) atomicMax(&r[2 * y + 1], x);
         if (bottom) atomicMax(&ymax[(size_t)img * cap + k], y);
     }
-    if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1]; }
+    if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1] | (ctr[2] << 30); }   // test mode: an integrity failure shows as an impossible count
     PPSTAMP();
 #undef PPSTAMP
 }
@@ -1062,7 +1094,10 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     int grid = (int)((npix + 255) / 256);
     const int gmax = hd->num_cus * 8;
     if (grid > gmax) grid = gmax;
-    const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;         // test hook: exercise the multi-launch front end
+    // test hooks, read per call (SegmapManager.postprocess keeps its handles): the multi-launch front end at any map size; LDS
+    // poisoning + forest integrity check of the one-launch front end
+    const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;
+    const int pp_poison = getenv("UBD_PP_POISON") != nullptr;
     if (hw <= PP_LDS_MAX_HW && !force_global) {
         if (!hd->pp_lds_attr_set) {                              // per handle = per device (the attribute belongs to the device's code object)
             UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW, PP_LDS_MAX_HW / 2 + 2)));   // 1-pixel-high maps hold the most roots per pixel
@@ -1070,7 +1105,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
         }
         hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
                            map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
-                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote
+                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote, pp_poison
 #ifdef UBD_STAMPS
                            , g_pp_stamps
 #endif

@@ -188,6 +188,11 @@ class Model:
         self._pp_ws = None
         self.set_weights(self._glorot_init(seed))
 
+    @property
+    def num_cus(self):
+        """Compute units the handle sizes its persistent grids for (the device's, or UBD_TEST_NUM_CUS at creation)."""
+        return int(self._lib.ubd_num_cus(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
