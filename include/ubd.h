@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define UBD_ABI_VERSION 1
+#define UBD_ABI_VERSION 2
 
 /* activation storage / compute dtype (weights, logits, loss and gradients are fp32) */
 enum { UBD_F32 = 0, UBD_BF16 = 1, UBD_F16 = 2 };
@@ -133,12 +133,14 @@ int ubd_adam_step(float *params, const float *grads, float *m, float *v, size_t 
 
 /* --- training labels --------------------------------------------------------
  * Replaces SegmapManager.build_segmentation_map (segmap_manager.py:81-104) + _proper_round (:106-133) for a whole batch:
- * every object quad (8 ints x1,y1..x4,y4 in IMAGE pixels) is divided by `scale`, its corners are snapped outward and the
- * polygon is filled with PIL's ImageDraw.polygon rule, objects in order (later over earlier), into an int32 map of
- * (map_h, map_w) = image size / scale.  values[i][o]: what to write (class id + 1, or 1; 255 for drawing).
- *   quads int32 (n, cap, 8), values int32 (n, cap), counts int32 (n) (objects per image, <= cap), labels int32 (n, map_h, map_w):
- * the y_true layout of ubd_loss / ubd_train_step.  Bit-identical to Pillow for convex quads (see raster.hip). */
-int ubd_build_label_maps(const int32_t *quads, const int32_t *values, const int32_t *counts, int n, int cap,
+ * every object quad (8 float64 x1,y1..x4,y4 in IMAGE pixels; fractional after _rescale_image_and_markup / augmentation) is
+ * divided by `scale` in double precision, its corners are snapped outward and the polygon is filled with PIL's
+ * ImageDraw.polygon rule, objects in order (later over earlier), into an int32 map of (map_h, map_w) = image size / scale.
+ * values[i][o]: what to write (class id + 1, or 1; 255 for drawing).
+ *   quads float64 (n, cap, 8), values int32 (n, cap), counts int32 (n) (objects per image, <= cap), labels int32 (n, map_h, map_w):
+ * the y_true layout of ubd_loss / ubd_train_step.  Bit-identical to Pillow for every quad except zero-area folds whose
+ * opposite corners coincide (see raster.hip); the Python host rejects those. */
+int ubd_build_label_maps(const double *quads, const int32_t *values, const int32_t *counts, int n, int cap,
                          int map_h, int map_w, int scale, int32_t *labels, void *stream);
 
 /* --- data parallelism (no reference counterpart: the reference is single-device) -------------------

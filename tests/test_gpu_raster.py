@@ -1,7 +1,7 @@
 """GPU: device label rasteriser (ubd_build_label_maps; reference SegmapManager.build_segmentation_map + _proper_round,
 segmap_manager.py:81-133) against Pillow itself -- the engine the reference calls -- through the host mirror, bit-exact for
-convex object quads (rotated rectangles, perspective quads, boxes touching / leaving the image, class values, painter's
-order), and against the pinned oracle restatement for arbitrary quads."""
+object quads (rotated rectangles, perspective quads, boxes touching / leaving the image, class values, painter's order), for
+fractional (rescaled) markup and for arbitrary concave / self-intersecting quads."""
 import numpy as np
 import pytest
 import torch
@@ -63,11 +63,49 @@ def test_full_size_batch_and_train_step_consumes_the_labels():
     assert torch.isfinite(tr.loss).all() and float(tr.loss[0]) > 0
 
 
-def test_arbitrary_quads_equal_the_pinned_restatement():
-    """Self-intersecting / degenerate quads: the device kernel implements oracle/label_raster.py exactly (which is pinned
-    against Pillow on CPU and differs from it only at concave corners of such quads)."""
+def _folded(q):
+    return (q[0] == q[4] and q[1] == q[5]) or (q[2] == q[6] and q[3] == q[7])
+
+
+def test_arbitrary_quads_equal_pillow():
+    """Concave, self-intersecting, degenerate and partly-outside quads: the device fill is Pillow's (corner joining at every
+    local corner), compared with Pillow itself; scale 1 so that the corners are exactly the drawn ones."""
     rng = np.random.default_rng(44)
-    markups = [[ObjectMarkup(rng.integers(-10, 200, 8))] for _ in range(256)]
-    got = SegmapManager.build_segmentation_maps_on_device((192, 160), markups, scale=4).cpu().numpy()
+    markups = []
+    while len(markups) < 512:
+        q = rng.integers(-10, 200, 8) if len(markups) % 2 else rng.integers(0, 24, 8)
+        if not _folded(q):
+            markups.append([ObjectMarkup(q)])
+    got = SegmapManager.build_segmentation_maps_on_device((192, 160), markups, scale=1).cpu().numpy()
+    assert np.array_equal(got, _pil_maps((192, 160), markups, 1))
+    got4 = SegmapManager.build_segmentation_maps_on_device((192, 160), markups, scale=4).cpu().numpy()
     for i, m in enumerate(markups):
-        assert np.array_equal(got[i], olr.build_label_map(160, 192, [m[0].bbox], [1], 4)), m[0].bbox
+        assert np.array_equal(got4[i], olr.build_label_map(160, 192, [m[0].bbox], [1], 4)), m[0].bbox
+    assert np.array_equal(got4, _pil_maps((192, 160), markups, 4))
+
+
+def test_fractional_markup_equals_pillow():
+    """Rescaled / augmented markup is float64: division by the scale, comparisons and floor / ceil of _proper_round happen on
+    the device in double precision (segmap_manager.py:96, :106-133) -- compared with the host mirror (numpy + Pillow)."""
+    rng = np.random.default_rng(45)
+    markups = []
+    for i in range(128):
+        objs = []
+        for _ in range(int(rng.integers(1, 5))):
+            q = np.asarray(synthetic.random_quads(rng, 160, 192, 1, 1)[0]).reshape(-1)          # fractional corners
+            if i % 3 == 0:
+                q = q * np.tile([192 / 200, 160 / 150], 4)                                       # what _rescale_image_and_markup does
+            if i % 5 == 0:
+                q = np.round(q * 4) / 4                                                          # quotients that land on integers
+            objs.append(ClassifiedObjectMarkup(q, int(rng.integers(0, 4))))
+        markups.append(objs)
+    for scale in (4, 1, 2):
+        got = SegmapManager.build_segmentation_maps_on_device((192, 160), markups, scale=scale).cpu().numpy()
+        assert np.array_equal(got, _pil_maps((192, 160), markups, scale)), scale
+
+
+def test_folded_quads_are_refused():
+    with pytest.raises(ValueError, match="opposite corners"):
+        SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 40, 12, 8, 8, 20, 50])]], scale=4)
+    with pytest.raises(ValueError, match="quadrilateral"):
+        SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 40, 12, 8, 30])]], scale=4)

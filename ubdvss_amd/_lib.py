@@ -12,7 +12,7 @@ UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
 UBD_COMM_FUSED = 1
 UBD_COMM_GLOBAL_LOSS = 2
 UBD_UNIQUE_ID_BYTES = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class UbdConfig(ctypes.Structure):

@@ -66,6 +66,17 @@ class SegmapManager:
         return [ClassifiedObjectMarkup(bbox, class_id) for bbox, class_id in zip(q, c)]
 
     @staticmethod
+    def prepare_image_and_target(image, markup, net_config, augment=False):
+        """segmap_manager.py:24-39 without the augmentation branch (imgaug pipeline: outside the hot path):
+        rescale image + markup to the network's size rule, build the label map at ``net_config.get_scale()``.
+        Returns (image, markup, label map) like the reference."""
+        if augment:
+            raise ValueError("augmentation is not part of this package (SURVEY.md section 2: out of scope); augment the "
+                             "image and markup first, then call prepare_image_and_target(..., augment=False)")
+        image, markup = SegmapManager._rescale_image_and_markup(image, markup, net_config)
+        return image, markup, SegmapManager.build_segmentation_map(image, markup, scale=net_config.get_scale())
+
+    @staticmethod
     def build_segmentation_map(image, markup, scale=1, for_drawing=False):
         """Training label map (behaviour of segmap_manager.py:81-104): every quad is divided by ``scale``, its
         corners are snapped outward (``_proper_round``) and the polygon is filled, later objects over earlier
@@ -98,7 +109,10 @@ class SegmapManager:
             raise AssertionError("image size must be a multiple of the map scale")
         n = len(markups)
         cap = max(1, max((len(m) for m in markups), default=1))
-        quads = np.zeros((n, cap, 8), np.int32)
+        # float64 markup, as it reaches the reference's `object_markup.bbox / scale` (segmap_manager.py:96): rescaled or
+        # augmented quads are fractional, and _proper_round floors / ceils the QUOTIENT -- truncating the markup first
+        # would move a corner by a whole map pixel (12.3 / 4 ceils to 4, 12 / 4 to 3)
+        quads = np.zeros((n, cap, 8), np.float64)
         values = np.zeros((n, cap), np.int32)
         counts = np.zeros((n,), np.int32)
         for i, objs in enumerate(markups):
@@ -107,8 +121,12 @@ class SegmapManager:
                 value = 255 if for_drawing else (getattr(obj, "object_type", 0) + 1 if isinstance(obj, ClassifiedObjectMarkup) else 1)
                 if value > 255:
                     raise AssertionError("No more than 255 classes are supported")
-                quads[i, j] = np.asarray(obj.bbox, dtype=np.int64).reshape(8)
+                bbox = np.asarray(obj.bbox, dtype=np.float64).reshape(-1)
+                if bbox.size != 8:
+                    raise ValueError(f"object markup must be a quadrilateral (8 numbers), got {bbox.size} (image {i}, object {j})")
+                quads[i, j] = bbox
                 values[i, j] = value
+        SegmapManager._reject_folded_quads(quads, counts, scale)
         qd, vd, cd = (torch.from_numpy(a).to(device) for a in (quads, values, counts))
         labels = torch.empty((n, height // scale, width // scale), dtype=torch.int32, device=device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -116,6 +134,49 @@ class SegmapManager:
             _lib.check(lib.ubd_build_label_maps(qd.data_ptr(), vd.data_ptr(), cd.data_ptr(), n, cap, height // scale, width // scale,
                                                 int(scale), labels.data_ptr(), stream), "ubd_build_label_maps")
         return labels
+
+    @staticmethod
+    def _reject_folded_quads(quads, counts, scale):
+        """The device fill rule is Pillow's for every quadrilateral except a zero-area fold whose OPPOSITE corners coincide
+        after snapping (four edges in one point: Pillow's corner joining there is order-dependent and not restated,
+        oracle/label_raster.py).  Such markup is a labelling error; it is refused instead of being drawn approximately."""
+        pts = (quads / float(scale)).reshape(quads.shape[0], quads.shape[1], 4, 2)
+        n_larger = (pts[:, :, None, :, :] > pts[:, :, :, None, :]).sum(axis=3)
+        snapped = np.where(n_larger > 1, np.floor(pts), np.ceil(pts))
+        folded = ((snapped[:, :, 0] == snapped[:, :, 2]).all(-1) | (snapped[:, :, 1] == snapped[:, :, 3]).all(-1))
+        folded &= np.arange(quads.shape[1])[None, :] < np.asarray(counts)[:, None]
+        if folded.any():
+            i, j = np.argwhere(folded)[0]
+            raise ValueError(f"object {j} of image {i}: opposite corners of the quad coincide on the label map "
+                             f"({quads[i, j].tolist()} at scale {scale}); fix the markup")
+
+    @staticmethod
+    def _rescale_image_and_markup(image, markup, net_config, max_side=None):
+        """Image and markup at the size the network wants (behaviour of segmap_manager.py:135-173): if the longer side exceeds
+        ``max_side`` (default ``net_config.get_max_side()``) it becomes exactly ``max_side`` and the other side is scaled
+        in proportion and rounded to a multiple of ``net_config.get_side_multiple()``; otherwise both sides are rounded to
+        that multiple.  Rounding is Python 3's ``round`` (half to even), at least one multiple.  The image is resampled
+        with ``Image.BICUBIC``; every quad is multiplied by (new_w / w, new_h / h) and rewrapped with
+        ``create_same_markup`` (so it stays fractional, float64).  Empty / None markup is returned as it is.  Host-side
+        by nature (a PIL image in, a PIL image out), like the reference."""
+        w, h = image.size
+        multiple = net_config.get_side_multiple()
+        if max_side is None:
+            max_side = net_config.get_max_side()
+
+        def to_multiple(side):
+            return max(1, round(side / multiple)) * multiple
+
+        if max(w, h) > max_side:
+            shrink = max_side / max(h, w)
+            new_w, new_h = (max_side, to_multiple(h * shrink)) if w > h else (to_multiple(w * shrink), max_side)
+        else:
+            new_w, new_h = to_multiple(w), to_multiple(h)
+        resized = image.resize(size=(new_w, new_h), resample=Image.BICUBIC)
+        if not markup:
+            return resized, markup
+        factors = np.array([[new_w / w, new_h / h]])
+        return resized, [m.create_same_markup((np.array(m.bbox).reshape((-1, 2)) * factors).reshape((-1,))) for m in markup]
 
     @staticmethod
     def _proper_round(markup_bbox):
