@@ -125,13 +125,12 @@ def cpu_child(kind, seconds, n_threads):
             det = (lg[..., 0] > -0.0).astype(np.uint8)
             return [ocv.postprocess(det[i], None, 4, 5) for i in range(BATCH)]
         times, el = _timed_repeats(step, seconds)
-        # value = the FASTEST repeat: the GPU boxes' hosts are shared (256 CPUs, other tenants), repeats on pinned cores
-        # scatter 2.5x (55 .. 137 images/s in one run) and the median moved 62 <-> 101 between two runs, while the best repeat
-        # was 130 and 137 -- the least-disturbed repeat is what the cores can do.  Median and slowest repeat are reported too.
-        res = {"value": round(BATCH / min(times), 2), "unit": "images/s", "kind": "port", **pin,
-               "median": round(BATCH / float(np.median(times)), 2), "min": round(BATCH / max(times), 2), "repeats": len(times),
+        # value = the MEDIAN repeat (BASELINE.md section 3 / SURVEY.md 8(d)); the GPU boxes' hosts are shared (256 CPUs, other
+        # tenants) and repeats on pinned cores scatter, so the fastest and slowest repeat are reported beside it
+        res = {"value": round(BATCH / float(np.median(times)), 2), "unit": "images/s", "kind": "port", **pin,
+               "fastest": round(BATCH / min(times), 2), "slowest": round(BATCH / max(times), 2), "repeats": len(times),
                "sample": f"{len(times)} repeats of ONE batch of {BATCH} textured 512x512x3 images (the GPU step's tensor), torch-CPU fp32 "
-                         f"forward (oneDNN) + C restatement of the OpenCV postprocess; value = fastest repeat, {el:.1f} s in all"}
+                         f"forward (oneDNN) + C restatement of the OpenCV postprocess; value = median repeat, {el:.1f} s in all"}
     elif kind == "train":
         nb = 8                                                    # the reference's default batch (train.py:31)
         w = onet.init_weights(1, C_IN, 0)
@@ -147,10 +146,10 @@ def cpu_child(kind, seconds, n_threads):
             g = np.concatenate([a.reshape(-1) for a in grads]).astype(np.float64)
             state["flat"], state["m"], state["v"] = otorch.adam_step(state["flat"], g, state["m"], state["v"], state["t"])
         times, el = _timed_repeats(step, seconds)
-        res = {"value": round(nb / min(times), 2), "unit": "images/s", "kind": "port", **pin,
-               "median": round(nb / float(np.median(times)), 2), "min": round(nb / max(times), 2), "repeats": len(times),
+        res = {"value": round(nb / float(np.median(times)), 2), "unit": "images/s", "kind": "port", **pin,
+               "fastest": round(nb / min(times), 2), "slowest": round(nb / max(times), 2), "repeats": len(times),
                "sample": f"{len(times)} steps of batch {nb} (512x512x3), torch-CPU fp32 forward + loss + autograd backward + Adam; "
-                         f"value = fastest step, {el:.1f} s in all"}
+                         f"value = median step, {el:.1f} s in all"}
     else:                                                         # "latency": predict.py:73-78 on the CPU stand-in
         res = {**pin}
         for side in (512, 1024):
@@ -215,11 +214,68 @@ def launch_ranks(args):
             line = ln
         else:
             print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)                                   # rank 0's line is relayed even when a later leg failed (the reason is in it)
     if proc.returncode != 0 or line is None:
         print(f"bench.py: the {n}-rank run failed (exit code {proc.returncode})", file=sys.stderr)
         return proc.returncode or 4
-    print(line, flush=True)
     return 0
+
+
+def agree_on_native_comm(dist, device, attach, detach, rank):
+    """Every rank tries to create the C-ABI RCCL communicator (`attach`); the MIN over ranks of the outcome decides for ALL of
+    them.  If any rank failed, every rank drops what it created (`detach`: ubd_comm_destroy, so that no rank issues collectives
+    inside ubd_train_step that the others never join) and the caller falls back to torch.distributed's all-reduce.
+    Returns True when the native communicator is in use on every rank."""
+    ok = 1
+    try:
+        attach()
+    except Exception as e:                               # noqa: BLE001 -- reported, then decided collectively
+        ok = 0
+        sys.stderr.write(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); torch.distributed all-reduce instead\n")
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        detach()
+        return False
+    return True
+
+
+def guarded_dp_leg(dist, line, leg, timeout_s):
+    """Runs the data-parallel train leg `leg()` (configs[3]) behind a watchdog.  The headline figures in `line` (rank 0; None
+    elsewhere) are complete before this is called and must not be lost to a stalled exchange: if the leg has not finished
+    within `timeout_s` on a rank, that rank prints the line with the reason in `train_step` (rank 0) and leaves with exit code
+    6 WITHOUT the (possibly stuck) teardown.  Exactly one of the watchdog and the main path prints.  Returns the exit code of
+    the normal path: 0, or 6 when the leg raised."""
+    import threading
+    final = threading.Lock()                             # whoever takes it first prints; never both
+
+    def give_up():
+        if not final.acquire(blocking=False):
+            return                                       # the main path is already printing the complete line
+        if line is not None:
+            out_line = dict(line)
+            out_line["train_step"] = {"error": f"data-parallel train leg did not finish within {timeout_s:.0f} s; skipped"}
+            print(json.dumps(out_line), flush=True)
+        os._exit(6)                                      # the headline line is out; the run as a whole did NOT succeed
+
+    dog = threading.Timer(timeout_s, give_up)
+    dog.daemon = True
+    dog.start()
+    failed = 0
+    try:
+        res = leg()
+    except Exception as e:                               # noqa: BLE001 -- reported in the JSON line
+        res = {"error": f"data-parallel train leg failed: {e}"}
+        failed = 1
+    dist.barrier()                                       # still under the watchdog: a rank that failed leaves the others in a collective
+    if not final.acquire(blocking=False):
+        time.sleep(3600)                                 # the watchdog fired a moment ago: it prints and ends the process
+    dog.cancel()
+    if line is not None:
+        line["train_step"] = res
+        print(json.dumps(line), flush=True)
+    return 6 if failed else 0
 
 
 def dry_run(args, world, rank):
@@ -247,12 +303,46 @@ def dry_run(args, world, rank):
     g = torch.full((8,), float(rank + 1))
     dist.all_reduce(g)                                            # stands for the flat-gradient all-reduce
     ok = n_ranks == args.gpus and float(g[0]) == world * (world + 1) / 2
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": "images/sec (512x512) fwd+CCL", "value": round(world * BATCH * args.steps / float(t), 1), "unit": "images/s",
-                          "n_gpus": world, "n_ranks_rccl": n_ranks, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(t) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "DRY RUN on CPU/gloo: launch + collective plumbing only, no GPU work"}}), flush=True)
+        line = {"metric": "images/sec (512x512) fwd+CCL", "value": round(world * BATCH * args.steps / float(t), 1), "unit": "images/s",
+                "n_gpus": world, "n_ranks_rccl": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(float(t) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                "config": {"workload": "DRY RUN on CPU/gloo: launch + collective plumbing only, no GPU work"}}
+    if world > 1:
+        # the N > 1 train leg's control flow with a stubbed trainer (UBD_BENCH_DRY_FAULT injects the failures it must survive):
+        #   attach_fail -- the last rank cannot create its native communicator: ALL ranks must drop theirs and fall back together
+        #   stall       -- the last rank never arrives: the watchdog prints the line with the reason and the run exits non-zero
+        #   leg_fail    -- the leg raises on the last rank: line printed with that rank's... rank 0's result, exit code non-zero there
+        fault = os.environ.get("UBD_BENCH_DRY_FAULT", "")
+        last = rank == world - 1
+        state = {"native": False}
+
+        def attach():
+            if fault == "attach_fail" and last:
+                raise RuntimeError("injected: no communicator on this rank")
+            state["native"] = True
+
+        def detach():
+            state["native"] = False
+
+        def leg():
+            native = agree_on_native_comm(dist, None, attach, detach, rank)
+            assert native == state["native"]             # a rank that attached but lost the vote has been detached
+            if fault == "stall" and last:
+                time.sleep(3600)
+            if fault == "leg_fail" and last:
+                raise RuntimeError("injected: train leg failed on this rank")
+            gg = torch.full((8,), float(rank + 1))
+            dist.all_reduce(gg)                          # the (stub) exchange step of every train step
+            return {"parallelism": "native communicator" if native else "torch.distributed fallback", "grad_sum": float(gg[0])}
+
+        rc = guarded_dp_leg(dist, line, leg, float(os.environ.get("UBD_BENCH_TRAIN_TIMEOUT_S", "240")))
+        dist.destroy_process_group()
+        return rc if ok else 5
+    if line is not None:
+        print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 5
@@ -369,20 +459,12 @@ def main():
             # the same path: a rank whose communicator cannot be created makes all of them fall back to torch.distributed's
             # all-reduce of the flat gradient vector (same arithmetic, one more launch) instead of losing the bench line.
             from ubdvss_amd import distributed as ubd_dist
-            ok = 1
-            try:
-                ubd_dist.attach_native_comm(tmodel, fused=True)
-            except Exception as e:                       # noqa: BLE001 -- reported in the JSON line
-                ok = 0
-                sys.stderr.write(f"[bench] rank {rank}: native RCCL communicator unavailable ({e}); torch.distributed all-reduce instead\n")
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                tmodel._native_comm = None
-                comm_kind = f"dp{world}: per-replica loss, flat-gradient all-reduce per step through torch.distributed (RCCL)"
-            else:
+            if agree_on_native_comm(dist, dev, lambda: ubd_dist.attach_native_comm(tmodel, fused=True),
+                                    lambda: ubd_dist.detach_native_comm(tmodel), rank):
                 comm_kind = (f"dp{world}: per-replica loss, flat-gradient all-reduce per step through the C-ABI RCCL communicator, "
                              f"fused into the train step under the stem backward")
+            else:
+                comm_kind = f"dp{world}: per-replica loss, flat-gradient all-reduce per step through torch.distributed (RCCL)"
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
@@ -432,12 +514,16 @@ def main():
             m5.predict_on_device(x5)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps5
-        bytes_img = side5 * side5 * C_IN * 4.0 + side5 * side5 * 45.0 * 2.0 + (side5 // 4) ** 2 * 4.0   # fp32 image in, fp16 activations (SURVEY 8(d) element count), fp32 logits out
+        # E_fwd = H W (C_in + 45 + K/16) elements of 2 bytes = 100.79 MB per image -- the figure `frac` is quoted on.
+        # The image is FED as fp32 here (12.6 MB instead of 6.3 MB per image): the bytes actually moved are given beside it.
+        bytes_img = side5 * side5 * (C_IN + 45 + 1 / 16.0) * 2.0
+        bytes_img_fed = side5 * side5 * C_IN * 4.0 + side5 * side5 * 45.0 * 2.0 + (side5 // 4) ** 2 * 4.0
         res = {"workload": "configs[4]: batch=8 1024x1024x3 fp16 forward, dilations {1,2,4,8,16,1}", "ms_per_batch": round(ms, 4),
                "images_per_s": round(n5 / ms * 1e3, 1), "dtype": "f16",
                "roofline": {"bound": "hbm", "achieved": round(n5 * bytes_img / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s",
                             "frac": round(n5 * bytes_img / (ms * 1e-3) / 1e9 / PEAK_HBM, 4),
-                            "note": "algorithmic bytes: fp32 image read + every 16-bit activation written once and read once + fp32 logits"}}
+                            "note": "algorithmic bytes per SURVEY 8(d): 100.79 MB per image (every element 2 bytes)",
+                            "frac_with_fp32_image_and_logits_as_fed": round(n5 * bytes_img_fed / (ms * 1e-3) / 1e9 / PEAK_HBM, 4)}}
         del m5, x5
         torch.cuda.empty_cache()
         return res
@@ -521,9 +607,28 @@ def main():
             traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / 1e6, 1)     # MB per launch
         except Exception:
             traffic = None
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary (full-size launches only: the
+        # batch-1 latency leg launches it on 1 x 128 x 128 maps for a few microseconds)
+        profile_avg_us, profile_file = None, None
+        for cand in ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
+            try:
+                import csv
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    for row in csv.DictReader(f):
+                        if row["Name"].startswith("void dilconv_wino_kernel<0"):
+                            profile_avg_us = round(float(row["AverageNs"]) / 1e3, 2)
+                            if "FullSizeAverageNs" in row and row["FullSizeAverageNs"]:
+                                profile_avg_us = round(float(row["FullSizeAverageNs"]) / 1e3, 2)
+                            profile_file = "profiles/" + cand
+                            break
+            except (OSError, KeyError, ValueError):
+                continue
+            if profile_avg_us is not None:
+                break
         roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
                     "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r02_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
+                    "profile_avg_us": profile_avg_us, "profile_file": profile_file,
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
                     "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
         fwd_hbm = {"bound": "hbm", "achieved": round(BATCH * BYTES_PER_IMAGE_FP32 / (net_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM,
@@ -558,28 +663,10 @@ def main():
         # configs[3].  The headline number above must not depend on this leg: if the multi-rank exchange stalls (it cannot be
         # exercised before the run on a one-GPU development box), every rank gives up after TRAIN_DP_TIMEOUT_S, rank 0 prints the
         # line with the reason in place of the train figures, and the processes leave without the (possibly stuck) teardown.
-        import threading
         TRAIN_DP_TIMEOUT_S = float(os.environ.get("UBD_BENCH_TRAIN_TIMEOUT_S", "240"))
-
-        def give_up():
-            if line is not None:
-                if line.get("train_step") is None:
-                    line["train_step"] = {"error": f"data-parallel train leg did not finish within {TRAIN_DP_TIMEOUT_S:.0f} s; skipped"}
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(TRAIN_DP_TIMEOUT_S, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            tr_res = time_train("bfloat16")
-        except Exception as e:                           # noqa: BLE001 -- reported in the JSON line
-            tr_res = {"error": f"data-parallel train leg failed: {e}"}
-        if line is not None:
-            line["train_step"] = tr_res
-        dist.barrier()                                   # still under the watchdog: a rank that failed leaves the others in a collective
-        dog.cancel()
+        rc = guarded_dp_leg(dist, line, lambda: time_train("bfloat16"), TRAIN_DP_TIMEOUT_S)
         dist.destroy_process_group()
+        return rc
     elif dist is not None:
         dist.barrier()
         dist.destroy_process_group()

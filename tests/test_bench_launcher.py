@@ -39,3 +39,32 @@ def test_more_ranks_than_gpus_fails_loudly():
 def test_launcher_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def _line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-400:], r.stderr[-800:])    # printed exactly once, by exactly one of watchdog / main path
+    return json.loads(lines[0])
+
+
+def test_train_leg_control_flow_two_ranks():
+    """The data-parallel train leg's control flow (bench.guarded_dp_leg / agree_on_native_comm) under gloo with a stubbed
+    trainer: all good; one rank without a native communicator -> every rank falls back together; one rank stalls -> the
+    watchdog prints the headline line with the reason and the run exits NON-zero; the leg raises on one rank -> non-zero."""
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-800:]
+    assert _line(r)["train_step"] == {"parallelism": "native communicator", "grad_sum": 3.0}
+
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], {"UBD_BENCH_DRY_FAULT": "attach_fail"})
+    assert r.returncode == 0, r.stderr[-800:]
+    assert _line(r)["train_step"] == {"parallelism": "torch.distributed fallback", "grad_sum": 3.0}
+    assert "native RCCL communicator unavailable" in r.stderr
+
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], {"UBD_BENCH_DRY_FAULT": "stall", "UBD_BENCH_TRAIN_TIMEOUT_S": "4"})
+    assert r.returncode != 0
+    d = _line(r)
+    assert "did not finish within 4 s" in d["train_step"]["error"] and d["value"] > 0       # the headline figures survived
+
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], {"UBD_BENCH_DRY_FAULT": "leg_fail", "UBD_BENCH_TRAIN_TIMEOUT_S": "6"})
+    assert r.returncode != 0
+    assert "train_step" in _line(r)

@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libubd_hip.so")
+# UBD_LIB_PATH: another build of the same library (diagnostic builds of tools/: stamps, the racy-flatten proof); never a fallback
+LIB_PATH = os.environ.get("UBD_LIB_PATH") or os.path.join(_HERE, "libubd_hip.so")
 
 UBD_F32, UBD_BF16, UBD_F16 = 0, 1, 2
 UBD_IN_F32, UBD_IN_U8 = 0, 1

@@ -9,8 +9,8 @@
 // 33 028 floats, complete once the dilated layers' backward is done) goes out on the communication stream UNDER the
 // backward pass of the three stem layers (0.5 ms of the 1.6 ms bf16 step); the 1 755 stem floats follow on the caller's
 // stream, which then waits for the first part.
-// librccl is resolved with dlopen at ubd_comm_init time (the copy already mapped by the process -- torch's -- wins), so the
-// library has no link-time dependency on it and loads on hosts without RCCL / without a GPU.
+// librccl is resolved with dlopen at ubd_comm_init time (the copy already mapped by the process -- torch's -- wins; UBD_RCCL_LIB
+// names another one), so the library has no link-time dependency on it and loads on hosts without RCCL / without a GPU.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <rccl/rccl.h>
@@ -31,6 +31,11 @@ struct ubd_comm {
 
 static void *open_rccl()
 {
+    // UBD_RCCL_LIB: the collective library to use instead of the process's librccl -- a site's own RCCL build, or the in-process
+    // loopback stand-in the tests use to run N ranks as N threads on one GPU (tests/loopback/)
+    if (const char *over = getenv("UBD_RCCL_LIB")) {
+        if (over[0]) return dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    }
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
         void *l = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);          // a copy the process has already mapped (torch's) first

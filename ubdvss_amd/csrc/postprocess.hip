@@ -941,7 +941,11 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     // stale non-root there -- the round-2 wrong-quad defect.)  Any value a concurrent reader sees in lab[x] is an ancestor
     // of x or its root, so the walks stay correct while the stores land.
     for (int node = tid; node <= hw; node += PP_LDS_THREADS) {
+#ifdef UBD_PP_RACY_FLATTEN   // diagnostic build only (tools/prove_stress_power.sh): round 2's compressing find, to show that the stress test catches it
+        const int r = uf_find_wg(lab, node);
+#else
         const int r = uf_find_ro_wg(lab, node);
+#endif
         __hip_atomic_store(&lab[node], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // the owner / root-slot arrays were the union job queue until the barrier above: no entry is valid yet.  -1 = "no slot", so

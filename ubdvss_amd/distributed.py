@@ -98,6 +98,19 @@ def attach_native_comm(model, fused=True, group=None, global_loss=False):
     return w
 
 
+def detach_native_comm(model):
+    """Undoes attach_native_comm on this rank: destroys the handle's communicator (ubd_comm_destroy; harmless when there is
+    none) so that ubd_train_step issues no collective of its own, and clears the Python-side markers.  When one rank failed to
+    create its communicator EVERY rank must call this before falling back to torch.distributed's all-reduce -- otherwise the
+    ranks that succeeded would block in RCCL calls the others never join (or sum the gradients twice)."""
+    from . import _lib
+    lib = _lib.load()
+    with torch.cuda.device(model.device):
+        _lib.check(lib.ubd_comm_destroy(model._h), "ubd_comm_destroy")
+    model._native_comm = None
+    model._global_loss = False
+
+
 def max_over_ranks(value, device=None, group=None):
     """max of a python float over all ranks (bench timing contract)."""
     if world_size(group) == 1:
