@@ -111,9 +111,14 @@ def test_two_ranks_per_replica_loss(loopback, dtype, fused):
         torch.cuda.current_stream().synchronize()
         return g, loss, m.params.clone()
     outs = _ranks(world, body)
+    assert torch.equal(outs[0][0], outs[1][0])                   # one all-reduce result on both ranks, bit for bit
     for r in range(world):
-        assert torch.equal(outs[r][0], want), (r, float((outs[r][0] - want).abs().max()))
-        assert torch.equal(outs[r][1], alone[r][1])              # per-replica loss: each rank's own
+        if dtype == "bfloat16":                                  # fixed-order reductions: the shard gradients repeat bit for bit
+            assert torch.equal(outs[r][0], want), (r, float((outs[r][0] - want).abs().max()))
+            assert torch.equal(outs[r][1], alone[r][1])          # per-replica loss: each rank's own
+        else:                                                    # fp32 weight gradients are summed with float atomics: run-to-run rounding
+            assert torch.allclose(outs[r][0], want, rtol=1e-4, atol=1e-7)
+            assert torch.allclose(outs[r][1], alone[r][1], rtol=1e-5)
     assert torch.equal(outs[0][2], outs[1][2])                   # same update everywhere
     if fused:
         ref = Trainer(Model(cfg, dtype=dtype, seed=3), Adam(lr=1e-3))
@@ -123,7 +128,10 @@ def test_two_ranks_per_replica_loss(loopback, dtype, fused):
         _lib.check(_lib.load().ubd_adam_step(ref.model.params.data_ptr(), ref.grads.data_ptr(), ref.m.data_ptr(), ref.v.data_ptr(),
                                              ref.grads.numel(), 1, o.lr, o.beta_1, o.beta_2, o.epsilon, 0.5, ref.model._stream()), "adam")
         torch.cuda.synchronize()
-        assert torch.equal(outs[0][2], ref.model.params)
+        if dtype == "bfloat16":
+            assert torch.equal(outs[0][2], ref.model.params)
+        else:
+            assert torch.allclose(outs[0][2], ref.model.params, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("n_cls", [0, 3])
