@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     from ubdvss_amd import _lib
     _lib.LIB_PATH = os.path.join(ROOT, "ubdvss_amd", sys.argv[2])
-    from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
+    from ubdvss_amd import NetConfig, Model, ModelRunner, Trainer, Adam, synthetic
     torch.cuda.set_device(0)
     def timed(fn, reps):
         for _ in range(20): fn()
@@ -26,11 +26,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     x5 = torch.from_numpy(synthetic.noise_images(7, 8, 1024, 1024, 3)).cuda()
     mf = Model(NetConfig(grey=False), seed=1)
     xf = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
-    out = {"train_ms": [], "cfg5_ms": [], "fwd32_ms": []}
+    labs = synthetic.rectangle_maps(3, 32, 128, 128)
+    xs = torch.from_numpy(synthetic.textured_images(4, labs, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    runner = ModelRunner(NetConfig(grey=False), max_objects_per_image=1024, pipelined=True)
+    out = {"train_ms": [], "cfg5_ms": [], "fwd32_ms": [], "step_ms": []}
     for _ in range(3):
         out["train_ms"].append(round(timed(lambda: tr.train_step_on_device(x, y), 100), 4))
         out["cfg5_ms"].append(round(timed(lambda: m5.predict_on_device(x5), 200), 4))
         out["fwd32_ms"].append(round(timed(lambda: mf.predict_on_device(xf), 200), 4))
+        out["step_ms"].append(round(timed(lambda: runner.predict_on_device(mf, xs), 300), 4))
     print(json.dumps(out))
 else:
     for rep in range(2):

@@ -80,6 +80,11 @@ __device__ __forceinline__ void ubd_blds4(__amdgpu_buffer_rsrc_t rsrc, unsigned 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
+// ReLU of a matrix-pipe result in ONE instruction, with an optional zero mask: clamp(x, 0, cap), cap = +inf (keep) or 0 (the
+// position is padding: result 0).  fmaxf(x, 0) on an MFMA output costs two v_max (hipcc first canonicalises a value it
+// cannot prove quiet: v_max x, x) plus a v_cndmask for the mask; v_med3_f32 needs neither and returns the same value for
+// every non-NaN x (NaN -> 0, as fmaxf).
+__device__ __forceinline__ float ubd_relu_cap(float x, float cap) { return __builtin_amdgcn_fmed3f(x, 0.f, cap); }
 __device__ __forceinline__ unsigned ubd_lds_addr(const void *lds_generic)
 {
     return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_generic);

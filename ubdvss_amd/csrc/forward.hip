@@ -125,6 +125,29 @@ __device__ __forceinline__ void store_tile_relu_t(float *__restrict__ y, size_t 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs, (int)base1, 0, 0);
 }
 
+// same with the bias already in the accumulators (it rode in as the MFMA's C operand): ReLU in one instruction per value
+__device__ __forceinline__ void store_tile_relu_nb(float *__restrict__ y, size_t row_base_elems, int x0, int ow,
+                                                   int lane, f32x4 acc0, f32x4 acc1)
+{
+    const int i = lane & 15, q = lane >> 4;
+    const unsigned long long rp = (unsigned long long)(y + (row_base_elems + (size_t)x0) * UBD_C);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rp);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rp >> 32));
+    float *rowp = (float *)(((unsigned long long)rhi << 32) | rlo);
+    int npx = ow - x0 < 16 ? ow - x0 : 16;
+    npx = npx < 0 ? 0 : npx;
+    const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, (int)bytes, 0x00020000);
+    const unsigned base = (unsigned)i * (UBD_C * 4u) + 16u * (unsigned)q;
+    const unsigned base1 = q < 2 ? base + 64u : 0x40000000u;
+    const float cap = __builtin_inff();
+    f32x4 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o0[r] = ubd_relu_cap(acc0[r], cap); o1[r] = ubd_relu_cap(acc1[r], cap); }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs, (int)base, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs, (int)base1, 0, 0);
+}
+
 // Backward epilogue: no bias; multiply by the ReLU mask of the layer below (its saved output > 0).
 __device__ __forceinline__ void store_tile_masked(float *__restrict__ y, const float (&mk)[8],
                                                   size_t row_base_elems, int x0, int ow, int lane, f32x4 acc0, f32x4 acc1)
@@ -785,7 +808,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #define S123_STAMP_ARG
 #endif
 #define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket S123_STAMP_ARG)
-        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 31);   // fp32 fed as it is: LDS-DMA path
+        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30);   // fp32 fed as it is: LDS-DMA path (offsets of one image in 30 bits)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
 #undef UBD_LAUNCH_S123

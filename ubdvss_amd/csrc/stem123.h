@@ -26,8 +26,9 @@ template <int CIN> struct s123_cfg {
     static constexpr int XH = 2 * B::PH + 1, XW = 2 * AC + 1;      // input patch 23 x 69
     static constexpr int XE = XH * XW * CIN;                       // elements
     static constexpr int XREGS = (XE + NT - 1) / NT;
-    static constexpr int XPIECES = (XE + 63) / 64;                 // PLAIN: 256-byte LDS-DMA pieces of the patch
-    static constexpr int XP_FLOATS = XPIECES * 64;                 // whole pieces (the last one runs past the patch)
+    static constexpr int PPR = (XW * CIN + 63) / 64;               // PLAIN: 256-byte LDS-DMA pieces per patch row (the last one partial)
+    static constexpr int XPIECES = XH * PPR;
+    static constexpr int XP_FLOATS = (XE + 63) / 64 * 64;
     static constexpr int A1_FLOATS = B::PH * B::PW * UBD_C;        // a1 patch, stem23's layout
     static constexpr int NPIX = B::PH * AC;                        // 374 L1 outputs per tile
     static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
@@ -167,19 +168,35 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     };
 
     const unsigned lds_xp = ubd_lds_addr(xp);
-    auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, 256 bytes per piece
+    auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, one patch row = PPR pieces of <= 256 bytes
         const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)p.img * H * WC * 4), 0,
                                                                         (int)((unsigned)H * WC * 4u), 0x00020000);
+        // Pieces never cross a patch row, so a piece's source offset is a wave-uniform term (row, tile column, piece) plus
+        // 4 * lane: ONE vector add per piece (the flat 64-element pieces of the first version needed a division by the row
+        // length and a range check per lane and piece: 70 vector instructions per wave and tile).  Rows above / below the
+        // image fall out of the descriptor's range by themselves (a negative term wraps); only tiles that touch the left /
+        // right image border (block-uniform) check their columns per lane.
+        // The block's 8 waves walk the pieces in order, and 8 is a multiple of the pieces per row: a wave always fetches the
+        // same piece j of a row and steps RSTEP rows at a time -- term and LDS destination advance by constants, the column
+        // check (x-border tiles only) is the same for every one of the wave's pieces.
+        static_assert(C::NW % X::PPR == 0, "pieces per patch row must divide the wave count");
+        constexpr int RSTEP = C::NW / X::PPR;
+        const int j = wid % X::PPR, row0 = wid / X::PPR;                             // wave-uniform
+        const int lanes = j + 1 < X::PPR ? 64 : RWF - (X::PPR - 1) * 64;             // the row's last piece is partial: lanes past the row write nothing
+        const bool xin_range = fx0 >= 0 && fx0 + RWF <= WC;                          // block-uniform
+        unsigned off0 = (unsigned)lane * 4u;
+        if (!xin_range) off0 = (unsigned)(fx0 + j * 64 + lane) < (unsigned)WC ? off0 : 0x80000000u;   // image bytes < 2^30 (host): stays out of range with any term
+        int term = ((iy0 + row0) * WC + fx0 + j * 64) * 4;
+        unsigned dst = lds_xp + (unsigned)((row0 * RWF + j * 64) * 4);
+        if (lane < lanes) {
 #pragma unroll
-        for (int k = 0; k < (X::XPIECES + C::NW - 1) / C::NW; ++k) {
-            const int piece = k * C::NW + wid;
-            if (piece >= X::XPIECES) break;                                          // wave-uniform
-            const unsigned e = (unsigned)(piece * 64 + lane);                        // row-major [23][69 * C_in]; the last piece runs into row 23 (never read)
-            const unsigned row = e / (unsigned)RWF, col = e - row * (unsigned)RWF;
-            const int gy = iy0 + (int)row, gf = fx0 + (int)col;
-            const unsigned off = (unsigned)gf < (unsigned)WC ? (unsigned)((gy * WC + gf) * 4) : 0x80000000u;   // rows outside fall out of range by themselves
-            ubd_blds4(rsrc, off, lds_xp + piece * 256);
+            for (int k = 0; k < (X::XH + RSTEP - 1) / RSTEP; ++k) {
+                if (row0 + k * RSTEP >= X::XH) break;                                // wave-uniform
+                ubd_blds4(rsrc, (unsigned)term + off0, dst);
+                term += RSTEP * WC * 4;
+                dst += (unsigned)(RSTEP * RWF * 4);
+            }
         }
     };
 
@@ -263,12 +280,12 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd + (ky * X::XW + kx) * CIN], dwk1[ky * 3 + kx], dv);
             f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv, b1A, 0, 0, 0);
             f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv, b1B, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.f); acc1[r] = fmaxf(acc1[r], 0.f); }
             const int rc = u_rc[k];
             const int ar = rc >> 8, ac = rc & 255;
             const bool inside = rc >= 0 && (unsigned)(A0y + ar) < (unsigned)H2 && (unsigned)(A0x + ac) < (unsigned)W2;
-            if (!inside) { acc0 = z4; acc1 = z4; }                                   // L2's zero padding
+            const float cap = inside ? __builtin_inff() : 0.f;                       // outside L1's map: L2's zero padding
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[r] = ubd_relu_cap(acc0[r], cap); acc1[r] = ubd_relu_cap(acc1[r], cap); }
             if (rc >= 0) {
                 const int rot0 = 3 * ((ac >> 3) & 1);
                 int s4 = q + rot0;
@@ -353,12 +370,13 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf2[s][0], dwv[o][s], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf2[s][1], dwv[o][s], acc1, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r], 0.f); acc1[r] = fmaxf(acc1[r], 0.f); }
+                        float cap = __builtin_inff();
                         if (mask_needed) {
                             const bool ok = (unsigned)(C0 + pos) < (unsigned)W2 && (unsigned)(R0 + rb + o) < (unsigned)H2;
-                            if (!ok) { acc0 = z4; acc1 = z4; }                       // L3's zero padding
+                            cap = ok ? cap : 0.f;                                    // L3's zero padding
                         }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { acc0[r] = ubd_relu_cap(acc0[r], cap); acc1[r] = ubd_relu_cap(acc1[r], cap); }
                         float *dst = l2 + l2w + o * (C::LC * C::LP);
                         *(f32x4 *)dst = acc0;
                         if (q < 2) *(f32x4 *)(dst + 16) = acc1;
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa0[s] : pb0[s - 4], dv[s], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa1[s] : pb1[s - 4], dv[s], acc1, 0, 0, 0);
             }
-            store_tile_relu_t(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1, z4, z4);   // bias already in
+            store_tile_relu_nb(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1);          // bias already in
         }
         S123_STAMP(5);
         if (!has_next) break;
