@@ -26,15 +26,19 @@ template <int CIN> struct s123_cfg {
     static constexpr int XH = 2 * B::PH + 1, XW = 2 * AC + 1;      // input patch 23 x 69
     static constexpr int XE = XH * XW * CIN;                       // elements
     static constexpr int XREGS = (XE + NT - 1) / NT;
-    static constexpr int PPR = (XW * CIN + 63) / 64;               // PLAIN: 256-byte LDS-DMA pieces per patch row (the last one partial)
-    static constexpr int XPIECES = XH * PPR;
-    static constexpr int XP_FLOATS = (XE + 63) / 64 * 64;
+    // LDS image of the patch: one more pixel column on the left (image column 64 tx - 4) makes every patch row start on a
+    // 16-byte boundary of the image row (H, W multiples of 4), so a row is ONE 16-byte LDS-DMA piece of XCH lanes; rows are XS
+    // floats apart (a whole number of 16-byte chunks).  The 23 x 69 patch proper sits at columns 1 .. 69.
+    static constexpr int XCH = ((XW + 1) * CIN + 3) / 4;           // 16-byte chunks per row: 53 (RGB) / 18 (grey)
+    static constexpr int XS = XCH * 4;                             // row pitch in floats
+    static constexpr int XP_FLOATS = XH * XS;
     static constexpr int A1_FLOATS = B::PH * B::PW * UBD_C;        // a1 patch, stem23's layout
     static constexpr int NPIX = B::PH * AC;                        // 374 L1 outputs per tile
     static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
     static constexpr int UPW = (UNITS + NW - 1) / NW;              // units per wave
     static constexpr int W1_FLOATS = 64 * 12 + 64 + 4;              // L1 per-lane weights (9 depthwise taps, 2 pointwise, pad) + biases of L1 / L3 (2 x 32) + the ring of strip ids
     static constexpr int SMEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
+    static_assert(XCH <= 64 && (A1_FLOATS % 4) == 0 && (B::L2_FLOATS % 4) == 0, "patch rows are single 16-byte-aligned DMA pieces");
 };
 
 // PLAIN: fp32 input that is fed as it is (no preprocessing): the patch goes straight from memory into LDS by 4-byte LDS-DMA through a
@@ -168,34 +172,24 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     };
 
     const unsigned lds_xp = ubd_lds_addr(xp);
-    auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, one patch row = PPR pieces of <= 256 bytes
-        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+    auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, one 16-byte LDS-DMA piece per patch row
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 4) * CIN, WC = W * CIN;   // one column left of the patch: 16-byte aligned
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)p.img * H * WC * 4), 0,
                                                                         (int)((unsigned)H * WC * 4u), 0x00020000);
-        // Pieces never cross a patch row, so a piece's source offset is a wave-uniform term (row, tile column, piece) plus
-        // 4 * lane: ONE vector add per piece (the flat 64-element pieces of the first version needed a division by the row
-        // length and a range check per lane and piece: 70 vector instructions per wave and tile).  Rows above / below the
-        // image fall out of the descriptor's range by themselves (a negative term wraps); only tiles that touch the left /
-        // right image border (block-uniform) check their columns per lane.
-        // The block's 8 waves walk the pieces in order, and 8 is a multiple of the pieces per row: a wave always fetches the
-        // same piece j of a row and steps RSTEP rows at a time -- term and LDS destination advance by constants, the column
-        // check (x-border tiles only) is the same for every one of the wave's pieces.
-        static_assert(C::NW % X::PPR == 0, "pieces per patch row must divide the wave count");
-        constexpr int RSTEP = C::NW / X::PPR;
-        const int j = wid % X::PPR, row0 = wid / X::PPR;                             // wave-uniform
-        const int lanes = j + 1 < X::PPR ? 64 : RWF - (X::PPR - 1) * 64;             // the row's last piece is partial: lanes past the row write nothing
-        const bool xin_range = fx0 >= 0 && fx0 + RWF <= WC;                          // block-uniform
-        unsigned off0 = (unsigned)lane * 4u;
-        if (!xin_range) off0 = (unsigned)(fx0 + j * 64 + lane) < (unsigned)WC ? off0 : 0x80000000u;   // image bytes < 2^30 (host): stays out of range with any term
-        int term = ((iy0 + row0) * WC + fx0 + j * 64) * 4;
-        unsigned dst = lds_xp + (unsigned)((row0 * RWF + j * 64) * 4);
-        if (lane < lanes) {
+        // Row r of the patch = XCH chunks of 16 bytes from image row iy0 + r: a wave-uniform term plus 16 * lane.  Rows above /
+        // below the image fall out of the descriptor's range by themselves (a negative term wraps); chunks left / right of
+        // the image (they never straddle its border: W is a multiple of 4) get an out-of-range offset -- zeros in LDS either
+        // way = L1's zero padding.  23 pieces per tile (the first version moved 4 bytes per lane: 75 flat pieces with a
+        // division and a range check per lane; in-kernel stamps: 1.3 k of the tile's 9.7 k cycles went into issuing them).
+        unsigned off0 = (unsigned)lane * 16u;
+        off0 = (unsigned)(fx0 + 4 * lane) < (unsigned)WC ? off0 : 0x80000000u;      // image bytes < 2^30 (host): out of range with any row term
+        if (lane < X::XCH) {
 #pragma unroll
-            for (int k = 0; k < (X::XH + RSTEP - 1) / RSTEP; ++k) {
-                if (row0 + k * RSTEP >= X::XH) break;                                // wave-uniform
-                ubd_blds4(rsrc, (unsigned)term + off0, dst);
-                term += RSTEP * WC * 4;
-                dst += (unsigned)(RSTEP * RWF * 4);
+            for (int k = 0; k < (X::XH + C::NW - 1) / C::NW; ++k) {
+                const int row = k * C::NW + wid;
+                if (row >= X::XH) break;                                             // wave-uniform
+                const int term = ((iy0 + row) * WC + fx0) * 4;
+                ubd_blds16(rsrc, (unsigned)term + off0, lds_xp + (unsigned)(row * X::XS * 4));
             }
         }
     };
@@ -248,13 +242,17 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     auto convert_x = [&](tpos p) {
         const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;              // already preprocessed fp32 input: a copy
         if (!tile_interior(p)) fix_border(p);                                        // block-uniform
+        int pr = e0_row, pcf = e0_col;
 #pragma unroll
         for (int k = 0; k < X::XREGS; ++k) {
             const int e = k * C::NT + (int)threadIdx.x;
             if (e < X::XE) {
-                if constexpr (IN_U8) xp[e] = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
-                else xp[e] = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
+                float *dst = xp + pr * X::XS + CIN + pcf;                            // the LDS image keeps one unused pixel column on the left (dma_x)
+                if constexpr (IN_U8) *dst = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
+                else *dst = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
             }
+            pr += C::NT / RWF; pcf += C::NT % RWF;
+            if (pcf >= RWF) { pcf -= RWF; ++pr; }
         }
     };
     // ---- phase 0b of tile p: L1 -> a1 patch image
@@ -272,12 +270,12 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             if (wid < 4 && k >= 2) continue;                                         // wave-uniform: waves 0-3 own two units
             const int rc0 = u_rc[k] < 0 ? 1 : u_rc[k];                               // lanes without a pixel compute on pixel (0, 1) and store nothing
             const int ar0 = rc0 >> 8, ac0 = rc0 & 255;
-            const int u_rd = ((2 * ar0) * X::XW + 2 * (ac0 - 1)) * CIN + qc;
+            const int u_rd = (2 * ar0) * X::XS + (2 * (ac0 - 1) + 1) * CIN + qc;
             float dv = 0.f;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd + (ky * X::XW + kx) * CIN], dwk1[ky * 3 + kx], dv);
+                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd + ky * X::XS + kx * CIN], dwk1[ky * 3 + kx], dv);
             f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv, b1A, 0, 0, 0);
             f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv, b1B, 0, 0, 0);
             const int rc = u_rc[k];
