@@ -21,7 +21,7 @@ for _ in range(5): m.predict_on_device(x)
 torch.cuda.synchronize()
 lib.ubd_debug_set_stamps(None)
 s = st.cpu().numpy().astype(np.int64)
-names = ["0a patch->LDS + next loads", "barrier", "0b L1", "barrier", "A L2", "barrier", "B L3"]
+names = ["dma issue + carry", "A (L2)", "wait patch", "barrier", "B (L3, waves 0-3)", "0b (L1 next tile)", "barrier"]
 seg = np.diff(s[..., :8], axis=-1)              # (blk, wave, it, 7)
 its = slice(2, 14)
 print("cycles (s_memtime ticks = shader cycles), median over blocks x tiles 2..13, per wave:")

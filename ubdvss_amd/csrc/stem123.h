@@ -255,8 +255,22 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             if (pcf >= RWF) { pcf -= RWF; ++pr; }
         }
     };
-    // ---- phase 0b of tile p: L1 -> a1 patch image
-    auto phase0b = [&](tpos p) {
+    // ---- phase 0b of tile p: L1 -> a1 patch image.  A unit is a serial chain (nine LDS taps -> nine dependent FMAs -> two MFMAs
+    // -> clamp -> two LDS stores); run one after the other at two waves per SIMD the units cost ~800 cycles each, nearly all
+    // of it latency (in-kernel stamps).  So the stages are batched over the wave's units: all tap reads first (l1_taps), then
+    // the FMA chains side by side, the MFMAs back to back, the epilogues -- and the waves that also own an L3 row put that
+    // row between their tap reads and the rest (l1_finish), so the reads are long complete when they are consumed.
+    auto l1_taps = [&](int k, float (&tap)[9]) {
+        const int rc0 = u_rc[k] < 0 ? 1 : u_rc[k];                                   // lanes without a pixel compute on pixel (0, 1) and store nothing
+        const int ar0 = rc0 >> 8, ac0 = rc0 & 255;
+        const int u_rd = (2 * ar0) * X::XS + (2 * (ac0 - 1) + 1) * CIN + qc;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) tap[ky * 3 + kx] = xp[u_rd + ky * X::XS + kx * CIN];
+    };
+    auto l1_finish = [&](tpos p, auto nunits, auto &tap, int k0) {                  // units k0 .. k0 + NU - 1 of the wave
+        constexpr int NU = decltype(nunits)::value;
         const int A0y = 2 * p.ty * C::TH3 - 2, A0x = 32 * p.tx - 2;                  // a1 pixel of patch (0, 0)
         float dwk1[9], pwf1[2];
         {
@@ -265,38 +279,52 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             dwk1[8] = wc[0]; pwf1[0] = wc[1]; pwf1[1] = wc[2];
         }
         const f32x4 b1A = *(const f32x4 *)(bt + 4 * q), b1B = *(const f32x4 *)(bt + 16 + 4 * q);      // zeros beyond channel 23
+        float dv[NU];
 #pragma unroll
-        for (int k = 0; k < UPW; ++k) {
-            if (wid < 4 && k >= 2) continue;                                         // wave-uniform: waves 0-3 own two units
-            const int rc0 = u_rc[k] < 0 ? 1 : u_rc[k];                               // lanes without a pixel compute on pixel (0, 1) and store nothing
-            const int ar0 = rc0 >> 8, ac0 = rc0 & 255;
-            const int u_rd = (2 * ar0) * X::XS + (2 * (ac0 - 1) + 1) * CIN + qc;
-            float dv = 0.f;
+        for (int k = 0; k < NU; ++k) dv[k] = 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) dv = fmaf(xp[u_rd + ky * X::XS + kx * CIN], dwk1[ky * 3 + kx], dv);
-            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv, b1A, 0, 0, 0);
-            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv, b1B, 0, 0, 0);
-            const int rc = u_rc[k];
+            for (int k = 0; k < NU; ++k) dv[k] = fmaf(tap[k][t], dwk1[t], dv[k]);    // NU independent chains
+        f32x4 acc0[NU], acc1[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[0], dv[k], b1A, 0, 0, 0);
+            acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(pwf1[1], dv[k], b1B, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int rc = u_rc[k0 + k];
             const int ar = rc >> 8, ac = rc & 255;
             const bool inside = rc >= 0 && (unsigned)(A0y + ar) < (unsigned)H2 && (unsigned)(A0x + ac) < (unsigned)W2;
             const float cap = inside ? __builtin_inff() : 0.f;                       // outside L1's map: L2's zero padding
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { acc0[r] = ubd_relu_cap(acc0[r], cap); acc1[r] = ubd_relu_cap(acc1[r], cap); }
+            for (int r = 0; r < 4; ++r) { acc0[k][r] = ubd_relu_cap(acc0[k][r], cap); acc1[k][r] = ubd_relu_cap(acc1[k][r], cap); }
             if (rc >= 0) {
                 const int rot0 = 3 * ((ac >> 3) & 1);
                 int s4 = q + rot0;
                 s4 = s4 >= 6 ? s4 - 6 : s4;
                 float *dst = a1p + (ar * C::PW + ac) * UBD_C + 4 * s4;               // chunk q; chunk 4 + q (q < 2) sits 16 floats further, modulo the rotation
-                *(f32x4 *)dst = acc0;
+                *(f32x4 *)dst = acc0[k];
                 if (q < 2) {                                                         // chunk 4 + q: slot (4 + q + 3f) % 6
-                    const int rot = 3 * ((ac >> 3) & 1);
-                    int s1 = 4 + q + rot;
+                    int s1 = 4 + q + rot0;
                     s1 = s1 >= 6 ? s1 - 6 : s1;
-                    *(f32x4 *)(a1p + (ar * C::PW + ac) * UBD_C + 4 * s1) = acc1;
+                    *(f32x4 *)(a1p + (ar * C::PW + ac) * UBD_C + 4 * s1) = acc1[k];
                 }
             }
+        }
+    };
+    auto phase0b = [&](tpos p) {                                                     // the whole phase at once (first tile of a block)
+        if (wid < 4) {                                                               // wave-uniform: waves 0-3 own two units, waves 4-7 four
+            float tap[2][9];
+            l1_taps(0, tap[0]); l1_taps(1, tap[1]);
+            l1_finish(p, std::integral_constant<int, 2>{}, tap, 0);
+        } else {                                                                     // two pairs: four units' taps at once do not fit the register file
+            float tap[2][9];
+            l1_taps(0, tap[0]); l1_taps(1, tap[1]);
+            l1_finish(p, std::integral_constant<int, 2>{}, tap, 0);
+            l1_taps(2, tap[0]); l1_taps(3, tap[1]);
+            l1_finish(p, std::integral_constant<int, 2>{}, tap, 2);
         }
     };
 
@@ -396,7 +424,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         __syncthreads();                                                             // L2 tile and the next input patch are complete
         S123_STAMP(4);
 
-        // ---- phase B, waves 0-3: L3 output row oy0 + wid
+        // ---- phase B (waves 0-3: L3 output row oy0 + wid) beside phase 0b of the next tile (all waves)
         if (wid < 4) {
             const int oy = oy0 + wid;
             float dv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -423,10 +451,20 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa1[s] : pb1[s - 4], dv[s], acc1, 0, 0, 0);
             }
             store_tile_relu_nb(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1);          // bias already in
+            S123_STAMP(5);
+            if (!has_next) break;
+            float tap[2][9];
+            l1_taps(0, tap[0]); l1_taps(1, tap[1]);
+            l1_finish(nx1, std::integral_constant<int, 2>{}, tap, 0);
+        } else {
+            S123_STAMP(5);
+            if (!has_next) break;
+            float tap[2][9];
+            l1_taps(0, tap[0]); l1_taps(1, tap[1]);
+            l1_finish(nx1, std::integral_constant<int, 2>{}, tap, 0);
+            l1_taps(2, tap[0]); l1_taps(3, tap[1]);
+            l1_finish(nx1, std::integral_constant<int, 2>{}, tap, 2);
         }
-        S123_STAMP(5);
-        if (!has_next) break;
-        phase0b(nx1);
         S123_STAMP(6);
         if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;       // visible after the barrier below and the next tile's
         __syncthreads();                                                             // a1 patch of the next tile complete; phase B is over
