@@ -14,6 +14,75 @@ from . import _lib, utils
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 
+class _DeviceEvent:
+    """A HIP event created with hipEventDisableTiming | hipEventDisableSystemFence: recording it orders work between two
+    streams of THIS device without the system-scope cache write-back a default event carries (the forward stream goes straight
+    on with the next batch; nothing on the host reads what the event guards).  torch.cuda.Event cannot express the second
+    flag, so the runtime is called directly; same three operations the pipeline needs (record / wait on a stream / query)."""
+    _hip = None
+    _FLAGS = 0x2 | 0x20000000            # hipEventDisableTiming | hipEventDisableSystemFence
+
+    def __init__(self):
+        cls = type(self)
+        if cls._hip is None:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+            hip.hipEventQuery.argtypes = [ctypes.c_void_p]
+            hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+            hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+            cls._hip = hip
+        self._e = ctypes.c_void_p()
+        rc = cls._hip.hipEventCreateWithFlags(ctypes.byref(self._e), cls._FLAGS)
+        if rc != 0:
+            raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+
+    def record(self, stream):
+        rc = self._hip.hipEventRecord(self._e, ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed ({rc})")
+
+    def wait(self, stream):
+        rc = self._hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), self._e, 0)
+        if rc != 0:
+            raise RuntimeError(f"hipStreamWaitEvent failed ({rc})")
+
+    def query(self):
+        return self._hip.hipEventQuery(self._e) == 0
+
+    def synchronize(self):
+        rc = self._hip.hipEventSynchronize(self._e)
+        if rc != 0:
+            raise RuntimeError(f"hipEventSynchronize failed ({rc})")
+
+    def __del__(self):
+        e, self._e = getattr(self, "_e", None), None
+        if e and self._hip is not None:
+            self._hip.hipEventDestroy(e)
+
+
+class _TorchEvent:
+    """torch.cuda.Event (default flags: its record carries a system-scope release) behind the same calls.  Used for the
+    "results complete" event -- the HOST reads those results after waiting for it -- and, with UBD_PIPE_EVENTS=torch, for the
+    device-to-device one too (A/B of the event flavour)."""
+
+    def __init__(self):
+        self._e = torch.cuda.Event()
+
+    def record(self, stream):
+        self._e.record(stream)
+
+    def wait(self, stream):
+        stream.wait_event(self._e)
+
+    def query(self):
+        return self._e.query()
+
+    def synchronize(self):
+        self._e.synchronize()
+
+
 class ModelRunner:
     def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256, pipelined=False):
         """model_runner.py:31-38: pixel_probability > pixel_threshold is positive.
@@ -25,7 +94,8 @@ class ModelRunner:
         self._logit_threshold = - np.log(1 / np.clip(pixel_threshold, eps, 1 - eps) - 1)
         self._cap = max_objects_per_image
         self._pipelined = pipelined
-        self._stagger_us = int(os.environ.get("UBD_STAGGER_US", "3"))
+        self._stagger_us = int(os.environ.get("UBD_STAGGER_US", "0"))
+        self._event_cls = _TorchEvent if os.environ.get("UBD_PIPE_EVENTS", "hip") == "torch" else _DeviceEvent
         self._side = None
         self._slots = {}
         self._step = 0
@@ -60,24 +130,26 @@ class ModelRunner:
         slot = self._slots.get(key)
         if slot is None:
             slot = {"logits": torch.empty((n, hh // 4, ww // 4, model.k_out), dtype=torch.float32, device=model.device),
-                    "out": model.alloc_postprocess_outputs(n, hh // 4, ww // 4, self._cap), "done": None}
+                    "out": model.alloc_postprocess_outputs(n, hh // 4, ww // 4, self._cap), "done": None, "used": False,
+                    "fwd": self._event_cls()}               # logits ready: consumed by kernels of this device only
             self._slots[key] = slot
-        if slot["done"] is not None and not slot["done"].query():
-            main.wait_event(slot["done"])               # the previous postprocess of this slot still reads its logits
+        if slot["used"] and not slot["done"].query():
+            slot["done"].wait(main)                     # the previous postprocess of this slot still reads its logits
                                                         # (normally long finished: no barrier packet in the forward stream)
         if self.last_event is not None and self._stagger_us > 0:
             # the postprocess of the previous batch was enqueued on the side stream a moment ago: give its whole-CU blocks a
             # head start over the 16 384 small blocks of the first stem kernel (ubd_stream_delay, include/ubd.h)
             _lib.check(_lib.load().ubd_stream_delay(ctypes.c_void_p(main.cuda_stream), self._stagger_us), "ubd_stream_delay")
         logits = model.predict_on_device(images, out=slot["logits"])
-        fwd_done = torch.cuda.Event()
-        fwd_done.record(main)
-        self._side.wait_event(fwd_done)
+        slot["fwd"].record(main)                        # the slot's events are reused: its previous postprocess has been waited for above
+        slot["fwd"].wait(self._side)
+        if slot["done"] is None:
+            slot["done"] = _TorchEvent()                # results ready: the host reads them after this one
         with torch.cuda.stream(self._side):
             bmap, quads, classes, counts = model.postprocess_on_device(logits, self._logit_threshold, scale, min_area,
                                                                        cap=self._cap, outputs=slot["out"])
-            slot["done"] = torch.cuda.Event()
             slot["done"].record(self._side)
+        slot["used"] = True
         self.last_event = slot["done"]
         return logits, bmap, quads, classes, counts
 
