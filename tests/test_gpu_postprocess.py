@@ -14,14 +14,18 @@ from ubdvss_amd import NetConfig, Model, ModelRunner, SegmapManager, synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["lds", "global"], autouse=True)
+@pytest.fixture(params=["lds", "lds_split", "global"], autouse=True)
 def front_end(request, monkeypatch):
-    """Every case runs through both front ends: the one-launch LDS kernel (maps of <= 16384 pixels) and the multi-launch
-    global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    """Every case runs through every code path: "lds" = the whole postprocess of a batch as ONE launch (maps of <= 16384
+    pixels: front end, boxes, class vote and emit in one block per image), "lds_split" = the one-launch front end followed by
+    the separate boxes / vote / emit kernels (UBD_PP_SPLIT; what maps too tall for the in-block box scratch take), "global" =
+    the multi-launch global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
+    monkeypatch.delenv("UBD_PP_SPLIT", raising=False)
     if request.param == "global":
         monkeypatch.setenv("UBD_PP_GLOBAL", "1")
-    else:
-        monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
+    elif request.param == "lds_split":
+        monkeypatch.setenv("UBD_PP_SPLIT", "1")
     return request.param
 
 
@@ -258,7 +262,7 @@ def test_postprocess_stress_deterministic(golden_dir, front_end, mode, monkeypat
     CUs, LDS contents of earlier blocks differ).  `poison`: the one-launch front end starts from poisoned LDS and checks that the
     forest is flat and every slot it reads was written (an integrity failure makes counts impossible)."""
     if mode == "poison":
-        if front_end == "global":
+        if front_end != "lds":
             pytest.skip("the poison hook belongs to the one-launch LDS front end")
         monkeypatch.setenv("UBD_PP_POISON", "1")
     model = _model(0)

@@ -593,6 +593,85 @@ __device__ __forceinline__ void hull_finish(ipt *P, int nl, int nr, int &n_out)
     n_out = n;
 }
 
+// One wave, one kept object: row extents (global, 2 ints per row from row y0) -> hull -> minAreaRect -> boxPoints -> rounded quad
+// into st[1..8].  rws: the wave's LDS scratch of 12 * h + 4 ints (row extents | hull points | edge table).  ATOMIC: the
+// extents were accumulated by atomics of THIS launch (the fused one-launch front end): read them past the CU's vector L1.
+template <bool ATOMIC>
+__device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ g, int nrows, int y0, int h, int lane, int scale,
+                                              int *__restrict__ st)
+{
+    ipt *pts = (ipt *)(rws + 2 * h);
+    float *etab = (float *)(rws + 6 * h);                   // edge table of the hull: 3 x (<= 2h) floats
+    for (int r = lane; r < 2 * nrows; r += 64)
+        rws[r] = ATOMIC ? __hip_atomic_load(&g[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int cnt[2] = {0, 0};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {            // 0: left chain (min x), 1: right chain (max x)
+        // Gift wrapping down the chain: from vertex row c the next vertex is the later row with the
+        // extreme slope dx/dy (min for the left chain, max for the right one; farthest on ties, which
+        // drops collinear points).  Candidates are spread over the 64 lanes, fractions compared
+        // exactly by int32 cross-multiplication (|dx|, dy < 2^15), then a xor-butterfly reduction.
+        ipt *out = pts + (side ? cnt[0] : 0);
+        int nout = 0, c = 0;
+        for (;;) {
+            const int xc = rws[2 * c + side];
+            if (lane == 0) out[nout] = (ipt){xc, y0 + c};
+            ++nout;
+            if (c >= nrows - 1) break;
+            int bn = 0, bd = 0, br = -1;
+            for (int r = c + 1 + lane; r < nrows; r += 64) {
+                const int nn = rws[2 * r + side] - xc, dd = r - c;
+                bool better = true;
+                if (bd != 0) {
+                    const int lhs = nn * bd, rhs = bn * dd;
+                    better = side ? (lhs >= rhs) : (lhs <= rhs);      // later row wins ties
+                }
+                if (better) { bn = nn; bd = dd; br = r; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int on = __shfl_xor(bn, o, 64), od = __shfl_xor(bd, o, 64), orr = __shfl_xor(br, o, 64);
+                bool take;
+                if (od == 0) take = false;
+                else if (bd == 0) take = true;
+                else {
+                    const int lhs = on * bd, rhs = bn * od;
+                    take = lhs == rhs ? (orr > br) : (side ? (lhs > rhs) : (lhs < rhs));
+                }
+                if (take) { bn = on; bd = od; br = orr; }
+            }
+            c = br;
+        }
+        cnt[side] = nout;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int nh = 0;
+    if (lane == 0) hull_finish(pts, cnt[0], cnt[1], nh);
+    nh = __builtin_amdgcn_readfirstlane(nh);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < nh; e += 64) {           // one hull edge per lane (same arithmetic as min_area_box::vec)
+        const int j = (e + 1 < nh) ? e + 1 : 0;
+        const double dx = (float)pts[j].x - (float)pts[e].x;
+        const double dy = (float)pts[j].y - (float)pts[e].y;
+        etab[e] = (float)dx; etab[nh + e] = (float)dy;
+        etab[2 * nh + e] = (float)(1. / sqrt(dx * dx + dy * dy));
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float box[8];
+        min_area_box(pts, nh, box, etab);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
+        st[9] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w, const int *__restrict__ nkept,
                                                             int *__restrict__ stage, const int *__restrict__ ymax,
                                                             const int *__restrict__ rows_ws, int cap, int scale)
@@ -600,8 +679,6 @@ __global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w,
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int *rws = smem + wid * (12 * h + 4);
-    ipt *pts = (ipt *)(rws + 2 * h);
-    float *etab = (float *)(rws + 6 * h);                   // edge table of the hull: 3 x (<= 2h) floats
     for (int img = blockIdx.x; img < n; img += gridDim.x) {
         const int nk = min(nkept[img], cap);
         for (int k = wid; k < nk; k += nw) {
@@ -609,73 +686,7 @@ __global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w,
             const int y0 = st[0] / w;
             const int nrows = ymax[(size_t)img * cap + k] - y0 + 1;
             const int *g = rows_ws + ((size_t)img * cap + k) * (size_t)(6 * h) + 2 * y0;
-            for (int r = lane; r < 2 * nrows; r += 64) rws[r] = g[r];
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            int cnt[2] = {0, 0};
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {            // 0: left chain (min x), 1: right chain (max x)
-                // Gift wrapping down the chain: from vertex row c the next vertex is the later row with the
-                // extreme slope dx/dy (min for the left chain, max for the right one; farthest on ties, which
-                // drops collinear points).  Candidates are spread over the 64 lanes, fractions compared
-                // exactly by int32 cross-multiplication (|dx|, dy < 2^15), then a xor-butterfly reduction.
-                ipt *out = pts + (side ? cnt[0] : 0);
-                int nout = 0, c = 0;
-                for (;;) {
-                    const int xc = rws[2 * c + side];
-                    if (lane == 0) out[nout] = (ipt){xc, y0 + c};
-                    ++nout;
-                    if (c >= nrows - 1) break;
-                    int bn = 0, bd = 0, br = -1;
-                    for (int r = c + 1 + lane; r < nrows; r += 64) {
-                        const int nn = rws[2 * r + side] - xc, dd = r - c;
-                        bool better = true;
-                        if (bd != 0) {
-                            const int lhs = nn * bd, rhs = bn * dd;
-                            better = side ? (lhs >= rhs) : (lhs <= rhs);      // later row wins ties
-                        }
-                        if (better) { bn = nn; bd = dd; br = r; }
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const int on = __shfl_xor(bn, o, 64), od = __shfl_xor(bd, o, 64), orr = __shfl_xor(br, o, 64);
-                        bool take;
-                        if (od == 0) take = false;
-                        else if (bd == 0) take = true;
-                        else {
-                            const int lhs = on * bd, rhs = bn * od;
-                            take = lhs == rhs ? (orr > br) : (side ? (lhs > rhs) : (lhs < rhs));
-                        }
-                        if (take) { bn = on; bd = od; br = orr; }
-                    }
-                    c = br;
-                }
-                cnt[side] = nout;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            int nh = 0;
-            if (lane == 0) hull_finish(pts, cnt[0], cnt[1], nh);
-            nh = __builtin_amdgcn_readfirstlane(nh);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < nh; e += 64) {           // one hull edge per lane (same arithmetic as min_area_box::vec)
-                const int j = (e + 1 < nh) ? e + 1 : 0;
-                const double dx = (float)pts[j].x - (float)pts[e].x;
-                const double dy = (float)pts[j].y - (float)pts[e].y;
-                etab[e] = (float)dx; etab[nh + e] = (float)dy;
-                etab[2 * nh + e] = (float)(1. / sqrt(dx * dx + dy * dy));
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                float box[8];
-                min_area_box(pts, nh, box, etab);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
-                st[9] = 0;
-            }
-            __builtin_amdgcn_wave_barrier();
+            pp_box_object<false>(rws, g, nrows, y0, h, lane, scale, st);
         }
     }
 }
@@ -797,11 +808,17 @@ static size_t pp_front_lds_bytes(int hw, int root_cap)
 static unsigned long long *g_pp_stamps = nullptr;
 extern "C" void ubd_debug_set_stamps_pp(void *p) { g_pp_stamps = (unsigned long long *)p; }
 #endif
+// TAIL: the block also fits its image's boxes (one wave per kept object, scratch in the dead parts of the forest / root-slot
+// arrays), takes the class vote and emits the lists -- the whole postprocess of a batch is then ONE launch.  (Measured in
+// round 3: in the two-stream pipeline every launch on the postprocess stream costs the forward stream ~5 us of dispatch
+// time whatever the kernel does; tools/pipe_ablation2.py.)
+template <bool TAIL>
 __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     const float *__restrict__ logits, int k_out, float thr, int h, int w, float min_area, int cap, int n_cls, int root_cap,
     int *__restrict__ binary_map, int *__restrict__ g_nroots, int *__restrict__ g_nkept, int *__restrict__ g_owner,
     int *__restrict__ g_roots, int *__restrict__ g_kept, int *__restrict__ stage, int *__restrict__ ymax,
-    int *__restrict__ rows, float *__restrict__ vote, int poison
+    int *__restrict__ rows, float *__restrict__ vote, int poison, int scale, int *__restrict__ quads,
+    int *__restrict__ classes, int *__restrict__ counts
 #ifdef UBD_STAMPS
     , unsigned long long *__restrict__ stamps
 #endif
@@ -986,7 +1003,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
         }
         if (poison && (own < -1 || own >= ctr[0])) atomicOr(&ctr[2], 1);   // test mode: a slot that no root wrote
         own16[loc] = (short)own;
-        if (g_owner) g_owner[pbase + loc] = own;
+        if (!TAIL && g_owner) g_owner[pbase + loc] = own;
     }
     __syncthreads();
     PPSTAMP();
@@ -1034,7 +1051,7 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
             }
         }
         kept[s] = k;
-        if (g_kept) g_kept[(size_t)img * root_cap + s] = k;
+        if (!TAIL && g_kept) g_kept[(size_t)img * root_cap + s] = k;
     }
     __syncthreads();
     PPSTAMP();
@@ -1067,6 +1084,72 @@ __global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(
     }
     if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1] | (ctr[2] << 30); }   // test mode: an integrity failure shows as an impossible count
     PPSTAMP();
+    if constexpr (TAIL) {
+        // ---- boxes (pp_boxes_wave_kernel): the row extents were accumulated by this block's atomics at the L2 -- every wave
+        // waits for its own (vmcnt) before the barrier, and the readers go past the vector L1 (pp_box_object<true>).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nk = min(ctr[1], cap);
+        const int wid = tid >> 6;
+        {
+            // per-wave scratch of 12 h + 4 ints in what is dead by now: the forest behind area2 | kept, and the root-slot array
+            const int S = 12 * h + 4;
+            const int nA = (lab_ints - 2 * root_cap) / S, nB = (hw & 1) ? 0 : (hw / 2) / S;
+            const int nwv = min(PP_LDS_THREADS / 64, nA + nB);                       // >= 1 (host)
+            int *scratch = wid < nA ? lab + 2 * root_cap + wid * S : (int *)rs16 + (wid - nA) * S;
+            if (wid < nwv)
+                for (int k = wid; k < nk; k += nwv) {
+                    int *st = stage + ((size_t)img * cap + k) * STAGE_INTS;
+                    const int y0 = row_of(st[0]);
+                    const int ym = __hip_atomic_load(&ymax[(size_t)img * cap + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int *g = rows + ((size_t)img * cap + k) * (size_t)(6 * h) + 2 * y0;
+                    pp_box_object<true>(scratch, g, ym - y0 + 1, y0, h, lane, scale, st);
+                }
+        }
+        // ---- vote (pp_vote_kernel): mean softmax over the filled region
+        if (n_cls > 0) {
+            for (int loc = tid; loc < hw; loc += PP_LDS_THREADS) {
+                const int o = own16[loc];
+                if (o < 0) continue;
+                const int k = kept[o];
+                if (k < 0) continue;
+                const float *lg = logits + (pbase + loc) * k_out + 1;
+                float mx = lg[0];
+                for (int c = 1; c < n_cls; ++c) mx = fmaxf(mx, lg[c]);
+                float sum = 0.f;
+                for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
+                float *v = vote + ((size_t)img * cap + k) * (n_cls + 1);
+                for (int c = 0; c < n_cls; ++c) atomicAdd(&v[c], expf(lg[c] - mx) / sum);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        PPSTAMP();
+        // ---- emit (pp_emit_kernel): objects ordered like cv2 returns them (last discovered first)
+        if (tid == 0) counts[img] = ctr[1] | (ctr[2] << 30);
+        const int *stg = stage + (size_t)img * cap * STAGE_INTS;
+        for (int sidx = tid; sidx < nk; sidx += PP_LDS_THREADS) {
+            const int root = stg[sidx * STAGE_INTS];
+            int rank = 0;
+            for (int t = 0; t < nk; ++t) rank += (stg[t * STAGE_INTS] > root) ? 1 : 0;
+            int *qd = quads + ((size_t)img * cap + rank) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qd[j] = stg[sidx * STAGE_INTS + 1 + j];
+            if (classes) {
+                int best = 0;
+                if (n_cls > 0) {
+                    const float *v = vote + ((size_t)img * cap + sidx) * (n_cls + 1);
+                    float bv = __hip_atomic_load(&v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int c = 1; c < n_cls; ++c) {
+                        const float vc = __hip_atomic_load(&v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (vc > bv) { bv = vc; best = c; }
+                    }
+                }
+                classes[(size_t)img * cap + rank] = best;
+            }
+        }
+        PPSTAMP();
+    }
 #undef PPSTAMP
 }
 
@@ -1102,18 +1185,32 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     // poisoning + forest integrity check of the one-launch front end
     const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;
     const int pp_poison = getenv("UBD_PP_POISON") != nullptr;
+    // one launch for the whole postprocess when a wave's box scratch (12 h + 4 ints) fits the dead part of the block's LDS
+    bool fused_tail = false;
     if (hw <= PP_LDS_MAX_HW && !force_global) {
         if (!hd->pp_lds_attr_set) {                              // per handle = per device (the attribute belongs to the device's code object)
-            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_front_lds_bytes(PP_LDS_MAX_HW, PP_LDS_MAX_HW / 2 + 2)));   // 1-pixel-high maps hold the most roots per pixel
+            const int lds_max = (int)pp_front_lds_bytes(PP_LDS_MAX_HW, PP_LDS_MAX_HW / 2 + 2);   // 1-pixel-high maps hold the most roots per pixel
+            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+            UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
             hd->pp_lds_attr_set = 1;
         }
-        hipLaunchKernelGGL(pp_front_lds_kernel, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
-                           map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
-                           n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote, pp_poison
+        {
+            const long lab_ints = (long)hw + 1 > 2L * L.root_cap ? (long)hw + 1 : 2L * L.root_cap, S = 12L * map_h + 4;
+            fused_tail = (lab_ints - 2L * L.root_cap) / S + ((hw & 1) ? 0 : (hw / 2) / S) >= 1 && getenv("UBD_PP_SPLIT") == nullptr;   // UBD_PP_SPLIT: test hook, separate tail launches
+        }
 #ifdef UBD_STAMPS
-                           , g_pp_stamps
+#define PP_STAMP_ARG , g_pp_stamps
+#else
+#define PP_STAMP_ARG
 #endif
-                           );
+        if (fused_tail)
+            hipLaunchKernelGGL(pp_front_lds_kernel<true>, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
+                               map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, (int *)nullptr, roots,
+                               (int *)nullptr, stage, ymax, rows, vote, pp_poison, scale, quads, classes, counts PP_STAMP_ARG);
+        else
+            hipLaunchKernelGGL(pp_front_lds_kernel<false>, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, logits, hd->k_out, logit_threshold,
+                               map_h, map_w, min_area, cap, n_cls, L.root_cap, binary_map, nroots, nkept, n_cls > 0 ? owner : nullptr, roots,
+                               n_cls > 0 ? kept : nullptr, stage, ymax, rows, vote, pp_poison, scale, quads, classes, counts PP_STAMP_ARG);
     } else {
     UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_label, st));          // the two per-image counters
     hipLaunchKernelGGL(pp_init_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, logit_threshold, npix, hw, map_w, fg, label, binary_map);
@@ -1125,7 +1222,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     hipLaunchKernelGGL(pp_keep_kernel, dim3(n), dim3(256), 0, st, n, map_h, nroots, roots, area2, L.root_cap, min_area, nkept, kept, stage, ymax, rows, cap, vote, n_cls);
     hipLaunchKernelGGL(pp_extents_kernel, dim3(grid), dim3(256), 0, st, owner, kept, npix, map_h, map_w, L.root_cap, cap, rows, ymax);
     }
-    {
+    if (!fused_tail) {
         // one wave per kept object; 8 waves per image block, fewer while their LDS does not fit
         int waves = 8;
         size_t lds = (size_t)waves * (12 * map_h + 4) * sizeof(int);
@@ -1139,9 +1236,11 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
             hipLaunchKernelGGL(pp_boxes_kernel, dim3(bgrid), dim3(64), 0, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
         }
     }
-    if (n_cls > 0)
-        hipLaunchKernelGGL(pp_vote_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, owner, kept, npix, hw, L.root_cap, cap, vote);
-    hipLaunchKernelGGL(pp_emit_kernel, dim3(n), dim3(256), 0, st, n, nkept, stage, vote, n_cls, cap, quads, classes, counts);
+    if (!fused_tail) {
+        if (n_cls > 0)
+            hipLaunchKernelGGL(pp_vote_kernel, dim3(grid), dim3(256), 0, st, logits, hd->k_out, owner, kept, npix, hw, L.root_cap, cap, vote);
+        hipLaunchKernelGGL(pp_emit_kernel, dim3(n), dim3(256), 0, st, n, nkept, stage, vote, n_cls, cap, quads, classes, counts);
+    }
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }
