@@ -26,7 +26,9 @@ extern "C" {
 enum { UBD_F32 = 0, UBD_BF16 = 1, UBD_F16 = 2 };
 /* input image dtype for ubd_forward; UBD_IN_PREPACKED may be OR-ed in: the packed-fragment region of `workspace`
  * already holds the fragments of the CURRENT parameter values (left there by a previous ubd_forward or
- * ubd_pack_weights on the same handle and workspace), so the per-call repacking kernels (~14 us) are skipped. */
+ * ubd_pack_weights on the same handle and workspace), so the per-call repacking kernels (~14 us) are skipped -- and so is the
+ * zeroing of the fused stem kernel's strip counters, which that kernel leaves at zero itself: pass the flag only while
+ * nothing else has written to the head of the workspace since. */
 enum { UBD_IN_F32 = 0, UBD_IN_U8 = 1, UBD_IN_PREPACKED = 0x100 };
 /* preprocessing fused into the first layer's load (net.py:217-218, NetConfig.get_preprocessing_fn) */
 enum { UBD_PRE_NONE = 0, UBD_PRE_MOBILENET = 1 };

@@ -746,6 +746,7 @@ extern "C" int ubd_pack_weights(ubd_handle *h, const float *params, void *worksp
     ubd_fwd_layout_compute(h, 1, 4, 4, 0, &L);
     UBD_REQUIRE(workspace_bytes >= L.off_a1, "ubd_pack_weights: workspace too small");
     launch_pack(h, params, (float *)((char *)workspace + L.off_wfrag), (hipStream_t)stream);
+    UBD_CHECK_HIP(hipMemsetAsync((char *)workspace + L.off_tickets, 0, 256, (hipStream_t)stream));   // the fused stem's self-resetting counters
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -800,8 +801,11 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
         int grid = h->num_cus;
         if (grid > strips) grid = strips;
         const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
-        int *ticket = (int *)(ws + L.off_tickets);                // strip tickets of the one-kernel stem, zeroed per pass
-        UBD_CHECK_HIP(hipMemsetAsync(ticket, 0, 256, st));
+        // strip tickets of the one-kernel stem ([0]) and its check-out counter ([16]): the kernel leaves both at zero, so they are
+        // zeroed here only when the caller does not vouch for the workspace (UBD_IN_PREPACKED: intact since the previous
+        // ubd_forward of this handle, which then left the counters at zero as well)
+        int *ticket = (int *)(ws + L.off_tickets);
+        if (!prepacked) UBD_CHECK_HIP(hipMemsetAsync(ticket, 0, 256, st));
 #ifdef UBD_STAMPS
 #define S123_STAMP_ARG , g_ubd_stamps
 #else

@@ -230,7 +230,20 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     }
     __syncthreads();
     tpos cur = strip_pos(0, 0);
-    if (cur.ls >= strips) return;                                                    // block-uniform: nothing left
+    // The counter resets itself: every block checks out through a second counter, and the last one out -- by then nobody draws
+    // tickets any more -- zeroes both for the next launch on this workspace (stream order; the host zeroes them only before
+    // the first launch on a workspace: the per-pass memset was a 5 us kernel of its own between two forward passes).
+    auto check_out = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int left = __hip_atomic_fetch_add(ticket + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left == (int)gridDim.x - 1) {
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket + 16, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (cur.ls >= strips) { check_out(); return; }                                   // block-uniform: nothing left
     tpos nx1 = advance(cur);
     int pending = 0;                                                                 // ticket in flight (thread 0)
 #ifdef UBD_STAMPS   // diagnostic build only: s_memtime at the phase boundaries, lane 0 of every wave, first 16 tiles of the block
@@ -472,4 +485,5 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         cur = nx1;
         nx1 = advance(nx1);
     }
+    check_out();
 }
