@@ -403,6 +403,7 @@ def main():
         return runner.predict_on_device(model, x)
 
     def sync_all():
+        runner.flush()                                            # pipelined runner: the last batch's postprocess is still owed
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -106,6 +106,18 @@ int ubd_postprocess(ubd_handle *h, const float *logits, int n, int map_h, int ma
                     int32_t *binary_map, int32_t *quads, int32_t *classes, int32_t *counts, int cap,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ubd_forward of one batch and ubd_postprocess of an EARLIER batch's logits in one call (arguments as in those two; pp_* name the
+ * earlier batch).  Replaces nothing new in the reference -- ModelRunner.predict (model_runner.py:105-138) runs the model and the
+ * postprocess one after the other -- it is how the MI355X host overlaps the postprocess of batch k with the forward pass of
+ * batch k+1: when the forward pass takes the one-kernel stem, the first pp_n blocks of that kernel do the postprocess before they
+ * join the stem's work queue (no second stream, no events, no extra launch); otherwise the two calls are made back to back.
+ * pp_logits must not alias `logits`.  Results are identical to the separate calls. */
+int ubd_forward_postprocess(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                            int n, int height, int width, float *logits, void *workspace, size_t workspace_bytes,
+                            const float *pp_logits, int pp_n, int pp_map_h, int pp_map_w, float logit_threshold, int scale,
+                            float min_area, int32_t *binary_map, int32_t *quads, int32_t *classes, int32_t *counts, int cap,
+                            void *pp_workspace, size_t pp_workspace_bytes, void *stream);
+
 /* --- training ------------------------------------------------------------ */
 /* Replaces the loss callable losses.get_loss(classification_mode)(y_true, y_pred)
  * (losses.py:20-24, :33-126) together with its autodiff gradient.
@@ -169,13 +181,6 @@ int ubd_comm_world(const ubd_handle *h);                                        
 int ubd_allreduce_grads(ubd_handle *h, float *grads, size_t count, void *stream);
 /* params[0..count) of rank `root` to every rank (initial weights / after loading a model on one rank). */
 int ubd_broadcast_params(ubd_handle *h, float *params, size_t count, int root, void *stream);
-
-/* --- pipelining helper ---------------------------------------------------- */
-/* Enqueues a one-wave kernel that idles for `microseconds` (0..1000) on `stream`.  No reference counterpart:
- * ModelRunner.predict (model_runner.py:105-138) runs the model and the postprocess one after the other; the MI355X host
- * (ubdvss_amd.ModelRunner(pipelined=True)) overlaps the postprocess of batch k with the forward pass of batch k+1 on two
- * streams and delays the latter by a few microseconds so that the postprocess blocks are placed first. */
-int ubd_stream_delay(void *stream, int microseconds);
 
 #ifdef __cplusplus
 }

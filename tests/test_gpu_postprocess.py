@@ -200,28 +200,42 @@ def test_large_map_1024_input_shape():
     assert all(np.array_equal(x[0], y[0]) for x, y in zip(a, b))
 
 
+def _same_results(got, ref):
+    """(logits, binary map, quads, classes or None, counts) of two runs: equal, lists compared up to their counts (result
+    buffers of the pipelined runner are reused, so entries behind a list's end may be stale)."""
+    lg, bm, q, c, cnt = got
+    rlg, rbm, rq, rc, rcnt = ref
+    if not (torch.equal(lg, rlg) and torch.equal(bm, rbm) and torch.equal(cnt, rcnt)):
+        return False
+    live = torch.arange(q.shape[1], device=q.device)[None, :] < rcnt[:, None]
+    ok = bool(((q == rq) | ~live[..., None]).all())
+    if c is not None:
+        ok = ok and bool(((c == rc) | ~live).all())
+    return ok
+
+
 def test_pipelined_runner_matches_serial():
-    """Two-stream pipeline (postprocess of batch k overlapping forward of batch k+1) gives the same
-    results as the serial path, batch after batch."""
-    cfg = NetConfig(grey=False)
-    model = Model(cfg, seed=5)
-    w = onet.init_weights(41, 3, 0, bias_scale=0.3)
-    model.set_weights(w)
-    serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
-    batches = []
-    for k in range(5):
-        labels = synthetic.rectangle_maps(70 + k, 4, 32, 32)
-        batches.append(torch.from_numpy(synthetic.textured_images(80 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda())
-    ref = [[t.clone() for t in serial.predict_on_device(model, b) if t is not None] for b in batches]
-    got = []
-    for b in batches:
-        out = piped.predict_on_device(model, b)
-        got.append(out)
-    torch.cuda.synchronize()
-    # slots are double-buffered: only the last two batches are still resident
-    for k in (3, 4):
-        for a, r in zip([t for t in got[k] if t is not None], ref[k]):
-            assert torch.equal(a, r)
+    """Pipeline (the postprocess of batch k rides in the stem kernel of batch k+1's forward pass, ubd_forward_postprocess) gives
+    the same results as the serial path, batch after batch; big batches so that the one-kernel stem -- and with it the in-kernel
+    postprocess -- really runs (small ones take the back-to-back fallback, covered by the second loop)."""
+    for n_cls, n_img, side in ((0, 4, 128), (0, 34, 256), (3, 34, 256)):       # 34 x 16 strips = 544 >= 2 x 256 CUs: fused stem
+        cfg = NetConfig(class_names=[f"c{i}" for i in range(n_cls)] if n_cls else None, grey=False)
+        model = Model(cfg, seed=5)
+        model.set_weights(onet.init_weights(41, 3, n_cls, bias_scale=0.3))
+        serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
+        batches = []
+        for k in range(5):
+            labels = synthetic.rectangle_maps(70 + k, n_img, side // 4, side // 4)
+            batches.append(torch.from_numpy(synthetic.textured_images(80 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda())
+        ref = [[t.clone() if t is not None else None for t in serial.predict_on_device(model, b)] for b in batches]
+        got = []
+        for k, b in enumerate(batches):
+            got.append(piped.predict_on_device(model, b))
+            if k >= 1:                                            # batch k-1 is complete once this call has run
+                torch.cuda.synchronize()
+                assert _same_results(got[k - 1], ref[k - 1]), (n_cls, n_img, k - 1)
+        piped.synchronize()                                       # flushes the last batch's postprocess
+        assert _same_results(got[4], ref[4]), (n_cls, n_img, 4)
 
 
 # ---------------------------------------------------------------------------------------------- stress / determinism
@@ -294,9 +308,10 @@ def test_postprocess_stress_deterministic(golden_dir, front_end, mode, monkeypat
 
 
 def test_postprocess_stress_in_pipelined_runner():
-    """The same check inside ModelRunner(pipelined=True): the postprocess of batch k on the side stream under the forward
-    pass of batch k+1 (the bench's headline path), 300 steps over a ring of batches at the headline map size; every step's
-    lists equal the serial runner's lists of that batch."""
+    """The same check inside ModelRunner(pipelined=True) -- the bench's headline path: the postprocess of batch k runs in the
+    first blocks of the stem kernel of batch k+1 (512-thread blocks, LDS shared with the stem, other blocks of the kernel
+    already convolving).  300 steps over a ring of batches at the headline shape (32 x 512 x 512); every step's lists equal the
+    serial runner's lists of that batch."""
     cfg = NetConfig(grey=False)
     model = Model(cfg, seed=5)
     w = onet.init_weights(41, 3, 0, bias_scale=0.3)
@@ -304,24 +319,25 @@ def test_postprocess_stress_in_pipelined_runner():
     serial, piped = ModelRunner(cfg, max_objects_per_image=4200), ModelRunner(cfg, pipelined=True, max_objects_per_image=4200)
     batches, ref = [], []
     for k in range(4):
-        labels = synthetic.rectangle_maps(170 + k, 8, 128, 128)
+        labels = synthetic.rectangle_maps(170 + k, 32, 128, 128)
         b = torch.from_numpy(synthetic.textured_images(180 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
         batches.append(b)
         _, bmap, quads, _, counts = serial.predict_on_device(model, b)
         ref.append((bmap.clone(), quads.clone(), counts.clone()))
     torch.cuda.synchronize()
+    assert model._lib.ubd_num_cus(model._h) * 2 <= 32 * 32        # 1024 strips: the one-kernel stem (and the in-kernel postprocess) is in use
     pending = None
     bad = []
     for it in range(300):
         k = it % 4
         out = piped.predict_on_device(model, batches[k])
-        if pending is not None:                                   # results of the previous step: complete once its event fired
-            pk, pout, pev = pending
-            pev.synchronize()
+        if pending is not None:                                   # the previous step's lists: complete now that this call is enqueued
+            pk, pout = pending
+            torch.cuda.synchronize()
             _, bmap, quads, _, counts = pout
             live = torch.arange(quads.shape[1], device="cuda")[None, :, None] < ref[pk][2][:, None, None]
             if not (torch.equal(bmap, ref[pk][0]) and torch.equal(counts, ref[pk][2]) and bool(((quads == ref[pk][1]) | ~live).all())):
                 bad.append(it - 1)
-        pending = (k, out, piped.last_event)
-    torch.cuda.synchronize()
+        pending = (k, out)
+    piped.synchronize()
     assert not bad, bad[:10]

@@ -36,13 +36,14 @@ SIGNATURES = {
     "ubd_postprocess_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "ubd_loss_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "ubd_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ubd_forward_postprocess": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz,
+                                     _vp, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "ubd_pack_weights": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "ubd_dilated_layer": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ubd_postprocess": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "ubd_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ubd_train_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ubd_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
-    "ubd_stream_delay": (_i, [_vp, _i]),
     "ubd_build_label_maps": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ubd_comm_unique_id": (_i, [_vp]),
     "ubd_comm_init": (_i, [_vp, _vp, _i, _i, _i]),

@@ -175,8 +175,16 @@ extern "C" int ubd_comm_world(const ubd_handle *h);
 int ubd_comm_begin_tail(ubd_handle *h, float *grads, hipStream_t st);
 int ubd_comm_finish(ubd_handle *h, float *grads, hipStream_t st);
 void ubd_fwd_layout_compute(const ubd_handle *h, int n, int H, int W, int training, ubd_fwd_layout *L);
+struct pp_lds_args;       // pp_lds.h: one-launch postprocess job (the fused stem kernel can carry one for a previous batch)
 int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
-                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference = false);
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference = false,
+                     const pp_lds_args *pp_job = nullptr);
+// fills `job` for ubd_postprocess's arguments when the whole postprocess fits the one-launch in-block form with `threads`
+// threads per block (returns 1), else returns 0; negative: argument error (ubd_last_error)
+int ubd_pp_fill_job(ubd_handle *hd, const float *logits, int n, int map_h, int map_w, float logit_threshold, int scale, float min_area,
+                    int32_t *binary_map, int32_t *quads, int32_t *classes, int32_t *counts, int cap, void *workspace,
+                    size_t workspace_bytes, int threads, pp_lds_args *job);
+bool ubd_forward_uses_fused_stem(const ubd_handle *h, int n, int H, int W);
 void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const float *aux, int dilation,
                         const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu);

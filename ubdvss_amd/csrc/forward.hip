@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? (STRIDE == 1 ? 3 : 2) : 5) vo
 static unsigned long long *g_ubd_stamps = nullptr;
 extern "C" void ubd_debug_set_stamps(void *p) { g_ubd_stamps = (unsigned long long *)p; }
 #endif
+#include "pp_lds.h"
 #include "stem23.h"
 #include "stem123.h"
 
@@ -764,8 +765,20 @@ extern "C" int ubd_dilated_layer(ubd_handle *h, const float *params, int layer, 
 }
 
 // Runs L1..L9 + head.  acts[0..8] receive the hidden activations (L1..L9 outputs).
+static bool fused_stem_applies(const ubd_handle *h, int n, int H)
+{
+    // the fused stem kernels give every CU whole strips of tiles (n * H4 / 4 of them): they need ~2 strips per CU to fill the chip
+    // (a single 512 x 512 image has 32); smaller launches take the three separate kernels unless UBD_STEM forces a variant
+    const int H4 = H / 4;
+    const long stem_strips = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
+    const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
+    return stem_big && h->fuse_stem == 2 && h->cfg.fml_compatible != 0;
+}
+bool ubd_forward_uses_fused_stem(const ubd_handle *h, int n, int H, int W) { (void)W; return h->cfg.dtype == UBD_F32 && fused_stem_applies(h, n, H); }
+
 int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
-                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference)
+                     int n, int H, int W, float *logits, char *ws, const ubd_fwd_layout &L, hipStream_t st, bool inference,
+                     const pp_lds_args *pp_job)
 {
     UBD_REQUIRE(h->cfg.dtype == UBD_F32, "ubd_forward: only UBD_F32 activations are implemented in this build");
     const bool prepacked = (in_dtype & UBD_IN_PREPACKED) != 0;
@@ -790,16 +803,18 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     if (preprocessing == UBD_PRE_MOBILENET) { sc = 127.5f; sh = 127.5f; }
     const int u8 = in_dtype == UBD_IN_U8;
     float *cur = (float *)(ws + L.off_acts[0]);
-    // the fused stem kernels give every CU whole strips of tiles (n * H4 / 4 of them): they need ~2 strips per CU to fill the chip
-    // (a single 512 x 512 image has 32); smaller launches take the three separate kernels unless UBD_STEM forces a variant
     const long stem_strips = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
     const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
-    const bool fuse_all = inference && stem_big && h->fuse_stem == 2 && pad_s2 == 1;
+    const bool fuse_all = inference && fused_stem_applies(h, n, H);
+    UBD_REQUIRE(!pp_job || fuse_all, "ubd_forward: a postprocess job needs the fused stem kernel (internal error)");
     if (fuse_all) {
         // L1 -> L2 -> L3 in one kernel (stem123.h): neither a1 nor a2 is touched
         const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
         int grid = h->num_cus;
         if (grid > strips) grid = strips;
+        pp_lds_args pj;
+        memset(&pj, 0, sizeof(pj));                              // n = 0: no postprocess job rides along
+        if (pp_job) pj = *pp_job;
         const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
         // strip tickets of the one-kernel stem ([0]) and its check-out counter ([16]): the kernel leaves both at zero, so they are
         // zeroed here only when the caller does not vouch for the workspace (UBD_IN_PREPACKED: intact since the previous
@@ -811,7 +826,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #else
 #define S123_STAMP_ARG
 #endif
-#define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket S123_STAMP_ARG)
+#define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG)
         const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30);   // fp32 fed as it is: LDS-DMA path (offsets of one image in 30 bits)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
@@ -877,4 +892,33 @@ extern "C" int ubd_forward(ubd_handle *h, const float *params, const void *image
     ubd_fwd_layout_compute(h, n, height, width, 0, &L);
     UBD_REQUIRE(workspace_bytes >= L.total, "ubd_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
     return ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, L, (hipStream_t)stream, true);
+}
+
+// ubd_forward of one batch + ubd_postprocess of ANOTHER (earlier) batch's logits, enqueued together: when the forward pass runs
+// the one-kernel stem, the first blocks of that kernel do the postprocess (one image each, pp_lds.h) before they join the stem's
+// strip queue -- no second stream, no events, no extra launch; otherwise the two calls are simply made one after the other.
+extern "C" int ubd_forward_postprocess(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing,
+                                       int n, int height, int width, float *logits, void *workspace, size_t workspace_bytes,
+                                       const float *pp_logits, int pp_n, int pp_map_h, int pp_map_w, float logit_threshold, int scale,
+                                       float min_area, int32_t *binary_map, int32_t *quads, int32_t *classes, int32_t *counts, int cap,
+                                       void *pp_workspace, size_t pp_workspace_bytes, void *stream)
+{
+    UBD_REQUIRE(h && params && images && logits && workspace, "ubd_forward_postprocess: null argument");
+    UBD_REQUIRE(pp_logits != logits, "ubd_forward_postprocess: the logits being postprocessed must not be the buffer this call writes");
+    if (h->cfg.dtype == UBD_F32 && n > 0 && height > 0 && (height % 4) == 0 && ubd_forward_uses_fused_stem(h, n, height, width)) {
+        pp_lds_args job;
+        const int fits = ubd_pp_fill_job(h, pp_logits, pp_n, pp_map_h, pp_map_w, logit_threshold, scale, min_area, binary_map, quads, classes,
+                                         counts, cap, pp_workspace, pp_workspace_bytes, s23_cfg::NT, &job);
+        if (fits < 0) return 1;
+        if (fits == 1) {
+            ubd_fwd_layout L;
+            ubd_fwd_layout_compute(h, n, height, width, 0, &L);
+            UBD_REQUIRE(workspace_bytes >= L.total, "ubd_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+            return ubd_forward_impl(h, params, images, in_dtype, preprocessing, n, height, width, logits, (char *)workspace, L, (hipStream_t)stream, true, &job);
+        }
+    }
+    int rc = ubd_postprocess(h, pp_logits, pp_n, pp_map_h, pp_map_w, logit_threshold, scale, min_area, binary_map, quads, classes, counts, cap,
+                             pp_workspace, pp_workspace_bytes, stream);
+    if (rc) return rc;
+    return ubd_forward(h, params, images, in_dtype, preprocessing, n, height, width, logits, workspace, workspace_bytes, stream);
 }

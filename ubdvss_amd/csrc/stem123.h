@@ -37,7 +37,9 @@ template <int CIN> struct s123_cfg {
     static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
     static constexpr int UPW = (UNITS + NW - 1) / NW;              // units per wave
     static constexpr int W1_FLOATS = 64 * 12 + 64 + 4;              // L1 per-lane weights (9 depthwise taps, 2 pointwise, pad) + biases of L1 / L3 (2 x 32) + the ring of strip ids
-    static constexpr int SMEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
+    static constexpr int STEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
+    static constexpr int PP_FLOATS = (PP_LDS_MAX_BYTES + 3) / 4;   // the postprocess job some blocks run first (pp_lds.h) uses the same LDS
+    static constexpr int SMEM_FLOATS = STEM_FLOATS > PP_FLOATS ? STEM_FLOATS : PP_FLOATS;
     static_assert(XCH <= 64 && (A1_FLOATS % 4) == 0 && (B::L2_FLOATS % 4) == 0, "patch rows are single 16-byte-aligned DMA pieces");
 };
 
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                                                                 const float *__restrict__ frag2, const float *__restrict__ bias2,
                                                                 const float *__restrict__ frag3, const float *__restrict__ bias3,
                                                                 int n, int H, int W, int H2, int W2, int H4, int W4,
-                                                                float pre_sub, float pre_div, int *__restrict__ ticket
+                                                                float pre_sub, float pre_div, int *__restrict__ ticket, pp_lds_args pj
 #ifdef UBD_STAMPS
                                                                 , unsigned long long *__restrict__ stamps
 #endif
@@ -59,6 +61,17 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     using C = s23_cfg;
     using X = s123_cfg<CIN>;
     __shared__ __attribute__((aligned(16))) float smem[X::SMEM_FLOATS];                     // ONE LDS object
+    // ---- the postprocess of an EARLIER batch rides along (ubd_forward_postprocess): block b first does image b, b + grid, ... of
+    // that job -- threshold, components, boxes, class vote, lists, all inside the block (pp_lds.h) -- and then joins the strip
+    // queue below, where the blocks that had no image have meanwhile taken its share (tickets).  One launch instead of a second
+    // stream with two events per step: round 3 measured 10 us of idle forward stream behind every event record and a placement
+    // race between the postprocess blocks and this kernel's whole-CU blocks.
+    if (pj.n > 0) {
+        for (int im = (int)blockIdx.x; im < pj.n; im += (int)gridDim.x) {
+            pp_image_lds<C::NT, true>((int *)smem, pj, im);
+            __syncthreads();
+        }
+    }
     float *a1p = smem;
     float *l2 = a1p + X::A1_FLOATS;
     float *xp = l2 + C::L2_FLOATS;

@@ -30,24 +30,3 @@ extern "C" int ubd_adam_step(float *params, const float *grads, float *m, float 
 }
 
 
-// ---- pipelining helper of ModelRunner (no counterpart in the reference: it runs predict and postprocess serially) --------
-// One wave that idles for `microseconds` (s_sleep on the constant 100 MHz clock) and exits: enqueued on the forward stream in
-// front of the next batch's first kernel, it gives the postprocess of the previous batch -- launched on a second stream at
-// the same moment -- the head start it needs to get its 32 whole-CU blocks placed.  Without it the first stem kernel
-// (16 384 small blocks) keeps every CU partly occupied, the postprocess front end only starts once that kernel drains
-// (~70 us) and then holds 32 CUs right under the PERSISTENT second stem kernel, whose 96 blocks for those CUs wait for it:
-// 83 -> 118 us (kernel timeline in DESIGN.md).
-__global__ void stream_delay_kernel(unsigned long long ticks)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-extern "C" int ubd_stream_delay(void *stream, int microseconds)
-{
-    UBD_REQUIRE(microseconds >= 0 && microseconds <= 1000, "ubd_stream_delay: 0..1000 us, got %d", microseconds);
-    if (microseconds == 0) return 0;
-    hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
-    UBD_CHECK_HIP(hipGetLastError());
-    return 0;
-}

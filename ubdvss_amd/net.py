@@ -280,9 +280,12 @@ class Model:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def predict_on_device(self, images, out=None, preprocessing=None):
+    def predict_on_device(self, images, out=None, preprocessing=None, postprocess=None):
         """images: torch tensor (N,H,W,C_in) on this device, float32 (fed as is) or uint8 (the
-        NetConfig preprocessing is fused into the first layer).  Returns fp32 logits (N,H/4,W/4,K)."""
+        NetConfig preprocessing is fused into the first layer).  Returns fp32 logits (N,H/4,W/4,K).
+        postprocess: None, or the keyword arguments of ``postprocess_on_device`` for ANOTHER batch's logits (with
+        ``outputs`` preallocated): that postprocess is enqueued together with this forward pass
+        (ubd_forward_postprocess: inside the stem kernel's first blocks when the one-kernel stem runs)."""
         if images.device != self.device:
             raise ValueError("images must live on the model's device")
         if images.dim() != 4 or images.shape[3] != self.c_in:
@@ -312,9 +315,24 @@ class Model:
             in_dtype |= _lib.UBD_IN_PREPACKED
         self._packed_key = None
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.ubd_forward(self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre,
-                                             n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                       "ubd_forward")
+            if postprocess is None:
+                _lib.check(self._lib.ubd_forward(self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre,
+                                                 n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                           "ubd_forward")
+            else:
+                pl = postprocess["logits"]
+                if not pl.is_contiguous() or pl.dtype != torch.float32 or pl.shape[3] != self.k_out:
+                    raise ValueError("postprocess job: logits must be a contiguous fp32 (N,h,w,K) tensor of this model")
+                pn, pmh, pmw, _ = pl.shape
+                bmap, quads, classes, counts = postprocess["outputs"]
+                cap = int(postprocess.get("cap", quads.shape[1]))
+                pws = self._workspace("_pp_ws", self._lib.ubd_postprocess_workspace_bytes(self._h, pn, pmh, pmw, cap))
+                _lib.check(self._lib.ubd_forward_postprocess(
+                    self._h, self.params.data_ptr(), images.data_ptr(), in_dtype, pre, n, hh, ww, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                    pl.data_ptr(), pn, pmh, pmw, float(postprocess["logit_threshold"]), int(postprocess["scale"]),
+                    float(postprocess["min_area"]), bmap.data_ptr() if bmap is not None else None, quads.data_ptr(),
+                    classes.data_ptr() if classes is not None else None, counts.data_ptr(), cap, pws.data_ptr(), pws.numel(), stream),
+                    "ubd_forward_postprocess")
         self._packed_key = key
         return out
 
