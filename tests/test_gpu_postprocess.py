@@ -18,14 +18,18 @@ pytestmark = pytest.mark.gpu
 def front_end(request, monkeypatch):
     """Every case runs through every code path: "lds" = the whole postprocess of a batch as ONE launch (maps of <= 16384
     pixels: front end, boxes, class vote and emit in one block per image), "lds_split" = the one-launch front end followed by
-    the separate boxes / vote / emit kernels (UBD_PP_SPLIT; what maps too tall for the in-block box scratch take), "global" =
-    the multi-launch global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    the separate boxes / vote / emit kernels (UBD_PP_SPLIT; what maps too tall for the in-block box scratch take) with the
+    ONE-LANE form of the box fit (UBD_PP_SERIAL_TAIL: hull clean-up and rotating calipers on lane 0 over LDS arrays, what hulls
+    of more than 64 vertices take; the other two variants run the wave-uniform register form), "global" = the multi-launch
+    global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
     monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
     monkeypatch.delenv("UBD_PP_SPLIT", raising=False)
+    monkeypatch.delenv("UBD_PP_SERIAL_TAIL", raising=False)
     if request.param == "global":
         monkeypatch.setenv("UBD_PP_GLOBAL", "1")
     elif request.param == "lds_split":
         monkeypatch.setenv("UBD_PP_SPLIT", "1")
+        monkeypatch.setenv("UBD_PP_SERIAL_TAIL", "1")
     return request.param
 
 

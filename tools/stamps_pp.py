@@ -21,6 +21,6 @@ for name, lg in (("rectangle maps", synthetic.logits_from_maps(labels, 0, seed=5
     s = st.cpu().numpy()
     k = int((s[0] > 0).sum())
     seg = np.diff(s[:, :k], axis=1)
-    names = ["init", "merge", "flatten", "roots", "owner", "zero area", "area", "keep", "rows init", "extents"]
+    names = ["init", "merge", "flatten", "roots", "owner", "zero area", "area", "keep", "rows init", "extents", "boxes + vote", "emit"]
     print(name, "total cycles median", int(np.median(s[:, k - 1] - s[:, 0])))
     print("   " + "  ".join(f"{names[i] if i < len(names) else i}: {int(np.median(seg[:, i]))}" for i in range(k - 1)))

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void pp_boxes_kernel(int n, int h, int w, const
 
 __global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w, const int *__restrict__ nkept,
                                                             int *__restrict__ stage, const int *__restrict__ ymax,
-                                                            const int *__restrict__ rows_ws, int cap, int scale)
+                                                            const int *__restrict__ rows_ws, int cap, int scale, int serial_tail)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void pp_boxes_wave_kernel(int n, int h, int w,
             const int y0 = st[0] / w;
             const int nrows = ymax[(size_t)img * cap + k] - y0 + 1;
             const int *g = rows_ws + ((size_t)img * cap + k) * (size_t)(6 * h) + 2 * y0;
-            pp_box_object<false>(rws, g, nrows, y0, h, lane, scale, st);
+            pp_box_object<false>(rws, g, nrows, y0, h, lane, scale, st, serial_tail != 0);
         }
     }
 }
@@ -499,11 +499,11 @@ __global__ __launch_bounds__(256) void pp_emit_kernel(int n, const int *__restri
 static unsigned long long *g_pp_stamps = nullptr;
 extern "C" void ubd_debug_set_stamps_pp(void *p) { g_pp_stamps = (unsigned long long *)p; }
 #endif
-template <bool TAIL>
-__global__ __launch_bounds__(PP_LDS_THREADS) void pp_front_lds_kernel(pp_lds_args a)
+template <bool TAIL, int NT = PP_LDS_THREADS>
+__global__ __launch_bounds__(NT) void pp_front_lds_kernel(pp_lds_args a)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    pp_image_lds<PP_LDS_THREADS, TAIL>(smem, a, (int)blockIdx.x);
+    pp_image_lds<NT, TAIL>(smem, a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -531,7 +531,7 @@ int ubd_pp_fill_job(ubd_handle *hd, const float *logits, int n, int map_h, int m
     if (hw > PP_LDS_MAX_HW || (PP_LDS_MAX_HW % threads) != 0 || getenv("UBD_PP_GLOBAL") || getenv("UBD_PP_SPLIT") || !pp_tail_fits(map_h, map_w, L.root_cap)) return 0;
     char *ws = (char *)workspace;
     a->logits = logits; a->n = n; a->k_out = hd->k_out; a->h = map_h; a->w = map_w; a->cap = cap; a->n_cls = n_cls; a->root_cap = L.root_cap;
-    a->poison = getenv("UBD_PP_POISON") != nullptr; a->scale = scale; a->thr = logit_threshold; a->min_area = min_area;
+    a->poison = getenv("UBD_PP_POISON") != nullptr; a->serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr; a->scale = scale; a->thr = logit_threshold; a->min_area = min_area;
     a->binary_map = binary_map; a->g_nroots = (int *)(ws + L.off_nroots); a->g_nkept = (int *)(ws + L.off_nkept);
     a->g_roots = (int *)(ws + L.off_roots); a->stage = (int *)(ws + L.off_stage); a->ymax = (int *)(ws + L.off_ymax); a->rows = (int *)(ws + L.off_rows);
     a->vote = (float *)(ws + L.off_vote); a->quads = quads; a->classes = classes; a->counts = counts;
@@ -582,7 +582,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
         fused_tail = pp_tail_fits(map_h, map_w, L.root_cap) && getenv("UBD_PP_SPLIT") == nullptr;   // UBD_PP_SPLIT: test hook, separate tail launches
         pp_lds_args a;
         a.logits = logits; a.n = n; a.k_out = hd->k_out; a.h = map_h; a.w = map_w; a.cap = cap; a.n_cls = n_cls; a.root_cap = L.root_cap;
-        a.poison = pp_poison; a.scale = scale; a.thr = logit_threshold; a.min_area = min_area;
+        a.poison = pp_poison; a.serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr; a.scale = scale; a.thr = logit_threshold; a.min_area = min_area;
         a.binary_map = binary_map; a.g_nroots = nroots; a.g_nkept = nkept; a.g_roots = roots; a.stage = stage; a.ymax = ymax; a.rows = rows;
         a.vote = vote; a.quads = quads; a.classes = classes; a.counts = counts;
         a.g_owner = (!fused_tail && n_cls > 0) ? owner : nullptr;
@@ -592,7 +592,11 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
 #else
         a.stamps = nullptr;
 #endif
-        if (fused_tail)
+        if (fused_tail && getenv("UBD_PP_THREADS_512")) {        // diagnostics: the block shape the job has inside the stem kernel (512 threads)
+            static bool attr512 = false;
+            if (!attr512) { UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_MAX_BYTES)); attr512 = true; }
+            hipLaunchKernelGGL((pp_front_lds_kernel<true, 512>), dim3(n), dim3(512), pp_front_lds_bytes(hw, L.root_cap), st, a);
+        } else if (fused_tail)
             hipLaunchKernelGGL(pp_front_lds_kernel<true>, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, a);
         else
             hipLaunchKernelGGL(pp_front_lds_kernel<false>, dim3(n), dim3(PP_LDS_THREADS), pp_front_lds_bytes(hw, L.root_cap), st, a);
@@ -613,7 +617,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
         size_t lds = (size_t)waves * (12 * map_h + 4) * sizeof(int);
         while (lds > 64 * 1024 && waves > 1) { waves /= 2; lds /= 2; }
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(64 * waves), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale);
+            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(64 * waves), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale, getenv("UBD_PP_SERIAL_TAIL") != nullptr);
         } else {                                       // very tall maps: serial per-object fallback in global memory
             const long total = (long)n * cap;
             int bgrid = (int)((total + 63) / 64);

@@ -183,12 +183,205 @@ __device__ __forceinline__ void hull_finish(ipt *P, int nl, int nr, int &n_out)
     n_out = n;
 }
 
+// ---- wave-uniform forms of hull_finish / min_area_box for polygons of at most 64 vertices: vertex v lives in LANE v
+// (registers X, Y), every lane runs the same scalar program and fetches vertices with v_readlane (index in an SGPR) instead
+// of walking an LDS array on one lane.  Same operations in the same order as the one-lane forms above: the results are
+// bit-identical.  Measured (in-kernel stamps, round 3): the box fit of an image's largest object is 64 k cycles this way against
+// 70 k on one lane -- a serial chain of dependent instructions costs ~10 cycles per instruction either way; building the hull
+// chains in registers too (monotone chain with v_readlane) was SLOWER (119 k).  Kept for the 6 k and because it frees the lane-0
+// LDS traffic; the results are bit-identical (tests/test_gpu_postprocess.py runs every case through both -- UBD_PP_SPLIT keeps the LDS form).
+__device__ __forceinline__ int pp_rl(int v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
+__device__ __forceinline__ float pp_rlf(float v, int idx)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(idx)));
+}
+
+// P = lc[0..nl-1] (top -> bottom) in lanes 0..nl-1 followed by rc REVERSED (bottom -> top) in lanes nl..nl+nr-1 on entry.
+__device__ __forceinline__ int hull_finish_wave(int &X, int &Y, int nl, int nr, int lane)
+{
+    int n = nl + nr;
+    auto remove_at = [&](int k) {                              // P[k..n-2] = P[k+1..n-1]
+        const int xs = __shfl_down(X, 1, 64), ys = __shfl_down(Y, 1, 64);
+        if (lane >= k) { X = xs; Y = ys; }
+        --n;
+    };
+    if (nr > 0 && pp_rl(X, nl - 1) == pp_rl(X, nl) && pp_rl(Y, nl - 1) == pp_rl(Y, nl)) remove_at(nl);      // bottom junction
+    if (n > 1 && pp_rl(X, n - 1) == pp_rl(X, 0) && pp_rl(Y, n - 1) == pp_rl(Y, 0)) --n;                    // top junction
+    bool changed = true;
+    while (changed && n > 2) {
+        changed = false;
+        for (int k = 0; k < n && n > 2; ++k) {
+            const int ka = k == 0 ? n - 1 : k - 1, kc = k + 1 == n ? 0 : k + 1;
+            const ipt a = {pp_rl(X, ka), pp_rl(Y, ka)}, b = {pp_rl(X, k), pp_rl(Y, k)}, c = {pp_rl(X, kc), pp_rl(Y, kc)};
+            if (cross3(a, b, c) == 0) { remove_at(k); --k; changed = true; }
+        }
+    }
+    if (n == 2) {
+        const int x0 = pp_rl(X, 0), y0 = pp_rl(Y, 0), x1 = pp_rl(X, 1), y1 = pp_rl(Y, 1);
+        if ((x1 < x0) || (x1 == x0 && y1 < y0)) {               // lexicographic min first
+            if (lane == 0) { X = x1; Y = y1; }
+            if (lane == 1) { X = x0; Y = y0; }
+        }
+    } else if (n > 2) {
+        int s = 0, sx = pp_rl(X, 0), sy = pp_rl(Y, 0);         // min-x (then min-y) vertex comes first
+        for (int k = 1; k < n; ++k) {
+            const int xk = pp_rl(X, k), yk = pp_rl(Y, k);
+            if (xk < sx || (xk == sx && yk < sy)) { s = k; sx = xk; sy = yk; }
+        }
+        if (s != 0) {
+            int src = lane + s;
+            src = src >= n ? src - n : src;
+            const int xr = __shfl(X, src, 64), yr = __shfl(Y, src, 64);
+            X = xr; Y = yr;
+        }
+    }
+    return n;
+}
+
+// cv::minAreaRect + cv::boxPoints as min_area_box, hull vertex v in lane v (n <= 64); every lane returns the same box8.
+__device__ __forceinline__ void min_area_box_wave(int X, int Y, int n, int lane, float *box8)
+{
+#pragma clang fp contract(off)
+    float cxr = 0.f, cyr = 0.f, bw = 0.f, bh = 0.f, angle = 0.f;
+    const float fx = (float)X, fy = (float)Y;
+    if (n > 2) {
+        // edge table, one edge per lane (min_area_box::vec)
+        float evx, evy, einv;
+        {
+            int j = lane + 1;
+            j = j < n ? j : 0;
+            const float xj = (float)__shfl(X, j, 64), yj = (float)__shfl(Y, j, 64);
+            const double dx = xj - fx;
+            const double dy = yj - fy;
+            evx = (float)dx; evy = (float)dy;
+            einv = (float)(1. / sqrt(dx * dx + dy * dy));
+        }
+        float minarea = 3.402823466e+38f;
+        int buf_i0 = 0, buf_i5 = 0;
+        float buf1 = 0.f, buf2 = 0.f, buf3 = 0.f, buf4 = 0.f;
+        int left = 0, bottom = 0, right = 0, top = 0;
+        float left_x, right_x, top_y, bottom_y;
+        left_x = right_x = pp_rlf(fx, 0);
+        top_y = bottom_y = pp_rlf(fy, 0);
+        for (int i = 0; i < n; ++i) {
+            const float px = pp_rlf(fx, i), py = pp_rlf(fy, i);
+            if (px < left_x) left_x = px, left = i;
+            if (px > right_x) right_x = px, right = i;
+            if (py > top_y) top_y = py, top = i;
+            if (py < bottom_y) bottom_y = py, bottom = i;
+        }
+        float orientation = 0.f;
+        {
+            double ax = pp_rlf(evx, n - 1), ay = pp_rlf(evy, n - 1);
+            for (int i = 0; i < n; ++i) {
+                const double bx = pp_rlf(evx, i), by = pp_rlf(evy, i);
+                const double convexity = ax * by - ay * bx;
+                if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
+                ax = bx; ay = by;
+            }
+        }
+        float base_a = orientation, base_b = 0.f;
+        // the four calipers: index, edge (vx, vy, 1/length) and vertex of each -- only the one that advances is re-fetched
+        int s0 = bottom, s1 = right, s2 = top, s3 = left;
+        float vx0 = pp_rlf(evx, s0), vy0 = pp_rlf(evy, s0), in0 = pp_rlf(einv, s0), px0 = pp_rlf(fx, s0), py0 = pp_rlf(fy, s0);
+        float vx1 = pp_rlf(evx, s1), vy1 = pp_rlf(evy, s1), in1 = pp_rlf(einv, s1), px1 = pp_rlf(fx, s1), py1 = pp_rlf(fy, s1);
+        float vx2 = pp_rlf(evx, s2), vy2 = pp_rlf(evy, s2), in2 = pp_rlf(einv, s2), px2 = pp_rlf(fx, s2), py2 = pp_rlf(fy, s2);
+        float vx3 = pp_rlf(evx, s3), vy3 = pp_rlf(evy, s3), in3 = pp_rlf(einv, s3), px3 = pp_rlf(fx, s3), py3 = pp_rlf(fy, s3);
+        for (int k = 0; k < n; ++k) {
+            const float dp0 = +base_a * vx0 + base_b * vy0;
+            const float dp1 = -base_b * vx1 + base_a * vy1;
+            const float dp2 = -base_a * vx2 - base_b * vy2;
+            const float dp3 = +base_b * vx3 - base_a * vy3;
+            float maxcos = dp0 * in0;
+            int main_element = 0;
+            const float c1 = dp1 * in1; if (c1 > maxcos) { main_element = 1; maxcos = c1; }
+            const float c2 = dp2 * in2; if (c2 > maxcos) { main_element = 2; maxcos = c2; }
+            const float c3 = dp3 * in3; if (c3 > maxcos) { main_element = 3; maxcos = c3; }
+            main_element = __builtin_amdgcn_readfirstlane(main_element);
+            {
+                const float mvx = main_element == 0 ? vx0 : main_element == 1 ? vx1 : main_element == 2 ? vx2 : vx3;
+                const float mvy = main_element == 0 ? vy0 : main_element == 1 ? vy1 : main_element == 2 ? vy2 : vy3;
+                const float min_ = main_element == 0 ? in0 : main_element == 1 ? in1 : main_element == 2 ? in2 : in3;
+                const float lead_x = mvx * min_;
+                const float lead_y = mvy * min_;
+                switch (main_element) {
+                case 0: base_a = lead_x;  base_b = lead_y;  break;
+                case 1: base_a = lead_y;  base_b = -lead_x; break;
+                case 2: base_a = -lead_x; base_b = -lead_y; break;
+                default: base_a = -lead_y; base_b = lead_x; break;
+                }
+            }
+            {
+                int sm = main_element == 0 ? s0 : main_element == 1 ? s1 : main_element == 2 ? s2 : s3;
+                sm += 1;
+                sm = (sm == n) ? 0 : sm;
+                const float nvx = pp_rlf(evx, sm), nvy = pp_rlf(evy, sm), nin = pp_rlf(einv, sm), npx = pp_rlf(fx, sm), npy = pp_rlf(fy, sm);
+                if (main_element == 0) { s0 = sm; vx0 = nvx; vy0 = nvy; in0 = nin; px0 = npx; py0 = npy; }
+                else if (main_element == 1) { s1 = sm; vx1 = nvx; vy1 = nvy; in1 = nin; px1 = npx; py1 = npy; }
+                else if (main_element == 2) { s2 = sm; vx2 = nvx; vy2 = nvy; in2 = nin; px2 = npx; py2 = npy; }
+                else { s3 = sm; vx3 = nvx; vy3 = nvy; in3 = nin; px3 = npx; py3 = npy; }
+            }
+            {
+                float dx = px1 - px3;
+                float dy = py1 - py3;
+                const float width = dx * base_a + dy * base_b;
+                dx = px2 - px0;
+                dy = py2 - py0;
+                const float height = -dx * base_b + dy * base_a;
+                const float area = width * height;
+                if (area <= minarea) {
+                    minarea = area;
+                    buf_i0 = s3;
+                    buf1 = base_a; buf2 = width; buf3 = base_b; buf4 = height;
+                    buf_i5 = s0;
+                }
+            }
+        }
+        const float A1 = buf1, B1 = buf3, A2 = -buf3, B2 = buf1;
+        const float h0x = pp_rlf(fx, buf_i0), h0y = pp_rlf(fy, buf_i0), h5x = pp_rlf(fx, buf_i5), h5y = pp_rlf(fy, buf_i5);
+        const float C1 = A1 * h0x + h0y * B1;
+        const float C2 = A2 * h5x + h5y * B2;
+        const float idet = 1.f / (A1 * B2 - A2 * B1);
+        const float ox = (C1 * B2 - C2 * B1) * idet;
+        const float oy = (A1 * C2 - A2 * C1) * idet;
+        const float o1x = A1 * buf2, o1y = B1 * buf2, o2x = A2 * buf4, o2y = B2 * buf4;
+        cxr = ox + (o1x + o2x) * 0.5f;
+        cyr = oy + (o1y + o2y) * 0.5f;
+        bw = (float)sqrt((double)o1x * o1x + (double)o1y * o1y);
+        bh = (float)sqrt((double)o2x * o2x + (double)o2y * o2y);
+        angle = (float)atan2((double)o1y, (double)o1x);
+    } else if (n == 2) {
+        const float x0 = pp_rlf(fx, 0), y0 = pp_rlf(fy, 0), x1 = pp_rlf(fx, 1), y1 = pp_rlf(fy, 1);
+        cxr = (x0 + x1) * 0.5f;
+        cyr = (y0 + y1) * 0.5f;
+        const double dx = x1 - x0, dy = y1 - y0;
+        bw = (float)sqrt(dx * dx + dy * dy);
+        bh = 0.f;
+        angle = (float)atan2(dy, dx);
+    } else if (n == 1) {
+        cxr = pp_rlf(fx, 0); cyr = pp_rlf(fy, 0);
+    }
+    angle = (float)(angle * 180 / CV_PI);
+    // RotatedRect::points
+    const double _angle = angle * CV_PI / 180.;
+    const float b = (float)cos(_angle) * 0.5f;
+    const float a = (float)sin(_angle) * 0.5f;
+    box8[0] = cxr - a * bh - b * bw;
+    box8[1] = cyr + b * bh - a * bw;
+    box8[2] = cxr + a * bh - b * bw;
+    box8[3] = cyr - b * bh - a * bw;
+    box8[4] = 2 * cxr - box8[0];
+    box8[5] = 2 * cyr - box8[1];
+    box8[6] = 2 * cxr - box8[2];
+    box8[7] = 2 * cyr - box8[3];
+}
+
 // One wave, one kept object: row extents (global, 2 ints per row from row y0) -> hull -> minAreaRect -> boxPoints -> rounded quad
 // into st[1..8].  rws: the wave's LDS scratch of 12 * h + 4 ints (row extents | hull points | edge table).  ATOMIC: the
 // extents were accumulated by atomics of THIS launch (the fused one-launch front end): read them past the CU's vector L1.
 template <bool ATOMIC>
 __device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ g, int nrows, int y0, int h, int lane, int scale,
-                                              int *__restrict__ st)
+                                              int *__restrict__ st, bool serial_tail = false)
 {
 #pragma clang fp contract(off)
     ipt *pts = (ipt *)(rws + 2 * h);
@@ -239,6 +432,23 @@ __device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ 
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
+    if (cnt[0] + cnt[1] <= 64 && !serial_tail) {                  // wave-uniform: the polygon fits the wave's lanes (the usual case)
+        int X = 0, Y = 0;
+        if (lane < cnt[0] + cnt[1]) {
+            const ipt pv = pts[lane < cnt[0] ? lane : cnt[0] + (cnt[1] - 1 - (lane - cnt[0]))];   // the right chain reversed
+            X = pv.x; Y = pv.y;
+        }
+        const int nh = hull_finish_wave(X, Y, cnt[0], cnt[1], lane);
+        float box[8];
+        min_area_box_wave(X, Y, nh, lane, box);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[1 + j] = (int)rintf(box[j] * (float)scale);   // np.round: half to even
+            st[9] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     int nh = 0;
     if (lane == 0) hull_finish(pts, cnt[0], cnt[1], nh);
     nh = __builtin_amdgcn_readfirstlane(nh);
@@ -326,7 +536,7 @@ static size_t pp_front_lds_bytes(int hw, int root_cap)
 // Everything the block needs for its image(s); filled by the host (postprocess.hip pp_job_fill), passed by value.
 struct pp_lds_args {
     const float *logits;
-    int n, k_out, h, w, cap, n_cls, root_cap, poison, scale;
+    int n, k_out, h, w, cap, n_cls, root_cap, poison, scale, serial_tail;   // serial_tail: one-lane LDS form of the box fit (tests)
     float thr, min_area;
     int *binary_map, *g_nroots, *g_nkept, *g_owner, *g_roots, *g_kept, *stage, *ymax, *rows;
     float *vote;
@@ -630,7 +840,7 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
                     const int y0 = row_of(st[0]);
                     const int ym = __hip_atomic_load(&ymax[(size_t)img * cap + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int *g = rows + ((size_t)img * cap + k) * (size_t)(6 * h) + 2 * y0;
-                    pp_box_object<true>(scratch, g, ym - y0 + 1, y0, h, lane, scale, st);
+                    pp_box_object<true>(scratch, g, ym - y0 + 1, y0, h, lane, scale, st, A.serial_tail != 0);
                 }
         }
         // ---- vote (pp_vote_kernel): mean softmax over the filled region
