@@ -173,6 +173,28 @@ def forward(x, weights, fml_compatible=True, dtype=np.float64, return_all=False,
     return (logits, acts) if return_all else logits
 
 
+def forward_bn(x, weights_bn, fml_compatible=True, eps=1e-3, dtype=np.float64):
+    """The use_bn=True branch of conv_bn (net.py:248-250; never instantiated by the reference's own model builder, net.py:292-304
+    passes no use_bn): conv with bias and NO activation, keras BatchNormalization in inference mode (defaults: epsilon 1e-3,
+    gamma / beta / moving mean / moving variance per output channel), then ReLU.  weights_bn: per hidden layer its conv arrays
+    followed by [gamma, beta, moving_mean, moving_variance] (the get_weights() order of such a model), head last."""
+    x = np.asarray(x, dtype=dtype)
+    w = [np.asarray(a, dtype=dtype) for a in weights_bn]
+
+    def bn_relu(z, g, b, m, v):
+        return np.maximum((z - m) / np.sqrt(v + eps) * g + b, 0.0)
+    i = 0
+    for stride in (2, 1, 2):
+        z = separable_conv(x, w[i], w[i + 1], w[i + 2], stride, fml_compatible, relu=False)
+        x = bn_relu(z, *w[i + 3:i + 7])
+        i += 7
+    for d in DILATIONS:
+        z = dilated_conv(x, w[i], w[i + 1], d, relu=False)
+        x = bn_relu(z, *w[i + 2:i + 6])
+        i += 6
+    return x @ w[i][0, 0] + w[i + 1]
+
+
 def logit_threshold(pixel_threshold=0.5):
     """model_runner.py:37-38."""
     eps = 1e-9

@@ -16,10 +16,20 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def model_layers(c_in, n_classes):
-    """(layer name, [(weight name, shape)]) in model.layers order for net.py:278-314 (fml-compatible)."""
+def model_layers(c_in, n_classes, use_bn=False):
+    """(layer name, [(weight name, shape)]) in model.layers order for net.py:278-314 (fml-compatible); use_bn: the
+    conv_bn(..., use_bn=True) branch (net.py:248-250): a BatchNormalization and an Activation layer behind every hidden conv."""
     layers = [("input_1", [])]
     sep, conv, pad = 0, 0, 0
+    bn = [0]
+
+    def bn_layers():
+        if not use_bn:
+            return []
+        bn[0] += 1
+        n = f"batch_normalization_{bn[0]}"
+        return [(n, [(f"{n}/gamma:0", (24,)), (f"{n}/beta:0", (24,)), (f"{n}/moving_mean:0", (24,)), (f"{n}/moving_variance:0", (24,))]),
+                (f"activation_{bn[0]}", [])]
     cin = c_in
     for stride in (2, 1, 2):
         if stride == 2:
@@ -29,11 +39,13 @@ def model_layers(c_in, n_classes):
         n = f"separable_conv2d_{sep}"
         layers.append((n, [(f"{n}/depthwise_kernel:0", (3, 3, cin, 1)), (f"{n}/pointwise_kernel:0", (1, 1, cin, 24)),
                            (f"{n}/bias:0", (24,))]))
+        layers += bn_layers()
         cin = 24
     for _ in range(6):
         conv += 1
         n = f"conv2d_{conv}"
         layers.append((n, [(f"{n}/kernel:0", (3, 3, 24, 24)), (f"{n}/bias:0", (24,))]))
+        layers += bn_layers()
     conv += 1
     n = f"conv2d_{conv}"
     layers.append((n, [(f"{n}/kernel:0", (1, 1, 24, 1 + n_classes)), (f"{n}/bias:0", (1 + n_classes,))]))
@@ -53,9 +65,9 @@ def save_weights_to_hdf5_group(g, layers, rng, **dset_kw):
             d[:] = val
 
 
-def write_model(path, c_in, n_classes, seed, whole_model, libver=None, **dset_kw):
+def write_model(path, c_in, n_classes, seed, whole_model, libver=None, use_bn=False, **dset_kw):
     rng = np.random.default_rng(seed)
-    layers = model_layers(c_in, n_classes)
+    layers = model_layers(c_in, n_classes, use_bn)
     with h5py.File(path, "w", libver=libver) as f:
         if whole_model:                                          # keras.Model.save
             f.attrs["keras_version"] = b"2.2.4"
@@ -75,6 +87,7 @@ if __name__ == "__main__":
     write_model(os.path.join(HERE, "keras_weights_grey_cls2.h5"), 1, 2, 101, False)                # save_weights
     write_model(os.path.join(HERE, "keras_model_grey_gzip.h5"), 1, 0, 102, True,                    # chunked + shuffle + deflate
                 chunks=True, compression="gzip", shuffle=True)
+    write_model(os.path.join(HERE, "keras_model_rgb_bn.h5"), 3, 0, 104, True, use_bn=True)          # conv_bn(use_bn=True) model
     # libver="latest" (not what Keras writes): v2 object headers + compact link messages for small groups ...
     rng = np.random.default_rng(103)
     with h5py.File(os.path.join(HERE, "tiny_latest.h5"), "w", libver="latest") as f:

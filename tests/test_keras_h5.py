@@ -85,3 +85,23 @@ def test_reference_pickled_config_loads(tmp_path):
     assert cfg.get_preprocessing_type() is PreprocessingType.MOBILENET_LIKE and cfg.get_max_side() == 1024
     assert not cfg.is_grey() and cfg.get_min_pixels_for_detection() == 7
     assert NetManager(str(tmp_path)).build_model.__self__._net_config.get_scale() == 4     # NetManager(log_dir) loads it
+
+
+def test_batchnorm_model_file_is_read_and_folded(golden_dir):
+    """A model built with conv_bn(use_bn=True) (net.py:248-250): the file carries a batch_normalization_k group behind every
+    hidden conv; the reader returns get_weights() order (conv arrays, then gamma, beta, moving_mean, moving_variance per layer)
+    and fold_batchnorm turns the 59 arrays into the 29 of the BN-free architecture."""
+    from ubdvss_amd.net import fold_batchnorm
+    arrays, names = keras_h5.read_keras_weights(os.path.join(golden_dir, "keras_model_rgb_bn.h5"))
+    assert len(arrays) == 59
+    assert names[:7] == ["separable_conv2d_1/depthwise_kernel:0", "separable_conv2d_1/pointwise_kernel:0", "separable_conv2d_1/bias:0",
+                         "batch_normalization_1/gamma:0", "batch_normalization_1/beta:0", "batch_normalization_1/moving_mean:0",
+                         "batch_normalization_1/moving_variance:0"]
+    assert names[-8:-2] == ["conv2d_6/kernel:0", "conv2d_6/bias:0", "batch_normalization_9/gamma:0", "batch_normalization_9/beta:0",
+                            "batch_normalization_9/moving_mean:0", "batch_normalization_9/moving_variance:0"]
+    arrays = [np.abs(a) + 0.1 if n.endswith("moving_variance:0") else a for a, n in zip(arrays, names)]   # the fixture's noise can be negative
+    folded = fold_batchnorm(arrays)
+    assert [a.shape for a in folded] == [tuple(s) for s in weight_shapes(3, 0)]
+    s = arrays[3] / np.sqrt(arrays[6].astype(np.float64) + 1e-3)
+    assert np.allclose(folded[1], arrays[1] * s, rtol=1e-6) and np.allclose(folded[2], (arrays[2] - arrays[5]) * s + arrays[4], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(folded[0], arrays[0]) and np.array_equal(folded[-1], arrays[-1])

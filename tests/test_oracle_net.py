@@ -102,3 +102,28 @@ def test_golden_net_cases(golden_dir, manifest):
         w = onet.unflatten_weights(d["params"], int(d["c_in"]), int(d["n_classes"]))
         lg = otorch.forward_numpy(d["x"], w, bool(d["fml"]), torch.float64)
         assert np.abs(lg - d["logits"]).max() < 1e-6
+
+
+def test_batchnorm_fold_equals_the_bn_branch():
+    """net.py:248-250 (use_bn=True: conv -> BatchNormalization -> ReLU; never instantiated by the reference's own builder):
+    ubdvss_amd.net.fold_batchnorm turns the 59 arrays of such a model into the 29 of the BN-free architecture; the folded
+    model computes what the oracle's statement of the BN branch computes."""
+    from ubdvss_amd.net import fold_batchnorm
+    rng = np.random.default_rng(17)
+    for cin, ncls in ((3, 0), (1, 2)):
+        w = onet.init_weights(50 + cin, cin, ncls, bias_scale=0.3, dtype=np.float64)
+        wbn, i = [], 0
+        for n_conv in (3, 3, 3, 2, 2, 2, 2, 2, 2):
+            wbn += w[i:i + n_conv]
+            wbn += [rng.uniform(0.5, 1.5, 24), rng.normal(0, 0.3, 24), rng.normal(0, 0.5, 24), rng.uniform(0.2, 2.0, 24)]
+            i += n_conv
+        wbn += w[i:]
+        assert len(wbn) == 59
+        x = rng.normal(0, 1, (2, 24, 40, cin))
+        ref = onet.forward_bn(x, wbn)
+        folded = fold_batchnorm(wbn)
+        assert [a.shape for a in folded] == [s for _, s in onet.weight_shapes(cin, ncls)]
+        got = onet.forward(x, folded)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())       # fp32 rounding of the folded arrays
+        with pytest.raises(ValueError):
+            fold_batchnorm(wbn[:-1])

@@ -158,6 +158,28 @@ def weight_shapes(c_in, n_classes):
     return shapes
 
 
+def fold_batchnorm(weights_bn, eps=1e-3):
+    """``get_weights()`` of a model built with ``conv_bn(..., use_bn=True)`` (net.py:225-252: conv with bias, no activation ->
+    BatchNormalization -> ReLU; Keras default epsilon 1e-3) -> the 29 arrays of the BN-free architecture that computes the
+    same function at inference time: with s = gamma / sqrt(moving_variance + eps) per output channel, the layer's last kernel
+    (pointwise of a separable layer, the HWIO kernel of a Conv2D) is scaled by s along its output axis and the bias becomes
+    (bias - moving_mean) * s + beta.  Per hidden layer the input holds its conv arrays followed by gamma, beta, moving_mean,
+    moving_variance; the 1x1 head (no BN) comes last.  Inference only: the train step has no BatchNormalization."""
+    w = [np.asarray(a, dtype=np.float64) for a in weights_bn]
+    if len(w) != 3 * 7 + 6 * 6 + 2:
+        raise ValueError(f"expected {3 * 7 + 6 * 6 + 2} arrays of a use_bn model, got {len(w)}")
+    out, i = [], 0
+    for n_conv in (3, 3, 3, 2, 2, 2, 2, 2, 2):
+        conv, (gamma, beta, mean, var) = w[i:i + n_conv], w[i + n_conv:i + n_conv + 4]
+        s = gamma / np.sqrt(var + eps)
+        out += [a.astype(np.float32) for a in conv[:-2]]
+        out.append((conv[-2] * s).astype(np.float32))       # output channels are the last axis of both kernel kinds
+        out.append(((conv[-1] - mean) * s + beta).astype(np.float32))
+        i += n_conv + 4
+    out += [w[i].astype(np.float32), w[i + 1].astype(np.float32)]
+    return out
+
+
 _DTYPES = {"float32": _lib.UBD_F32, "bfloat16": _lib.UBD_BF16, "float16": _lib.UBD_F16}
 
 
@@ -232,6 +254,8 @@ class Model:
 
     def set_weights(self, weights):
         shapes = weight_shapes(self.c_in, self.n_classes)
+        if len(weights) == len(shapes) + 4 * 9:             # a use_bn=True model (net.py:248-250): inference-time fold
+            weights = fold_batchnorm(weights)
         if len(weights) != len(shapes):
             raise ValueError(f"expected {len(shapes)} weight arrays, got {len(weights)}")
         for w, s in zip(weights, shapes):
