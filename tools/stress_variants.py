@@ -35,5 +35,25 @@ for (n, h, w) in shapes:
         b = model({"UBD_STEM": "unfused"}).predict_on_device(inp).clone()
         ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
         print(f"{n}x{h}x{w} fp32 net, {name} input, stem fused123 == unfused: {ok}", flush=True)
+# ---- repeat runs at the headline sizes: every launch of the persistent kernels must reproduce the first one bit for bit
+REPS = int(os.environ.get("UBD_VARIANT_REPEATS", "200"))
+x = torch.from_numpy(synthetic.noise_images(5, 32, 512, 512, 3)).cuda()
+for name, env, kw in (("fp32 one-kernel stem + Winograd", {"UBD_STEM": "fused123"}, {}), ("fp16 staged dilated forward", {}, {"dtype": "float16"})):
+    m = model(env, **kw)
+    first = m.predict_on_device(x).clone()
+    diff = sum(0 if torch.equal(m.predict_on_device(x), first) else 1 for _ in range(REPS))
+    bad += diff
+    print(f"{name}: {REPS} launches at 32 x 512 x 512, {diff} differ from the first", flush=True)
+lab = synthetic.rectangle_maps(9, 64, 128, 128)
+xt = torch.from_numpy(synthetic.textured_images(10, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+y = torch.from_numpy(lab).cuda()
+t = Trainer(model({}, dtype="bfloat16"), Adam())
+t.backward_on_device(xt, y); g0 = t.grads.clone()
+diff = 0
+for _ in range(REPS):
+    t.backward_on_device(xt, y)
+    diff += 0 if torch.equal(t.grads, g0) else 1
+bad += diff
+print(f"bf16 train step (fused dilated backward): {REPS} passes at 64 x 512 x 512, {diff} differ from the first", flush=True)
 print("MISMATCHES:", bad)
 sys.exit(1 if bad else 0)
