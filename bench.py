@@ -561,6 +561,26 @@ def main():
 
     latency = time_latency() if (world == 1 and rank == 0) else None
 
+    # ---- extra: the PCIe-inclusive rate -- ModelRunner.predict with HOST numpy input (the reference's calling convention,
+    #      model_runner.py:105-138): H2D of the batch, forward, device postprocess, D2H of maps / logits / lists, python lists
+    #      of ObjectMarkup.  Never `value` (the bench contract times HBM-resident input); reported so that it is measured.
+    def time_host_path():
+        res = {"protocol": "ModelRunner.predict(model, numpy batch of 32 x 512 x 512 x 3) -> (maps, class logits, object lists), wall clock, "
+                           "median of 8 after 2 warm-up calls; pageable host memory"}
+        hr = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
+        x_u8 = synthetic.textured_images(4 + rank, labels, 4, C_IN)
+        for name, arr in (("uint8", x_u8), ("float32", x_u8.astype(np.float32) / 127.5 - 1.0)):
+            for _ in range(2):
+                hr.predict(model, arr)
+            ts = []
+            for _ in range(8):
+                t0 = time.perf_counter(); hr.predict(model, arr); ts.append(time.perf_counter() - t0)
+            med = float(np.median(ts))
+            res[name] = {"ms_per_batch": round(med * 1e3, 3), "images_per_s": round(BATCH / med, 1), "h2d_MB": round(arr.nbytes / 1e6, 1)}
+        return res
+
+    host_path = time_host_path() if (world == 1 and rank == 0) else None
+
     line = None
     if rank == 0:
         # ---- parts: net only / postprocess only (rectangle maps) -- HIP events on the launch stream
@@ -601,7 +621,8 @@ def main():
         traffic = None
         try:
             vals = {}
-            for ln in open(os.path.join(ROOT, "profiles", "r02_pmc_dilconv_wino.txt")):
+            pmc_file = "r03_pmc_dilconv_wino.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_dilconv_wino.txt")) else "r02_pmc_dilconv_wino.txt"
+            for ln in open(os.path.join(ROOT, "profiles", pmc_file)):
                 parts = ln.split()
                 if len(parts) >= 2:
                     vals[parts[0]] = float(parts[1])
@@ -628,7 +649,7 @@ def main():
                 break
         roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
-                    "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r02_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
+                    "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r03_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
                     "profile_avg_us": profile_avg_us, "profile_file": profile_file,
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
                     "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
@@ -655,7 +676,7 @@ def main():
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
-            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5, "latency_batch1": latency,
+            "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5, "latency_batch1": latency, "pcie_inclusive_host_numpy": host_path,
             "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},

@@ -24,6 +24,21 @@ else:
 torch.cuda.synchronize()
 PY
 i=0
+if [ -n "$UBD_PMC_ONLY" ]; then   # one custom counter set instead of the standard passes
+  rm -rf /tmp/pmcx
+  rocprofv3 --kernel-trace --pmc $UBD_PMC_ONLY --output-format csv -d /tmp/pmcx -- python3 /tmp/fwd_once.py > /dev/null 2>&1
+  f=$(find /tmp/pmcx -name "*counter_collection.csv" | head -1)
+  python3 - "$f" "$PAT" <<'PY' >> "$OUT"
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if sys.argv[2] in r["Kernel_Name"]:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    print(k, sum(v) / len(v), "n=", len(v))
+PY
+  cat "$OUT"; exit 0
+fi
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmc$i
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc$i -- python3 /tmp/fwd_once.py > /dev/null 2>&1

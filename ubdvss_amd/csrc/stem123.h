@@ -220,7 +220,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         const int ar = (live ? p : 0) / X::AC, ac = (live ? p : 0) - ar * X::AC + 1;
         u_rc[k] = live ? ((ar << 8) | ac) : -1;
     }
-    const int qc = q < CIN ? q : 0;
+    const int qc = q < CIN ? q : CIN - 1;                         // lanes without a channel (zero weights) read what their neighbours read: an LDS broadcast, not a second address on the same banks
     // ---- phase A constants (stem23.h, CARRY variant)
     const int half = wid & 1, rg = wid >> 1;
     const int rb = rg == 0 ? 0 : 2 * rg + 1, rw = rg == 0 ? 3 : 2;

@@ -20,6 +20,7 @@ L_DETECTION_WEIGHT = 1.
 L_CLASSIFICATION_WEIGHT = 1.
 
 _handles = {}
+_workspaces = {}          # device -> uint8 scratch reused between calls (grown on demand)
 
 
 def _handle(n_classes, device):
@@ -54,7 +55,11 @@ def loss_and_grad(y_true, y_pred, want_grad=True):
     hd = _handle(k - 1, device)
     loss = torch.zeros(16, dtype=torch.float32, device=device)
     grad = torch.empty_like(yp) if want_grad else None
-    ws = torch.empty(int(lib.ubd_loss_workspace_bytes(hd, n, h, w)), dtype=torch.uint8, device=device)
+    nbytes = int(lib.ubd_loss_workspace_bytes(hd, n, h, w))
+    ws = _workspaces.get(str(device))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[str(device)] = ws
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     _lib.check(lib.ubd_loss(hd, yp.data_ptr(), yt.data_ptr(), n, h, w, loss.data_ptr(),
                             grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(), stream), "ubd_loss")

@@ -13,6 +13,16 @@ from . import _lib
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 _handles = {}
+_workspaces = {}          # (device, bytes bucket) -> uint8 tensor: the static entry points reuse their scratch between calls
+
+
+def _workspace(device, nbytes):
+    """Device scratch of at least nbytes, kept per device (grown when a bigger request comes; never shrunk)."""
+    ws = _workspaces.get(str(device))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[str(device)] = ws
+    return ws
 
 
 def _handle(n_classes, device):
@@ -51,7 +61,7 @@ class SegmapManager:
         quads = torch.zeros((1, cap, 8), dtype=torch.int32, device=device)
         classes = torch.zeros((1, cap), dtype=torch.int32, device=device)
         counts = torch.zeros((1,), dtype=torch.int32, device=device)
-        ws = torch.empty(int(lib.ubd_postprocess_workspace_bytes(hd, 1, h, w, cap)), dtype=torch.uint8, device=device)
+        ws = _workspace(device, lib.ubd_postprocess_workspace_bytes(hd, 1, h, w, cap))
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         _lib.check(lib.ubd_postprocess(hd, lgt.data_ptr(), 1, h, w, 0.5, int(scale), float(min_area_threshold),
                                        None, quads.data_ptr(), classes.data_ptr(), counts.data_ptr(), cap,
