@@ -19,6 +19,14 @@
 // t + 1 (waves 4-7, which have no L3 row, take twice the L1 units).  Training keeps the separate kernels (it needs a1 and a2).
 #pragma once
 
+// a1 patch image of this kernel: pixel pitch 24 dwords = six 16-byte chunks; chunk c of the pixel in patch column `col` sits in
+// slot c ^ bit2(col) (c < 4) / 4 + ((c - 4) ^ bit3(col)) (c = 4, 5).  Found by enumerating swizzles under the LDS bank map of
+// MI355X_MICROARCH.md (16-lane groups of ds_read_b128, 32-lane groups of ds_read_b64, 8-lane groups of ds_write_b128): phase
+// A's three b128 + three b64 reads per row are conflict-free (4 + 2 LDS cycles), L1's chunk stores cost 8.7 + 8 cycles per unit
+// instead of 16 + 8 -- 1024 LDS cycles per tile against 1596 for the rotate-by-three-slots layout of stem23.h (which it keeps:
+// its image is written by LDS-DMA).  PMC: SQ_LDS_BANK_CONFLICT of the kernel in profiles/r03_pmc_stem123_fp32.txt.
+__device__ __forceinline__ int s123_slot(int c, int col) { return c < 4 ? (c ^ ((col >> 2) & 1)) : 4 + ((c - 4) ^ ((col >> 3) & 1)); }
+
 template <int CIN> struct s123_cfg {
     using B = s23_cfg;
     static constexpr int NT = B::NT, NW = B::NW;
@@ -228,11 +236,9 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     int ro4[3], ro2[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int pcol = pos + kx, rot = 3 * ((pcol >> 3) & 1);
-        int s4 = q + rot, s2 = 4 + (q >> 1) + rot;
-        s4 = s4 >= 6 ? s4 - 6 : s4; s2 = s2 >= 6 ? s2 - 6 : s2;
-        ro4[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s4;
-        ro2[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s2 + 2 * (q & 1);
+        const int pcol = pos + kx;
+        ro4[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s123_slot(q, pcol);
+        ro2[kx] = (rb * C::PW + pcol) * UBD_C + 4 * s123_slot(4 + (q >> 1), pcol) + 2 * (q & 1);
     }
     const int l2w = (rb * C::LC + pos) * C::LP + 4 * q;
     const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;
@@ -327,15 +333,10 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc0[k][r] = ubd_relu_cap(acc0[k][r], cap); acc1[k][r] = ubd_relu_cap(acc1[k][r], cap); }
             if (rc >= 0) {
-                const int rot0 = 3 * ((ac >> 3) & 1);
-                int s4 = q + rot0;
-                s4 = s4 >= 6 ? s4 - 6 : s4;
-                float *dst = a1p + (ar * C::PW + ac) * UBD_C + 4 * s4;               // chunk q; chunk 4 + q (q < 2) sits 16 floats further, modulo the rotation
+                float *dst = a1p + (ar * C::PW + ac) * UBD_C + 4 * s123_slot(q, ac);  // chunk q; chunk 4 + q from the lanes q < 2
                 *(f32x4 *)dst = acc0[k];
                 if (q < 2) {                                                         // chunk 4 + q: slot (4 + q + 3f) % 6
-                    int s1 = 4 + q + rot0;
-                    s1 = s1 >= 6 ? s1 - 6 : s1;
-                    *(f32x4 *)(a1p + (ar * C::PW + ac) * UBD_C + 4 * s1) = acc1[k];
+                    *(f32x4 *)(a1p + (ar * C::PW + ac) * UBD_C + 4 * s123_slot(4 + q, ac)) = acc1[k];
                 }
             }
         }
