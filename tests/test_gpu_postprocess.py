@@ -345,3 +345,37 @@ def test_postprocess_stress_in_pipelined_runner():
         pending = (k, out)
     piped.synchronize()
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("grey,u8", [(False, False), (False, True), (True, False), (True, True)])
+def test_postprocess_inside_every_stem_kernel_variant(grey, u8, monkeypatch):
+    """ubd_forward_postprocess through every instantiation of the one-kernel stem (grey / RGB, fp32 fed as it is / uint8 with the
+    fused preprocessing), with MORE maps than the kernel has blocks (UBD_TEST_NUM_CUS=2: each block does 17 maps in turn, then
+    joins the strip queue), maps of another shape than the pass's own, classes, and the LDS poison / integrity mode: the lists
+    equal the stand-alone postprocess's, the logits equal the plain forward pass's."""
+    from ubdvss_amd import PreprocessingType
+    monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
+    monkeypatch.setenv("UBD_STEM", "fused123")
+    monkeypatch.setenv("UBD_PP_POISON", "1")
+    n_cls = 2
+    cfg = NetConfig(class_names=["a", "b"], grey=grey, preprocessing=PreprocessingType.MOBILENET_LIKE if u8 else PreprocessingType.NONE)
+    cin = 1 if grey else 3
+    model = Model(cfg, seed=2)
+    assert model.num_cus == 2
+    model.set_weights(onet.init_weights(7, cin, n_cls, bias_scale=0.2))
+    x = synthetic.noise_images(3, 3, 96, 160, cin, as_float=not u8)
+    xt = torch.from_numpy(x).cuda()
+    plain = model.predict_on_device(xt).clone()
+    maps = synthetic.rectangle_maps(91, 34, 48, 80, n_classes=n_cls)              # 34 maps for 2 blocks, not the pass's map shape
+    lg = torch.from_numpy(synthetic.logits_from_maps(maps, n_cls, seed=92)).cuda()
+    ref = model.postprocess_on_device(lg, 0.0, 4, 5, cap=64)
+    ref = [t.clone() for t in ref]
+    outs = model.alloc_postprocess_outputs(34, 48, 80, 64)
+    job = {"logits": lg, "logit_threshold": 0.0, "scale": 4, "min_area": 5, "cap": 64, "outputs": outs}
+    for _ in range(3):                                                           # repeated: the strip counters reset themselves
+        outs[1].fill_(-3)
+        got = model.predict_on_device(xt, postprocess=job)
+        torch.cuda.synchronize()
+        assert torch.equal(got, plain)
+        assert _same_results((got,) + tuple(outs), (plain,) + tuple(ref))
+        assert int(outs[3].max()) <= 64                                          # no integrity flag in the counts
