@@ -379,3 +379,19 @@ def test_postprocess_inside_every_stem_kernel_variant(grey, u8, monkeypatch):
         assert torch.equal(got, plain)
         assert _same_results((got,) + tuple(outs), (plain,) + tuple(ref))
         assert int(outs[3].max()) <= 64                                          # no integrity flag in the counts
+
+
+def test_pipelined_runner_16bit_model_falls_back_to_back_to_back_calls():
+    """A 16-bit handle has no one-kernel stem: ubd_forward_postprocess makes the two calls one after the other; same results."""
+    cfg = NetConfig(grey=False)
+    model = Model(cfg, dtype="float16", seed=5)
+    model.set_weights(onet.init_weights(41, 3, 0, bias_scale=0.3))
+    serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
+    batches = []
+    for k in range(3):
+        labels = synthetic.rectangle_maps(70 + k, 34, 64, 64)
+        batches.append(torch.from_numpy(synthetic.textured_images(80 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda())
+    ref = [[t.clone() if t is not None else None for t in serial.predict_on_device(model, b)] for b in batches]
+    got = [piped.predict_on_device(model, b) for b in batches]
+    piped.synchronize()
+    assert _same_results(got[2], ref[2]) and _same_results(got[1], ref[1])
