@@ -15,6 +15,7 @@
 // Weight gradients: every block writes one row of a partial-sum matrix, reduce_partials_kernel adds the rows in a
 // fixed order into the flat gradient vector (Keras get_weights() order, same as the parameters).
 #include "common.h"
+#include "pack.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -64,53 +65,11 @@ template <> __device__ __forceinline__ f32x4 mfma16<_Float16>(u32x4 a, u32x4 b, 
 template <typename TX> struct UBD_G16 { static constexpr bool value = false; };
 template <> struct UBD_G16<__bf16> { static constexpr bool value = true; };
 
-#define UBD_BWD_DGRAD_FLOATS (UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
-#define UBD_BWD_SEP_FLOATS (6 * 2 * 64)
-#define UBD_BWD_DIRECT_FLOATS (UBD_BWD_DGRAD_FLOATS + 3 * UBD_BWD_SEP_FLOATS)
-#define UBD_BWD_FRAG_FLOATS (UBD_BWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)
 
-// ------------------------------------------------------------------------------------
-// Backward weight fragments:
-//   dgrad[L][t'][j][nt][lane] = W_L[8-t'][co' ][ci']   with ci' = input channel of the dgrad conv
-//        (= forward output channel) from (j, q) as in the forward packing, co' = (lane&15)+16nt
-//   seppwT[s][step][tile][lane]: A operand of the dDW product, A[rho = lane&15][k = q]
-//        = pw[ch(rho, tile)][co = 6q + step];   CIN==24: ch = 6*(rho>>2) + (rho&3) + 4*tile (tile 1: rho&3 < 2)
-//                                               CIN< 24: tile 0 only, ch = rho>>2 if (rho&3)==0 and ch < CIN
-// ------------------------------------------------------------------------------------
-struct pack_bwd_args {
-    size_t off_sep_pw[3];
-    size_t off_dil_k[UBD_NUM_DIL];
-    int c_in;
-};
-
+// ------------------------------------------------------------------------------------ backward weight fragments (pack.h)
 __global__ void pack_bwd_kernel(const float *__restrict__ params, float *__restrict__ out, pack_bwd_args a)
 {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < UBD_BWD_DIRECT_FLOATS; idx += gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (idx < UBD_BWD_DGRAD_FLOATS) {
-            int L = idx / UBD_DIL_FRAG_FLOATS, r = idx % UBD_DIL_FRAG_FLOATS;
-            int lane = r & 63, nt = (r >> 6) & 1, tj = r >> 7, j = tj % 6, t = tj / 6;
-            int q = lane >> 4, cop = (lane & 15) + 16 * nt;
-            int cip = j < 4 ? 4 * q + j : 16 + 2 * q + (j - 4);
-            if (cop < UBD_C) v = params[a.off_dil_k[L] + ((size_t)(8 - t) * UBD_C + cop) * UBD_C + cip];
-        } else {
-            int r = idx - UBD_BWD_DGRAD_FLOATS;
-            int s = r / UBD_BWD_SEP_FLOATS;
-            r %= UBD_BWD_SEP_FLOATS;
-            int cin = s == 0 ? a.c_in : UBD_C;
-            int lane = r & 63, tile = (r >> 6) & 1, step = r >> 7;
-            int rho = lane & 15, q = lane >> 4;
-            int ch = -1;
-            if (cin == UBD_C) {
-                int sub = (rho & 3) + 4 * tile;
-                if (sub < 6) ch = 6 * (rho >> 2) + sub;
-            } else if (tile == 0 && (rho & 3) == 0 && (rho >> 2) < cin) {
-                ch = rho >> 2;
-            }
-            if (ch >= 0) v = params[a.off_sep_pw[s] + (size_t)ch * UBD_C + 6 * q + step];
-        }
-        out[idx] = v;
-    }
+    pack_bwd_body(params, out, a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 #define RP_COLS 16          // elements per block of reduce_partials_kernel
@@ -976,23 +935,48 @@ static int launch_head_wgrad(const ubd_handle *h, const void *a9, const float *d
 
 // Backward pass given the saved activations (element type TX): a1, a2 at half resolution, acts[0..6] = L3, L4..L9
 // outputs at quarter resolution; wfrag = forward fp32 fragments (depthwise / pointwise per-lane weights).
+// One launch in front of the bf16 train step: the four weight packers (fp32 stem fragments, 16-bit dilated fragments, backward
+// fragments, transposed 16-bit fragments: 48 blocks each) + zero gradient vector + zero loss scratch -- they were four ~5-us
+// kernels and two memset kernels scattered over the step, each serialised behind its predecessor (rocprofv3: 29 us of a 1.22-ms step).
+struct train_prologue_args {
+    pack_args pa;
+    pack_bwd_args pb;
+    size_t off0, layer_stride, n_params, loss_zero_words;
+    float *wfrag32, *bfrag, *grads;
+    unsigned *wfrag16, *frag16t, *loss_zero;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void train_prologue16_kernel(const float *__restrict__ params, train_prologue_args a)
+{
+    const int part = (int)blockIdx.x / 48, vtid = ((int)blockIdx.x % 48) * 256 + (int)threadIdx.x, vthreads = 48 * 256;
+    if (part == 0) pack_weights_body(params, a.wfrag32, a.pa, vtid, vthreads);
+    else if (part == 1) pack16_body<T>(params, a.wfrag16, a.off0, a.layer_stride, 0, vtid, vthreads);
+    else if (part == 2) pack_bwd_body(params, a.bfrag, a.pb, vtid, vthreads);
+    else pack16_body<T>(params, a.frag16t, a.off0, a.layer_stride, 1, vtid, vthreads);
+    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gthreads = (size_t)gridDim.x * 256;
+    for (size_t i = gtid; i < a.n_params; i += gthreads) a.grads[i] = 0.f;
+    for (size_t i = gtid; i < a.loss_zero_words; i += gthreads) a.loss_zero[i] = 0u;
+}
+
 template <typename TX>
 static int backward_impl(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H,
                          int W, const void *a1, const void *a2, const void *const *acts, const float *wfrag, float *dlogits,
-                         float *grads, char *ws, const train_layout &T, hipStream_t st)
+                         float *grads, char *ws, const train_layout &T, hipStream_t st, bool prepacked = false)
 {
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
     const int act_dtype = h->cfg.dtype;
     float *bfrag = (float *)(ws + T.off_bfrag);
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const long npix = (long)n * H4 * W4;
-    UBD_CHECK_HIP(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), st));
-    pack_bwd_args pa;
-    for (int s = 0; s < 3; ++s) pa.off_sep_pw[s] = h->off_sep_pw[s];
-    for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
-    pa.c_in = h->cfg.c_in;
-    hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
-    if (h->use_wino && !(sizeof(TX) == 2 && UBD_G16<TX>::value)) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
+    if (!prepacked) {                                          // (the bf16 step's prologue kernel has zeroed and packed everything)
+        UBD_CHECK_HIP(hipMemsetAsync(grads, 0, h->n_params * sizeof(float), st));
+        pack_bwd_args pa;
+        for (int s = 0; s < 3; ++s) pa.off_sep_pw[s] = h->off_sep_pw[s];
+        for (int k = 0; k < UBD_NUM_DIL; ++k) pa.off_dil_k[k] = h->off_dil_k[k];
+        pa.c_in = h->cfg.c_in;
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3(64), dim3(256), 0, st, params, bfrag, pa);
+        if (h->use_wino && !(sizeof(TX) == 2 && UBD_G16<TX>::value)) ubd_launch_pack_wino(h, params, bfrag + UBD_BWD_DIRECT_FLOATS, 1, st);
+    }
 
     float *gq[2] = {(float *)(ws + T.off_gq[0]), (float *)(ws + T.off_gq[1])};
     float *ddw3 = (float *)(ws + T.off_ddw3);
@@ -1008,7 +992,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         //      separable backward kernels; the transposed 16-bit fragments reuse the Winograd part of bfrag
         unsigned short *g16[2] = {(unsigned short *)gq[0], (unsigned short *)gq[0] + (size_t)npix * UBD_C};
         unsigned *frag16t = (unsigned *)(bfrag + UBD_BWD_DIRECT_FLOATS);
-        ubd_launch_pack16(h, params, frag16t, 1, st);
+        if (!prepacked) ubd_launch_pack16(h, params, frag16t, 1, st);
         if (h->k_out == 1) {                                   // one pass over A9 for both head gradients
             int g1 = (int)((npix * 3 + 255) / 256);
             if (g1 > h->num_cus * 6) g1 = h->num_cus * 6;
@@ -1153,14 +1137,27 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
                                     acts, (const float *)(ws + T.fwd.off_wfrag), dlogits, grads, ws, T, st);
     }
     UBD_REQUIRE(in_dtype == UBD_IN_F32 || in_dtype == UBD_IN_U8, "ubd_train_step: bad in_dtype %d", in_dtype);
-    rc = ubd_forward16_layout(h, params, images, in_dtype, preprocessing, n, height, width, logits, ws, T.fwd16, st);
+    const bool one_prologue = h->cfg.dtype == UBD_BF16;                          // configs[2] / configs[3]
+    if (one_prologue) {
+        train_prologue_args a;
+        for (int s = 0; s < 3; ++s) { a.pa.off_sep_dw[s] = h->off_sep_dw[s]; a.pa.off_sep_pw[s] = h->off_sep_pw[s]; a.pb.off_sep_pw[s] = h->off_sep_pw[s]; }
+        for (int k = 0; k < UBD_NUM_DIL; ++k) { a.pa.off_dil_k[k] = h->off_dil_k[k]; a.pb.off_dil_k[k] = h->off_dil_k[k]; }
+        a.pa.c_in = a.pb.c_in = h->cfg.c_in;
+        a.off0 = h->off_dil_k[0]; a.layer_stride = h->off_dil_k[1] - h->off_dil_k[0];
+        a.n_params = h->n_params; a.loss_zero_words = ubd_loss_zero_bytes() / 4;
+        a.wfrag32 = (float *)(ws + T.fwd16.off_wfrag32); a.wfrag16 = (unsigned *)(ws + T.fwd16.off_wfrag16);
+        a.bfrag = (float *)(ws + T.off_bfrag); a.frag16t = (unsigned *)(a.bfrag + UBD_BWD_DIRECT_FLOATS);
+        a.grads = grads; a.loss_zero = (unsigned *)(ws + T.off_loss);
+        hipLaunchKernelGGL((train_prologue16_kernel<__bf16>), dim3(4 * 48), dim3(256), 0, st, params, a);
+    }
+    rc = ubd_forward16_layout(h, params, images, one_prologue ? (in_dtype | UBD_IN_PREPACKED) : in_dtype, preprocessing, n, height, width, logits, ws, T.fwd16, st);
     if (rc) return rc;
-    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st, h);
+    rc = ubd_loss_impl(logits, h->k_out, y_true, npix, loss, dlogits, ws + T.off_loss, st, h, one_prologue);
     if (rc) return rc;
     for (int k = 0; k < 7; ++k) acts[k] = ws + T.fwd16.off_acts[k];
     if (h->cfg.dtype == UBD_BF16)
         return backward_impl<__bf16>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd16.off_a1, ws + T.fwd16.off_a2,
-                                     acts, (const float *)(ws + T.fwd16.off_wfrag32), dlogits, grads, ws, T, st);
+                                     acts, (const float *)(ws + T.fwd16.off_wfrag32), dlogits, grads, ws, T, st, true);
     return backward_impl<_Float16>(h, params, images, in_dtype, preprocessing, n, height, width, ws + T.fwd16.off_a1, ws + T.fwd16.off_a2,
                                    acts, (const float *)(ws + T.fwd16.off_wfrag32), dlogits, grads, ws, T, st);
 }

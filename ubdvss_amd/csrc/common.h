@@ -189,7 +189,8 @@ void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const f
                         const float *in, float *out, int n, int H4, int W4, hipStream_t st);
 int ubd_grid_for(long waves_needed, int num_cus, int waves_per_block, int blocks_per_cu);
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
-                  char *ws, hipStream_t st, ubd_handle *h = nullptr);
+                  char *ws, hipStream_t st, ubd_handle *h = nullptr, bool prezeroed = false);
+size_t ubd_loss_zero_bytes(void);
 extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h, int map_w);
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,

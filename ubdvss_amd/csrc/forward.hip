@@ -32,44 +32,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 //     pwfrag[(step*2 + nt)*64 + lane] = pw[ch][co]
 //     dwlane[(tap*6 + step)*64 + lane] = dw[tap][ch]
 // ------------------------------------------------------------------------------------
-struct pack_args {
-    size_t off_sep_dw[3], off_sep_pw[3];
-    size_t off_dil_k[UBD_NUM_DIL];
-    int c_in;
-};
-
+#include "pack.h"
 __global__ void pack_weights_kernel(const float *__restrict__ params, float *__restrict__ wfrag, pack_args a)
 {
-    const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
-    const int total = 3 * per_sep + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (idx < 3 * per_sep) {
-            int s = idx / per_sep, r = idx % per_sep;
-            int cin = s == 0 ? a.c_in : UBD_C;
-            if (r < UBD_SEP_FRAG_FLOATS) {
-                int lane = r & 63, nt = (r >> 6) & 1, step = r >> 7;
-                int q = lane >> 4, co = (lane & 15) + 16 * nt;
-                int ch = cin == UBD_C ? 6 * q + step : ((step == 0 && q < cin) ? q : -1);
-                if (ch >= 0 && co < UBD_C) v = params[a.off_sep_pw[s] + (size_t)ch * UBD_C + co];
-            } else {
-                r -= UBD_SEP_FRAG_FLOATS;
-                int lane = r & 63, ts = r >> 6, step = ts % 6, tap = ts / 6;
-                int q = lane >> 4;
-                int ch = cin == UBD_C ? 6 * q + step : ((step == 0 && q < cin) ? q : -1);
-                if (ch >= 0) v = params[a.off_sep_dw[s] + (size_t)tap * cin + ch];
-            }
-        } else {
-            int r = idx - 3 * per_sep;
-            int L = r / UBD_DIL_FRAG_FLOATS;
-            r %= UBD_DIL_FRAG_FLOATS;
-            int lane = r & 63, nt = (r >> 6) & 1, tj = r >> 7, j = tj % 6, t = tj / 6;
-            int q = lane >> 4, co = (lane & 15) + 16 * nt;
-            int ci = j < 4 ? 4 * q + j : 16 + 2 * q + (j - 4);
-            if (co < UBD_C) v = params[a.off_dil_k[L] + ((size_t)t * UBD_C + ci) * UBD_C + co];
-        }
-        wfrag[idx] = v;
-    }
+    pack_weights_body(params, wfrag, a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // ------------------------------------------------------------------------------------

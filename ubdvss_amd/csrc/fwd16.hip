@@ -12,6 +12,7 @@
 //                      the layer's weights live in 56 VGPRs.  At 16 bit the layer is HBM-bound (AI ~46 flop/B).
 //   head16_kernel      1x1 conv 24 -> K from 16-bit activations, fp32 logits.
 #include "common.h"
+#include "pack.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -76,33 +77,11 @@ __device__ __forceinline__ unsigned mask_pk16(unsigned m)
     return __builtin_bit_cast(unsigned, (u16x2)(__builtin_elementwise_min(p, one) * ones));
 }
 
-// ------------------------------------------------------------------------------------ pack
-// 16-bit B fragments of the dilated layers: lane (n = lane&15, q = lane>>4), chunk c, element j:
-//   k = 32c + 8q + j (flat (tap, ci) index, zero for k >= 216), co = n + 16 nt (zero for co >= 24)
-// transpose = 1: fragments of the data-gradient convolution, W'[t][ci'][co'] = W[8 - t][co'][ci'] (flipped taps,
-// channels swapped), same lane layout.
+// ------------------------------------------------------------------------------------ pack (pack.h)
 template <typename T>
 __global__ void pack16_kernel(const float *__restrict__ params, unsigned *__restrict__ out, size_t off0, size_t layer_stride, int transpose)
 {
-    const int total = UBD_NUM_DIL * UBD_DIL16_FRAG_U32;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int L = idx / UBD_DIL16_FRAG_U32;
-        int r = idx % UBD_DIL16_FRAG_U32;
-        const int dw = r & 3, lane = (r >> 2) & 63, cn = r >> 8, nt = cn & 1, c = cn >> 1;
-        const int q = lane >> 4, co = (lane & 15) + 16 * nt;
-        const float *wk = params + off0 + (size_t)L * layer_stride;
-        unsigned short h[2];
-        for (int e = 0; e < 2; ++e) {
-            const int k = 32 * c + 8 * q + 2 * dw + e;
-            float v = 0.f;
-            if (k < 216 && co < UBD_C) {
-                if (!transpose) v = wk[(size_t)k * UBD_C + co];
-                else { const int t = k / UBD_C, ci = k - t * UBD_C; v = wk[((size_t)(8 - t) * UBD_C + co) * UBD_C + ci]; }
-            }
-            h[e] = to_bits<T>(v);
-        }
-        out[idx] = (unsigned)h[0] | ((unsigned)h[1] << 16);
-    }
+    pack16_body<T>(params, out, off0, layer_stride, transpose, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // ------------------------------------------------------------------------------------ shared epilogue

@@ -244,14 +244,55 @@ __global__ __launch_bounds__(1024) void loss_tiescan_kernel(unsigned *blockties,
     if (t == nblocks - 1) blockties[nblocks] = s[t];
 }
 
+// sum_hard / sum_cls / cls_correct are passed in: inside loss_grad_kernel (last block out) they are read past the vector L1
+__device__ __forceinline__ void loss_finalize_body(const loss_hdr *hdr, double sum_hard, double sum_cls, int cls_correct, long npix, int n_cls,
+                                                   float *loss4)
+{
+    const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
+    const long n_neg_l = npix - hdr->n_pos;
+    const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
+    double hard = sum_hard / (double)hdr->k;
+    if (hard != hard) hard = 0.0;                                  // losses.py:117-121
+    const double det = 15.0 * hdr->sum_pos / n_pos + 1.0 * hdr->sum_neg / n_neg + 5.0 * hard;
+    const double cls = n_cls > 0 ? sum_cls / n_pos : 0.0;
+    loss4[0] = (float)(1.0 * det + (n_cls > 0 ? 1.0 * cls : 0.0));
+    loss4[1] = (float)det;
+    loss4[2] = (float)cls;
+    loss4[3] = (float)hdr->k;
+    // monitoring values of the Keras train step (losses.py:138-191, keras_metrics.py:110-172): loss components
+    // and the raw counters of the per-batch pixel metrics
+    loss4[4] = (float)(hdr->sum_pos / n_pos);
+    loss4[5] = (float)(hdr->sum_neg / n_neg);
+    loss4[6] = (float)hard;
+    loss4[7] = (float)hdr->n_pos;
+    loss4[8] = (float)hdr->tp;
+    loss4[9] = (float)hdr->tn;
+    loss4[10] = (float)hdr->fp;
+    loss4[11] = (float)(hdr->n_pos - hdr->tp);       // fn
+    loss4[12] = (float)cls_correct;
+    loss4[13] = (float)npix;
+    loss4[14] = 0.f;
+    loss4[15] = 0.f;
+}
+
+__global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, float *loss4)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    loss_finalize_body(hdr, hdr->sum_hard, hdr->sum_cls, hdr->cls_correct, npix, n_cls, loss4);
+}
+
 // ---- gradient + hard-negative / classification sums --------------------------------------------
 #define LOSS_GRAD_BLOCK 1024       // as loss_stats: four waves per SIMD on the one block a CU gets
 __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
                                                                const int *__restrict__ y_true, long npix, long chunk,
                                                                loss_hdr *hdr, const unsigned *__restrict__ blockties,
                                                                const float *__restrict__ ce_buf, float *__restrict__ dlogits,
-                                                               long npix_total, const unsigned *__restrict__ rank_ties, int rank)
+                                                               long npix_total, const unsigned *__restrict__ rank_ties, int rank,
+                                                               int raw_ties, float *__restrict__ loss4)
 {
+    // raw_ties: blockties holds the per-block COUNTS (no loss_tiescan launch): the block sums the counts in front of it itself.
+    // loss4 != nullptr: the last block out also evaluates the loss values (no loss_finalize launch).  Both are set on one GPU /
+    // with per-replica losses; the batch-global mode needs the host-enqueued collectives in between and keeps the two launches.
     __shared__ double s_red[LOSS_GRAD_BLOCK / 64];
     __shared__ unsigned s_wave_ties[LOSS_GRAD_BLOCK / 64];
     const unsigned T = hdr->T, need_eq = hdr->need_eq;
@@ -262,7 +303,16 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
     const float w_cls = (float)(1.0 / n_pos);
     const int n_cls = k_out - 1;
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
-    unsigned tie_base = blockties[blockIdx.x];          // ties before this iteration of this block
+    unsigned tie_base;                                  // ties before this iteration of this block
+    if (raw_ties) {
+        const double before = block_reduce_sum(threadIdx.x < blockIdx.x ? (double)blockties[threadIdx.x] : 0.0, s_red);   // grid <= LOSS_MAX_BLOCKS <= block size
+        if (threadIdx.x == 0) s_wave_ties[0] = (unsigned)before;          // the sum is valid in thread 0: hand it to everybody
+        __syncthreads();
+        tie_base = s_wave_ties[0];
+        __syncthreads();
+    } else {
+        tie_base = blockties[blockIdx.x];
+    }
     for (int j = 0; j < rank; ++j) tie_base += rank_ties[j];    // batch-global mode: the ranks before this one hold the lower flat indices
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double s_hard = 0, s_cls = 0;
@@ -327,36 +377,18 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_cls, r);
     r = block_reduce_sum((double)c_correct, s_red);
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->cls_correct, (int)r);
-}
-
-__global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, float *loss4)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    const double n_pos = hdr->n_pos > 1 ? (double)hdr->n_pos : 1.0;
-    const long n_neg_l = npix - hdr->n_pos;
-    const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
-    double hard = hdr->sum_hard / (double)hdr->k;
-    if (hard != hard) hard = 0.0;                                  // losses.py:117-121
-    const double det = 15.0 * hdr->sum_pos / n_pos + 1.0 * hdr->sum_neg / n_neg + 5.0 * hard;
-    const double cls = n_cls > 0 ? hdr->sum_cls / n_pos : 0.0;
-    loss4[0] = (float)(1.0 * det + (n_cls > 0 ? 1.0 * cls : 0.0));
-    loss4[1] = (float)det;
-    loss4[2] = (float)cls;
-    loss4[3] = (float)hdr->k;
-    // monitoring values of the Keras train step (losses.py:138-191, keras_metrics.py:110-172): loss components
-    // and the raw counters of the per-batch pixel metrics
-    loss4[4] = (float)(hdr->sum_pos / n_pos);
-    loss4[5] = (float)(hdr->sum_neg / n_neg);
-    loss4[6] = (float)hard;
-    loss4[7] = (float)hdr->n_pos;
-    loss4[8] = (float)hdr->tp;
-    loss4[9] = (float)hdr->tn;
-    loss4[10] = (float)hdr->fp;
-    loss4[11] = (float)(hdr->n_pos - hdr->tp);       // fn
-    loss4[12] = (float)hdr->cls_correct;
-    loss4[13] = (float)npix;
-    loss4[14] = 0.f;
-    loss4[15] = 0.f;
+    if (loss4 && threadIdx.x == 0) {
+        // last block out: every block's sums have been added at the L2 by then (the counter add follows them in program order
+        // on the same lane; the loads below go past this CU's vector L1, which may still hold the header as the kernel found it)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned done = __hip_atomic_fetch_add(&hdr->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            const double sh = __hip_atomic_load(&hdr->sum_hard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double sc = __hip_atomic_load(&hdr->sum_cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int cc = __hip_atomic_load(&hdr->cls_correct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss_finalize_body(hdr, sh, sc, cc, npix_total, k_out - 1, loss4);
+        }
+    }
 }
 
 // h != nullptr with a UBD_COMM_GLOBAL_LOSS communicator: the reductions of losses.py:86-126 (n_pos, n_neg, the two means, the
@@ -365,8 +397,10 @@ __global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, 
 // Eight small collectives on the caller's stream: (sums, counters, level-0 histogram), the two refined histograms, the tie
 // counts (all-gather), (hard-negative / classification sums, class hits).  Integer histograms make every rank select the
 // same threshold bit pattern; ties at the threshold go to the lower GLOBAL flat index like tf.nn.top_k.
+size_t ubd_loss_zero_bytes(void) { return LOSS_HDR_BYTES + 3 * 2048 * sizeof(unsigned); }   // header + the three histograms: zero before every evaluation
+
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
-                  char *ws, hipStream_t st, ubd_handle *h)
+                  char *ws, hipStream_t st, ubd_handle *h, bool prezeroed)
 {
     loss_layout L;
     loss_layout_compute(npix, &L);
@@ -380,7 +414,7 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     UBD_REQUIRE(world <= 256, "ubd_loss: batch-global loss supports at most 256 ranks");
     const long npix_total = npix * world;
     UBD_REQUIRE(npix_total < (1L << 31), "ubd_loss: too many pixels in the global batch");
-    UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_blockties, st));     // header + 3 histograms
+    if (!prezeroed) UBD_CHECK_HIP(hipMemsetAsync(ws, 0, L.off_blockties, st));     // header + 3 histograms (the bf16 train step's prologue kernel has done it)
     int grid = (int)((npix + LOSS_BLOCK - 1) / LOSS_BLOCK);
     if (grid > LOSS_MAX_BLOCKS) grid = LOSS_MAX_BLOCKS;
     long chunk = (npix + grid - 1) / grid;
@@ -398,15 +432,18 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     hipLaunchKernelGGL(loss_hist_kernel, dim3(grid), dim3(LOSS_BLOCK), 0, st, ce, npix, npix_total, hdr, hist + 2048, hist + 4096, 2);
     if (glob && (rc = ubd_comm_allreduce_raw(h, hist + 4096, 2048, UBD_RED_U32, st))) return rc;
     hipLaunchKernelGGL(loss_tiecount_kernel, dim3(cgrid), dim3(LOSS_BLOCK), 0, st, ce, npix, npix_total, chunk, hdr, hist + 4096, blockties);
-    hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
-    if (glob && (rc = ubd_comm_allgather_u32(h, blockties + cgrid, rankties, st))) return rc;     // this rank's tie count -> everyone
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
-                       npix_total, rankties, rank);
     if (glob) {
+        hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
+        if ((rc = ubd_comm_allgather_u32(h, blockties + cgrid, rankties, st))) return rc;     // this rank's tie count -> everyone
+        hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
+                           npix_total, rankties, rank, 0, (float *)nullptr);
         if ((rc = ubd_comm_allreduce_raw(h, &hdr->sum_hard, 2, UBD_RED_F64, st))) return rc;
         if ((rc = ubd_comm_allreduce_raw(h, &hdr->cls_correct, 1, UBD_RED_I32, st))) return rc;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix_total, k_out - 1, loss);
+    } else {                                             // one launch: prefix of the tie counts, gradient, loss values
+        hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
+                           npix_total, rankties, rank, 1, loss);
     }
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix_total, k_out - 1, loss);
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
 }
