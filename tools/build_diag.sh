@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../ubdvss_amd/csrc"
 mkdir -p _obj_diag
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
 pids=()
 for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   extra=""
@@ -15,5 +15,5 @@ for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libubd_hip_diag.so _obj_diag/*.o -ldl
-echo "built libubd_hip_diag.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../${DIAG_OUT:-libubd_hip_diag.so} _obj_diag/*.o -ldl
+echo "built ${DIAG_OUT:-libubd_hip_diag.so}"

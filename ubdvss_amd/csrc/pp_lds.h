@@ -694,14 +694,34 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
     // nodes at a grandparent read earlier and can land after the owner of that node has stored its final root, leaving a
     // stale non-root there -- the round-2 wrong-quad defect.)  Any value a concurrent reader sees in lab[x] is an ancestor
     // of x or its root, so the walks stay correct while the stores land.
-    for (int node = tid; node <= hw; node += NT) {
 #ifdef UBD_PP_RACY_FLATTEN   // diagnostic build only (tools/prove_stress_power.sh): round 2's compressing find, to show that the stress test catches it
+    for (int node = tid; node <= hw; node += NT) {
         const int r = uf_find_wg(lab, node);
-#else
-        const int r = uf_find_ro_wg(lab, node);
-#endif
         __hip_atomic_store(&lab[node], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#else
+    // four independent walks per thread, interleaved: a walk is a chain of dependent LDS reads, and the wave waits for the longest
+    // of its 64 chains; four chains in flight hide most of that latency.  (Pointer jumping in rounds -- parent := grandparent until
+    // nothing changes -- was measured too: 26.6 k cycles against 20.5 k for this, the rounds re-read every node log2(depth) times.)
+    for (int node0 = tid; node0 <= hw; node0 += 4 * NT) {
+        int cur[4];
+        bool live[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = node0 + k * NT; live[k] = cur[k] <= hw; if (!live[k]) cur[k] = 0; }
+        for (;;) {
+            int nxt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[k] = __hip_atomic_load(&lab[cur[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool moved = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { moved |= nxt[k] != cur[k]; cur[k] = nxt[k]; }
+            if (!moved) break;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k]) __hip_atomic_store(&lab[node0 + k * NT], cur[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#endif
     // the owner / root-slot arrays were the union job queue until the barrier above: no entry is valid yet.  -1 = "no slot", so
     // a read of an entry this launch never wrote cannot return a plausible slot (stale queue jobs are small integers).
     {
@@ -712,6 +732,7 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
     PPSTAMP();
 
     // ---- roots (pp_roots_kernel)
+#pragma unroll 4
     for (int loc = tid; loc < hw; loc += NT) {
         if (!m[loc] || lab[loc + 1] != loc + 1) continue;
         const bool external = (loc < w) || (lab[loc + 1 - w] == 0);
@@ -723,11 +744,16 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
     __syncthreads();
     PPSTAMP();
 
-    // ---- owner (pp_owner_kernel)
-    for (int loc = tid; loc < hw; loc += NT) {
-        // the forest is flat (every entry is a root: checked by tests/test_gpu_postprocess.py under UBD_PP_POISON through the
-        // slot of a non-root being -1), and a slot is read only at a root's own raster-first pixel
-        int node = lab[loc + 1];
+    // ---- owner (pp_owner_kernel).  All pixels of a region share its owner, so only the region's raster-first pixel (the root)
+    // walks the nesting chain -- two to three dependent LDS reads per step -- and the others copy the root's result after a
+    // barrier (two reads): 40 k -> 25 k cycles on noise maps at 512 threads (in-kernel stamps).
+    // Roots are sparse (a few hundred per map), so a thread first COLLECTS its roots -- a scan of independent LDS reads -- and then
+    // the wave walks them round by round with all their lanes together: walking inside the scan cost every one of the 16 / 32
+    // scan iterations a full walk latency for the one or two lanes that had a root there (in-kernel stamps: 23 k of 34 k cycles).
+    auto owner_walk = [&](int loc) {
+        // the forest is flat (every entry is a root: checked under UBD_PP_POISON in the copy pass below), and a slot is read
+        // only at a root's own raster-first pixel
+        int node = loc + 1;
         int own = -1;
         for (int guard = 0; guard < 4096; ++guard) {
             if (poison && lab[node] != node) atomicOr(&ctr[2], 1);          // test mode: a non-root survived the flatten phase
@@ -740,19 +766,68 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
         }
         if (poison && (own < -1 || own >= ctr[0])) atomicOr(&ctr[2], 1);   // test mode: a slot that no root wrote
         own16[loc] = (short)own;
-        if (!TAIL && g_owner) g_owner[pbase + loc] = own;
+    };
+    for (int skip = 0;; skip += 6) {                                            // six roots per thread and round; more only on adversarial maps
+        int r0 = -1, r1 = -1, r2 = -1, r3 = -1, r4 = -1, r5 = -1, nr = 0;
+#pragma unroll 8
+        for (int loc = tid; loc < hw; loc += NT) {
+            const bool is_root = lab[loc + 1] == loc + 1;
+            if (is_root) {
+                const int j = nr - skip;
+                r0 = j == 0 ? loc : r0; r1 = j == 1 ? loc : r1; r2 = j == 2 ? loc : r2;
+                r3 = j == 3 ? loc : r3; r4 = j == 4 ? loc : r4; r5 = j == 5 ? loc : r5;
+                ++nr;
+            }
+        }
+        if (r0 >= 0) owner_walk(r0);
+        if (r1 >= 0) owner_walk(r1);
+        if (r2 >= 0) owner_walk(r2);
+        if (r3 >= 0) owner_walk(r3);
+        if (r4 >= 0) owner_walk(r4);
+        if (r5 >= 0) owner_walk(r5);
+        if (!__syncthreads_or(nr > skip + 6)) break;                            // block-uniform: somebody has more roots
     }
     __syncthreads();
+    // copy pass: root -> every pixel of its region, into the OTHER 16-bit array (the root-slot array is dead now; source and
+    // destination cannot alias, so four pixels' reads are in flight together), which then takes over as the owner map
+    {
+        short *const own_src = own16, *const own_dst = rs16;
+        for (int loc0 = tid; loc0 < hw; loc0 += 4 * NT) {
+            int node[4], own[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int loc = loc0 + k * NT; node[k] = loc < hw ? lab[loc + 1] : 0; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (poison && lab[node[k]] != node[k]) atomicOr(&ctr[2], 1);    // test mode: a non-root survived the flatten phase
+                own[k] = node[k] == 0 ? -1 : own_src[node[k] - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int loc = loc0 + k * NT;
+                if (loc < hw) {
+                    own_dst[loc] = (short)own[k];
+                    if (!TAIL && g_owner) g_owner[pbase + loc] = own[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    { short *t = own16; own16 = rs16; rs16 = t; }                              // owner map <-> free 16-bit array (box scratch of the tail)
     PPSTAMP();
     const int nroots = ctr[0];
     for (int s = tid; s < nroots; s += NT) area2[s] = 0;       // the forest is dead from here on
     __syncthreads();
     PPSTAMP();
 
-    // ---- area (pp_area_kernel)
-    for (int loc = tid; loc < hw; loc += NT) {
-        int key = -1, val = 0;
-        if (loc < hw) {
+    // ---- area (pp_area_kernel).  A thread's pixels lie NT / w rows apart, usually inside the same object: the contributions are
+    // summed in a register while the key does not change and flushed with one LDS atomic per run (integer adds: any order gives
+    // the same sum).  One object covering the map -- what an untrained network's logits look like -- had every interior pixel
+    // add to ONE LDS word: the atomics of a wave serialise.
+    {
+        int run_key = -1, run_sum = 0;
+#pragma unroll 4
+        for (int loc = tid; loc < hw; loc += NT) {
+            int key = -1, val = 0;
             const int y = row_of(loc), x = loc - y * w;
             if (x < w - 1 && y < h - 1) {
                 const int o0 = own16[loc], o1 = own16[loc + 1], o2 = own16[loc + w], o3 = own16[loc + w + 1];
@@ -763,8 +838,15 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
                     key = o;
                 }
             }
+            if (val != 0) {
+                if (key != run_key) {
+                    if (run_sum != 0) atomicAdd(&area2[run_key], run_sum);
+                    run_key = key; run_sum = 0;
+                }
+                run_sum += val;
+            }
         }
-        if (val != 0) atomicAdd(&area2[key], val);                                  // LDS atomic (a wave-level pre-reduction of equal keys measured slower: 14 k -> 20 k cycles)
+        if (run_sum != 0) atomicAdd(&area2[run_key], run_sum);
     }
     __syncthreads();
     PPSTAMP();
@@ -803,21 +885,42 @@ __device__ __forceinline__ void pp_image_lds(int *__restrict__ smem, const pp_ld
     __syncthreads();
     PPSTAMP();
 
-    // ---- extents (pp_extents_kernel)
-    for (int loc = tid; loc < hw; loc += NT) {
-        const int o = own16[loc];
-        if (o < 0) continue;
-        const int y = row_of(loc), x = loc - y * w;
-        const bool left_end = (x == 0) || own16[loc - 1] != o;
-        const bool right_end = (x == w - 1) || own16[loc + 1] != o;
-        const bool bottom = (y == h - 1) || own16[loc + w] != o;
-        if (!(left_end || right_end || bottom)) continue;
-        const int k = kept[o];
-        if (k < 0) continue;
-        int *r = rows + ((size_t)img * cap + k) * (size_t)(6 * h);
-        if (left_end) atomicMin(&r[2 * y], x);
-        if (right_end) atomicMax(&r[2 * y + 1], x);
-        if (bottom) atomicMax(&ymax[(size_t)img * cap + k], y);
+    // ---- extents (pp_extents_kernel): four pixels' neighbourhoods are read together; the last row of an object is taken per
+    // thread at the end of a run of equal owners (a thread walks down the map), not by one global atomic per bottom-edge pixel
+    {
+        int run_k = -1, run_y = 0;
+        for (int loc0 = tid; loc0 < hw; loc0 += 4 * NT) {
+            int o[4], ol[4], orr[4], yy[4], xx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int loc = loc0 + k * NT;
+                o[k] = loc < hw ? own16[loc] : -1;
+                yy[k] = row_of(loc); xx[k] = loc - yy[k] * w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int loc = loc0 + k * NT;
+                ol[k] = (o[k] >= 0 && xx[k] > 0) ? own16[loc - 1] : -2;
+                orr[k] = (o[k] >= 0 && xx[k] < w - 1) ? own16[loc + 1] : -2;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (o[k] < 0) continue;
+                const int kk = kept[o[k]];
+                if (kk != run_k) {
+                    if (run_k >= 0) atomicMax(&ymax[(size_t)img * cap + run_k], run_y);
+                    run_k = kk;
+                }
+                run_y = yy[k];
+                if (kk < 0) continue;
+                const bool left_end = ol[k] != o[k], right_end = orr[k] != o[k];
+                if (!(left_end || right_end)) continue;
+                int *r = rows + ((size_t)img * cap + kk) * (size_t)(6 * h);
+                if (left_end) atomicMin(&r[2 * yy[k]], xx[k]);
+                if (right_end) atomicMax(&r[2 * yy[k] + 1], xx[k]);
+            }
+        }
+        if (run_k >= 0) atomicMax(&ymax[(size_t)img * cap + run_k], run_y);
     }
     if (tid == 0) { g_nroots[img] = nroots; g_nkept[img] = ctr[1] | (ctr[2] << 30); }   // test mode: an integrity failure shows as an impossible count
     PPSTAMP();
