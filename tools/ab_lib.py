@@ -38,6 +38,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     for rep in range(2):
-        for lib in ("libubd_hip_old.so", "libubd_hip.so"):
+        for lib in (sys.argv[1:] or ["libubd_hip_old.so", "libubd_hip.so"]):       # other builds: names inside ubdvss_amd/
             r = subprocess.run([sys.executable, __file__, "child", lib], capture_output=True, text=True)
             print(lib, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)

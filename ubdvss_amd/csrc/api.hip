@@ -52,6 +52,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         // the small shapes the CPU oracle can check (tests/test_gpu_persistent.py; ubd_num_cus reports what was taken)
         { const char *c = getenv("UBD_TEST_NUM_CUS"); if (c && atoi(c) > 0) h->num_cus = atoi(c); }
         { const char *b = getenv("UBD_DILBWD"); h->split_dilbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
+        { const char *b = getenv("UBD_STEM16"); h->split_stem16 = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }
     }
     // Keras model.get_weights() order

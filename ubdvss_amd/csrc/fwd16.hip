@@ -410,6 +410,260 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ L1 -> L2 in one kernel
+// net.py:292-294: ZeroPadding2D + SeparableConv2D(24, 3x3, stride 2, relu) (L1) and SeparableConv2D(24, 3x3, 'same', relu) (L2).
+// L2's 18 x 18 input patch is COMPUTED from the image instead of being copied from memory: L1's activation (201 MB per 64 images of
+// 512 x 512 at 16 bit) is not read back, and an inference pass does not write it either (WRITE_A1 = false; the train step keeps it,
+// every pixel stored once by the tile that owns it).  Same arithmetic as the two kernels above, operation for operation -- the
+// depthwise sum in fp32 in tap order, rounded to T, fp32 MFMA, bias, rounding, ReLU on the packed pairs --, so a1 and a2 are
+// bit-identical to the split pass (tests/test_gpu_forward16.py::test_fused_stem16_equals_split; UBD_STEM16=split keeps the two kernels).
+// Price: L1 on the halo as well (324 / 256 pixels per tile); L1 is the cheap layer (1 or 3 input channels).
+// Per tile: image patch 37 x 37 x CIN (register-staged one tile ahead, converted on the way into LDS) | barrier | L1 on 21 units of
+// 16 patch pixels -> the patch image L2 reads (0 outside L1's map = L2's 'same' padding) | barrier | L2 as sepconv16_kernel<24, 1>.
+template <int CIN> struct sep12_cfg {
+    static constexpr int AP = 18;                                  // a1 patch side
+    static constexpr int XP = 2 * (AP - 1) + 3;                    // image patch side: 37
+    static constexpr int ROWF = XP * CIN;                          // floats per patch row
+    static constexpr int ELEMS = XP * ROWF;
+    static constexpr int STAGE_REGS = (ELEMS + 255) / 256;         // dwords per thread: 17 (RGB) / 6 (grey)
+    static constexpr int A1_BYTES = 1024 * 16;                     // 324 pixels x 48 bytes, rounded as the split kernel's DMA buffer
+    static constexpr int XP_BYTES = STAGE_REGS * 1024;             // whole 1-KiB DMA pieces (64 lanes x 4 B x 4 waves)
+    static constexpr int UNITS = (AP * AP + 15) / 16;              // 21
+    static constexpr int UPW = (UNITS + 3) / 4;                    // unit slots per wave: 6 (wave 0: 6 units, waves 1-3: 5 and a masked one)
+};
+
+// PLAIN: fp32 input that is fed as it is -- the image patch goes straight from memory into LDS (4-byte LDS-DMA through a buffer
+// descriptor: zeros outside the image = L1's zero padding), requested a whole tile ahead into the other of two buffers; no staging
+// registers.  Otherwise (uint8 and / or preprocessing): through registers at the head of the tile, converted on the way into LDS; the
+// other blocks of the CU cover the load latency.
+template <int CIN, int IN_MODE, bool PLAIN, bool WRITE_A1, typename T>
+__global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict__ xin, unsigned short *__restrict__ a1out,
+                                                         unsigned short *__restrict__ y, const float *__restrict__ frag1,
+                                                         const float *__restrict__ bias1, const float *__restrict__ frag2,
+                                                         const float *__restrict__ bias2, int n, int H, int W, int H2, int W2,
+                                                         int pad_lo, float pre_sub, float pre_div)
+{
+    using C = sep12_cfg<CIN>;
+    constexpr int PW = C::AP;
+    static_assert(!PLAIN || IN_MODE == 0, "LDS-DMA moves fp32 pixels only");
+    __shared__ __attribute__((aligned(16))) char smem[C::A1_BYTES + (PLAIN ? 2 : 1) * C::XP_BYTES];
+    char *a1p = smem;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 15, q = lane >> 4;
+
+    // L1: per-lane taps of channel q (zero beyond CIN) and the two pointwise fragments, rounded to T like every kernel of the 16-bit pass
+    float dwk1[9];
+    {
+        const float *dwl1 = frag1 + UBD_SEP_FRAG_FLOATS;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dwk1[t] = round16<T>(dwl1[(t * 6) * 64 + lane]);
+    }
+    const float pw1a = round16<T>(frag1[0 * 64 + lane]), pw1b = round16<T>(frag1[1 * 64 + lane]);
+    const f32x4 b1A = *(const f32x4 *)(bias1 + 4 * q);
+    const f32x4 b1B = q < 2 ? *(const f32x4 *)(bias1 + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cb = (q < CIN) ? q : 0;
+
+    // L2: tap-folded diagonal depthwise fragments + pointwise B operands (as sepconv16_kernel<24, 1>)
+    u32x4 wa0[5], wa1[3], pwb[2];
+    int xo0[5], xo1[3];
+    {
+        const float *pwfrag = frag2, *dwlane = frag2 + UBD_SEP_FRAG_FLOATS;
+        auto wdw = [&](int t, int ch) { return to_bits<T>(dwlane[(t * 6 + ch % 6) * 64 + 16 * (ch / 6)]); };
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int ts = 2 * j + (q >> 1), t = ts < 9 ? ts : 8;
+            const int e = i - 8 * (q & 1);
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && e >= 0 && e < 8) w[e >> 1] = wdw(t, i) << (16 * (e & 1));
+            wa0[j] = u32x4{w[0], w[1], w[2], w[3]};
+            xo0[j] = ((t / 3) * PW + i + t % 3) * (UBD_C * 2) + 16 * (q & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ts = 4 * j + q, t = ts < 9 ? ts : 8;
+            const int r = i & 3, e = 2 * (i >> 2) + r;
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (ts < 9 && r < 2) w[e >> 1] = wdw(t, 16 + e) << (16 * (e & 1));
+            wa1[j] = u32x4{w[0], w[1], w[2], w[3]};
+            xo1[j] = ((t / 3) * PW + i + t % 3) * (UBD_C * 2) + 32;
+        }
+        float pw6[6][2];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+            const int src_lane = 16 * (ch / 6) + i, ss = ch % 6;
+            pw6[s][0] = pwfrag[(ss * 2 + 0) * 64 + src_lane];
+            pw6[s][1] = pwfrag[(ss * 2 + 1) * 64 + src_lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            pwb[nt] = u32x4{pack2<T>(pw6[0][nt], pw6[1][nt]), pack2<T>(pw6[2][nt], pw6[3][nt]), pack2<T>(pw6[4][nt], pw6[5][nt]), 0u};
+    }
+    const f32x4 b2A = *(const f32x4 *)(bias2 + 4 * q);
+    const f32x4 b2B = q < 2 ? *(const f32x4 *)(bias2 + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_x = (W2 + 15) >> 4, tiles_y = (H2 + 15) >> 4;
+    const int total = n * tiles_y * tiles_x;
+    ubd_tile_decoder tdec;
+    tdec.init(tiles_x, tiles_y, total);
+    auto tile_coords = [&](int tile, int &img, int &oy0, int &ox0) {
+        int tx, ty;
+        tdec.decode(tile, tx, ty, img);
+        oy0 = ty * 16; ox0 = tx * 16;
+    };
+    const int WC = W * CIN;
+    // element e = 256 k + thread of the image patch = row e / ROWF, float e % ROWF of that row (a patch row is contiguous in the image)
+    const unsigned lds_xp = ubd_lds_addr(smem + C::A1_BYTES);
+    auto dma_x = [&](int tile, int buf) {                                  // PLAIN
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = ((ox0 - 1) * 2 - pad_lo) * CIN;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)xin + (size_t)img * H * WC), 0,
+                                                                        (int)((unsigned)H * (unsigned)WC * 4u), 0x00020000);
+        const unsigned dst = lds_xp + (unsigned)(buf * C::XP_BYTES + wid * 256);
+#pragma unroll
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            const int e = k * 256 + (int)threadIdx.x;
+            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
+            const int gf = if0 + pf;
+            // rows above / below the image fall out of the descriptor's range by themselves (a negative offset wraps); columns left /
+            // right of it and the lanes past the patch get an out-of-range offset: zeros in LDS
+            const unsigned off = ((unsigned)gf < (unsigned)WC && e < C::ELEMS) ? (unsigned)(((iy0 + pr) * WC + gf) * 4) : 0x80000000u;
+            ubd_blds4(rsrc, off, dst + (unsigned)(k * 1024));
+        }
+    };
+    auto load_regs = [&](int tile, unsigned (&st)[C::STAGE_REGS]) {       // !PLAIN
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = ((ox0 - 1) * 2 - pad_lo) * CIN;
+        const unsigned char *img8 = (const unsigned char *)xin + (size_t)img * H * WC * ((IN_MODE == 1) ? 1 : 4);
+        // every element from the clamped position, all loads in flight, then the elements outside the image are replaced (exactly 0
+        // after the preprocessing) -- a select per load would put every load behind its own branch and wait
+#pragma unroll
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            int e = k * 256 + (int)threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
+            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
+            const int gy = min(max(iy0 + pr, 0), H - 1), gf = min(max(if0 + pf, 0), WC - 1);
+            const unsigned off = (unsigned)(gy * WC + gf);
+            if constexpr (IN_MODE == 1) st[k] = img8[off];
+            else st[k] = ((const unsigned *)img8)[off];
+        }
+#pragma unroll
+        for (int k = 0; k < C::STAGE_REGS; ++k) {
+            int e = k * 256 + (int)threadIdx.x;
+            e = e < C::ELEMS ? e : C::ELEMS - 1;
+            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
+            const bool inside = (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(if0 + pf) < (unsigned)WC;
+            st[k] = inside ? st[k] : ((IN_MODE == 1) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub));
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    if constexpr (PLAIN) dma_x(tile, 0);
+    for (int it = 0;; ++it) {
+        int img, oy0, ox0;
+        tile_coords(tile, img, oy0, ox0);
+        const int nxt = tile + (int)gridDim.x;
+        const bool has_next = nxt < total;                              // block-uniform
+        const float *xp = (const float *)(smem + C::A1_BYTES + (PLAIN ? (it & 1) * C::XP_BYTES : 0));
+        if constexpr (PLAIN) {
+            // Counted wait (vmcnt counts stores too and retires in order): this tile's DMA was issued a tile ago; behind it the wave
+            // issued that tile's stores: two per L1 unit slot when a1 is kept and eight of L2.
+            constexpr int S = (WRITE_A1 ? 2 * C::UPW : 0) + 8;
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+            __builtin_amdgcn_s_barrier();                               // also: every wave has left the previous tile's phases (a1p and the other patch buffer are free)
+            if (has_next) dma_x(nxt, (it + 1) & 1);
+        } else {
+            unsigned stage[C::STAGE_REGS];
+            load_regs(tile, stage);
+            // the previous tile's L1 phase (the readers of xp) ended at its second barrier: xp is free
+#pragma unroll
+            for (int k = 0; k < C::STAGE_REGS; ++k) {
+                const int e = k * 256 + (int)threadIdx.x;
+                if (e < C::ELEMS) {
+                    if constexpr (IN_MODE == 1) ((float *)xp)[e] = stage[k] > 255u ? 0.f : ((float)stage[k] - pre_sub) / pre_div;
+                    else ((float *)xp)[e] = (__builtin_bit_cast(float, stage[k]) - pre_sub) / pre_div;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();                               // also: every wave has left the previous tile's L2 phase (a1p is free)
+        }
+
+        // ---- L1 on this wave's units of 16 patch pixels (two units' taps in flight: unrolled further the kernel spills)
+        __amdgpu_buffer_rsrc_t a1rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a1out + (size_t)img * H2 * W2 * UBD_C), 0,
+                                                                        (int)((unsigned)H2 * (unsigned)W2 * (UBD_C * 2u)), 0x00020000);
+        // branch-free bodies (masked lanes and the slots past the last unit write to a spare corner of the patch buffer / an out-of-range
+        // offset), so that the scheduler can run two units' LDS reads, FMA chains and MFMAs against each other
+#pragma unroll 2
+        for (int j = 0; j < C::UPW; ++j) {
+            const int u = wid + 4 * j;                                   // wave-uniform; slots >= UNITS: every lane masked
+            const int p = 16 * u + i;
+            const bool valid = p < PW * PW;
+            const int pp = valid ? p : PW * PW - 1;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            const float *xb = xp + (2 * pr * C::XP + 2 * pc) * CIN + cb;
+            float dwv = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) dwv = fmaf(xb[(ky * C::XP + kx) * CIN], dwk1[ky * 3 + kx], dwv);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const float dr = round16<T>(dwv);
+            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw1a, dr, z4, 0, 0, 0);
+            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw1b, dr, z4, 0, 0, 0);
+            acc0 += b1A; acc1 += b1B;
+            const int gy = oy0 - 1 + pr, gx = ox0 - 1 + pc;
+            const bool inmap = (unsigned)gy < (unsigned)H2 && (unsigned)gx < (unsigned)W2;
+            u32x2 o0 = {relu_pk16(pack2<T>(acc0[0], acc0[1])), relu_pk16(pack2<T>(acc0[2], acc0[3]))};
+            u32x2 o1 = {relu_pk16(pack2<T>(acc1[0], acc1[1])), relu_pk16(pack2<T>(acc1[2], acc1[3]))};
+            if (!inmap) { o0 = u32x2{0u, 0u}; o1 = u32x2{0u, 0u}; }      // outside L1's map: L2's zero padding
+            const int spare = PW * PW * (UBD_C * 2) + 8 * lane;          // 512 of the 832 bytes behind the last patch pixel
+            *(u32x2 *)(a1p + (valid ? pp * (UBD_C * 2) + 8 * q : spare)) = o0;
+            *(u32x2 *)(a1p + ((valid && q < 2) ? pp * (UBD_C * 2) + 32 + 8 * q : spare)) = o1;
+            if constexpr (WRITE_A1) {
+                // the tile's own 16 x 16 pixels leave for memory; exactly two stores per slot (masked lanes: out-of-range offset)
+                const bool own = valid && inmap && pr >= 1 && pr <= 16 && pc >= 1 && pc <= 16;
+                const unsigned off = own ? (unsigned)((gy * W2 + gx) * (UBD_C * 2) + 8 * q) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b64(o0, a1rs, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(o1, a1rs, (int)((own && q < 2) ? off + 32u : 0x80000000u), 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+
+        // ---- L2 on this wave's four tile rows
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = wid * 4 + k;
+            const int oy = oy0 + r;
+            const char *rowb = a1p + r * (PW * UBD_C * 2);
+            u32x4 b0[5], b1[3];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) b0[j] = *(const u32x4 *)(rowb + xo0[j]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b1[j] = *(const u32x4 *)(rowb + xo1[j]);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c0 = z4, c1 = z4;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) c0 = h16<T>::mfma(wa0[j], b0[j], c0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) c1 = h16<T>::mfma(wa1[j], b1[j], c1);
+            const u32x4 av = {pack2<T>(c0[0], c0[1]), pack2<T>(c0[2], c0[3]), pack2<T>(c1[0], c1[1]), 0u};
+            const f32x4 acc0 = h16<T>::mfma(pwb[0], av, z4);
+            const f32x4 acc1 = h16<T>::mfma(pwb[1], av, z4);
+            int npx = W2 - ox0 < 16 ? W2 - ox0 : 16;
+            npx = (oy < H2) ? npx : 0;
+            const u32x2 nomask = {0u, 0u};
+            store_tile16_t<T, 0>(y, ((size_t)img * H2 + (oy < H2 ? oy : 0)) * W2 + ox0, npx, lane, acc0, acc1, b2A, b2B, nomask, nomask);
+        }
+        if (!has_next) break;
+        tile = nxt;
+    }
+}
+
 // ------------------------------------------------------------------------------------ dilated layers
 struct a16_frags { u32x4 v[7]; u32x2 m0, m1; };
 
@@ -737,6 +991,30 @@ static void launch_sep16(const ubd_handle *h, const void *x, unsigned short *y, 
     hipLaunchKernelGGL((sepconv16_kernel<CIN, STRIDE, IN_MODE, T>), dim3(grid), dim3(256), 0, st, x, y, frag, bias, n, H, W, OH, OW, pad_lo, sub, div);
 }
 
+template <int CIN, int IN_MODE, typename T>
+static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1, unsigned short *a2, const float *frag1, const float *bias1,
+                         const float *frag2, const float *bias2, int n, int H, int W, int pad_lo, float sub, float div, bool write_a1,
+                         hipStream_t st)
+{
+    const int H2 = H / 2, W2 = W / 2;
+    const long tiles = (long)n * ((H2 + 15) / 16) * ((W2 + 15) / 16);
+    long grid = (long)h->num_cus * 3;                          // three blocks per CU (registers; LDS 50 KiB with two patch buffers)
+    if (grid > tiles) grid = tiles;
+#define UBD_SEP12_LAUNCH(PLAIN, WR)                                                                                                   \
+    hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T>), dim3(grid), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
+                       bias2, n, H, W, H2, W2, pad_lo, sub, div)
+    // fp32 pixels fed as they are, offsets inside one image below 2^31: LDS-DMA
+    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31);
+    if constexpr (IN_MODE == 0) {
+        if (plain) {
+            if (write_a1) UBD_SEP12_LAUNCH(true, true); else UBD_SEP12_LAUNCH(true, false);
+            return;
+        }
+    }
+    if (write_a1) UBD_SEP12_LAUNCH(false, true); else UBD_SEP12_LAUNCH(false, false);
+#undef UBD_SEP12_LAUNCH
+}
+
 static unsigned magic_u32(unsigned d) { return d <= 1u ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 template <typename T>
@@ -808,14 +1086,26 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     float sub = 0.f, div = 1.f;
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const bool u8 = in_dtype == UBD_IN_U8;
-    if (h->cfg.c_in == 1) {
-        if (u8) launch_sep16<1, 2, 1, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
-        else launch_sep16<1, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+    if (h->split_stem16) {
+        if (h->cfg.c_in == 1) {
+            if (u8) launch_sep16<1, 2, 1, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+            else launch_sep16<1, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+        } else {
+            if (u8) launch_sep16<3, 2, 1, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+            else launch_sep16<3, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+        }
+        launch_sep16<UBD_C, 1, 2, T>(h, a1, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
     } else {
-        if (u8) launch_sep16<3, 2, 1, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
-        else launch_sep16<3, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
+        // L1 -> L2 in one kernel; the train step keeps L1's activation (the backward pass reads it)
+        const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1];
+        if (h->cfg.c_in == 1) {
+            if (u8) launch_sep12<1, 1, T>(h, images, a1, a2, sf0, b0, sf1, b1, n, H, W, pad_s2, sub, div, !inference, st);
+            else launch_sep12<1, 0, T>(h, images, a1, a2, sf0, b0, sf1, b1, n, H, W, pad_s2, sub, div, !inference, st);
+        } else {
+            if (u8) launch_sep12<3, 1, T>(h, images, a1, a2, sf0, b0, sf1, b1, n, H, W, pad_s2, sub, div, !inference, st);
+            else launch_sep12<3, 0, T>(h, images, a1, a2, sf0, b0, sf1, b1, n, H, W, pad_s2, sub, div, !inference, st);
+        }
     }
-    launch_sep16<UBD_C, 1, 2, T>(h, a1, a2, sf1, params + h->off_sep_b[1], n, H2, W2, H2, W2, 1, 0.f, 1.f, st);
     unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
     launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
     // inference with a single output channel: the head rides in the epilogue of L9 and L9's activation is never written
