@@ -39,5 +39,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     for rep in range(2):
         for lib in (sys.argv[1:] or ["libubd_hip_old.so", "libubd_hip.so"]):       # other builds: names inside ubdvss_amd/
-            r = subprocess.run([sys.executable, __file__, "child", lib], capture_output=True, text=True)
+            env = dict(os.environ)
+            name = lib
+            if "@" in lib:                                                    # libname@VAR=value: the child runs with that variable set
+                name, kv = lib.split("@", 1)
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+            r = subprocess.run([sys.executable, __file__, "child", name], capture_output=True, text=True, env=env)
             print(lib, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)

@@ -418,26 +418,30 @@ __global__ __launch_bounds__(256, (CIN == UBD_C) ? 1 : 5) void sepconv16_kernel(
 // depthwise sum in fp32 in tap order, rounded to T, fp32 MFMA, bias, rounding, ReLU on the packed pairs --, so a1 and a2 are
 // bit-identical to the split pass (tests/test_gpu_forward16.py::test_fused_stem16_equals_split; UBD_STEM16=split keeps the two kernels).
 // Price: L1 on the halo as well (324 / 256 pixels per tile); L1 is the cheap layer (1 or 3 input channels).
-// Per tile: image patch 37 x 37 x CIN (register-staged one tile ahead, converted on the way into LDS) | barrier | L1 on 21 units of
+// Per tile: image patch 37 x 40 x CIN in LDS | barrier | L1 on 21 units of
 // 16 patch pixels -> the patch image L2 reads (0 outside L1's map = L2's 'same' padding) | barrier | L2 as sepconv16_kernel<24, 1>.
 template <int CIN> struct sep12_cfg {
     static constexpr int AP = 18;                                  // a1 patch side
-    static constexpr int XP = 2 * (AP - 1) + 3;                    // image patch side: 37
-    static constexpr int ROWF = XP * CIN;                          // floats per patch row
-    static constexpr int ELEMS = XP * ROWF;
-    static constexpr int STAGE_REGS = (ELEMS + 255) / 256;         // dwords per thread: 17 (RGB) / 6 (grey)
-    static constexpr int A1_BYTES = 1024 * 16;                     // 324 pixels x 48 bytes, rounded as the split kernel's DMA buffer
-    static constexpr int XP_BYTES = STAGE_REGS * 1024;             // whole 1-KiB DMA pieces (64 lanes x 4 B x 4 waves)
+    static constexpr int XP = 2 * (AP - 1) + 3;                    // image patch rows: 37
+    // patch columns: the 37 that are needed start at image column 32 tx - 2 - pad; the LDS image starts at 32 tx - 4, so every patch row
+    // begins on a 16-byte boundary of the image row (H, W multiples of 4) and is moved in 16-byte pieces: 40 columns
+    static constexpr int XW = 40;
+    static constexpr int ROWF = XW * CIN;                          // floats per patch row: 120 (RGB) / 40 (grey)
+    static constexpr int RC = ROWF / 4;                            // 16-byte chunks per row
+    static constexpr int CHUNKS = XP * RC;                         // 1110 / 370
+    static constexpr int ROUNDS = (CHUNKS + 255) / 256;            // chunks per thread: 5 / 2
+    static constexpr int A1_BYTES = 1024 * 16;                     // 324 pixels x 48 bytes + a spare corner for masked lanes
+    static constexpr int XP_BYTES = CHUNKS * 16;
     static constexpr int UNITS = (AP * AP + 15) / 16;              // 21
     static constexpr int UPW = (UNITS + 3) / 4;                    // unit slots per wave: 6 (wave 0: 6 units, waves 1-3: 5 and a masked one)
 };
 
-// PLAIN: fp32 input that is fed as it is -- the image patch goes straight from memory into LDS (4-byte LDS-DMA through a buffer
-// descriptor: zeros outside the image = L1's zero padding), requested a whole tile ahead into the other of two buffers; no staging
-// registers.  Otherwise (uint8 and / or preprocessing): through registers at the head of the tile, converted on the way into LDS; the
+// PLAIN: fp32 input that is fed as it is -- the image patch goes straight from memory into LDS (16-byte LDS-DMA through a buffer
+// descriptor: zeros outside the image = L1's zero padding), requested a whole tile ahead into the other of two buffers (XB = 2) or,
+// with one buffer (XB = 1: a fourth block fits the CU), as soon as L1 has read the patch; no staging registers.  Otherwise (uint8 and / or preprocessing): through registers at the head of the tile, converted on the way into LDS; the
 // other blocks of the CU cover the load latency.
-template <int CIN, int IN_MODE, bool PLAIN, bool WRITE_A1, typename T>
-__global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict__ xin, unsigned short *__restrict__ a1out,
+template <int CIN, int IN_MODE, bool PLAIN, bool WRITE_A1, typename T, int XB>
+__global__ __launch_bounds__(256, XB == 1 ? 4 : 3) void sep12_16_kernel(const void *__restrict__ xin, unsigned short *__restrict__ a1out,
                                                          unsigned short *__restrict__ y, const float *__restrict__ frag1,
                                                          const float *__restrict__ bias1, const float *__restrict__ frag2,
                                                          const float *__restrict__ bias2, int n, int H, int W, int H2, int W2,
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict
     using C = sep12_cfg<CIN>;
     constexpr int PW = C::AP;
     static_assert(!PLAIN || IN_MODE == 0, "LDS-DMA moves fp32 pixels only");
-    __shared__ __attribute__((aligned(16))) char smem[C::A1_BYTES + (PLAIN ? 2 : 1) * C::XP_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[C::A1_BYTES + (PLAIN ? XB : 1) * C::XP_BYTES];
     char *a1p = smem;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
@@ -512,51 +516,55 @@ __global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict
         oy0 = ty * 16; ox0 = tx * 16;
     };
     const int WC = W * CIN;
-    // element e = 256 k + thread of the image patch = row e / ROWF, float e % ROWF of that row (a patch row is contiguous in the image)
+    // chunk c = 256 k + thread of the image patch = row c / RC, floats 4 (c % RC) .. + 3 of that row; the image's left and right
+    // borders fall on chunk boundaries (W is a multiple of 4), so a chunk is inside the image or outside it as a whole
+    const int dx0 = 2 - pad_lo;                                            // patch column of the first column that is needed
     const unsigned lds_xp = ubd_lds_addr(smem + C::A1_BYTES);
     auto dma_x = [&](int tile, int buf) {                                  // PLAIN
         int img, oy0, ox0;
         tile_coords(tile, img, oy0, ox0);
-        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = ((ox0 - 1) * 2 - pad_lo) * CIN;
+        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = (ox0 * 2 - 4) * CIN;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)xin + (size_t)img * H * WC), 0,
                                                                         (int)((unsigned)H * (unsigned)WC * 4u), 0x00020000);
-        const unsigned dst = lds_xp + (unsigned)(buf * C::XP_BYTES + wid * 256);
+        const unsigned dst = lds_xp + (unsigned)(buf * C::XP_BYTES + wid * 1024);
 #pragma unroll
-        for (int k = 0; k < C::STAGE_REGS; ++k) {
-            const int e = k * 256 + (int)threadIdx.x;
-            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
-            const int gf = if0 + pf;
-            // rows above / below the image fall out of the descriptor's range by themselves (a negative offset wraps); columns left /
-            // right of it and the lanes past the patch get an out-of-range offset: zeros in LDS
-            const unsigned off = ((unsigned)gf < (unsigned)WC && e < C::ELEMS) ? (unsigned)(((iy0 + pr) * WC + gf) * 4) : 0x80000000u;
-            ubd_blds4(rsrc, off, dst + (unsigned)(k * 1024));
+        for (int k = 0; k < C::ROUNDS; ++k) {
+            const int c = k * 256 + (int)threadIdx.x;
+            const int pr = c / C::RC, gf = if0 + 4 * (c - pr * C::RC);
+            // rows above / below the image fall out of the descriptor's range by themselves (a negative offset wraps); chunks left / right
+            // of it get an out-of-range offset: zeros in LDS.  Only the lanes that have a chunk write (16 bytes at dst + 16 * lane).
+            const unsigned off = (unsigned)gf < (unsigned)WC ? (unsigned)(((iy0 + pr) * WC + gf) * 4) : 0x80000000u;
+            if (k < C::ROUNDS - 1 || c < C::CHUNKS) ubd_blds16(rsrc, off, dst + (unsigned)(k * 4096));
         }
     };
-    auto load_regs = [&](int tile, unsigned (&st)[C::STAGE_REGS]) {       // !PLAIN
+    // !PLAIN: 4 bytes (uint8) / 16 bytes (fp32) per chunk through registers
+    constexpr int SW = (IN_MODE == 1) ? 1 : 4;                             // dwords per chunk
+    auto load_regs = [&](int tile, unsigned (&st)[C::ROUNDS][SW]) {
         int img, oy0, ox0;
         tile_coords(tile, img, oy0, ox0);
-        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = ((ox0 - 1) * 2 - pad_lo) * CIN;
+        const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = (ox0 * 2 - 4) * CIN;
         const unsigned char *img8 = (const unsigned char *)xin + (size_t)img * H * WC * ((IN_MODE == 1) ? 1 : 4);
-        // every element from the clamped position, all loads in flight, then the elements outside the image are replaced (exactly 0
-        // after the preprocessing) -- a select per load would put every load behind its own branch and wait
+        // every chunk from the clamped position, all loads in flight, then the chunks outside the image are replaced (exactly 0 after
+        // the preprocessing) -- a select per load would put every load behind its own branch and wait
 #pragma unroll
-        for (int k = 0; k < C::STAGE_REGS; ++k) {
-            int e = k * 256 + (int)threadIdx.x;
-            e = e < C::ELEMS ? e : C::ELEMS - 1;
-            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
-            const int gy = min(max(iy0 + pr, 0), H - 1), gf = min(max(if0 + pf, 0), WC - 1);
+        for (int k = 0; k < C::ROUNDS; ++k) {
+            int c = k * 256 + (int)threadIdx.x;
+            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+            const int pr = c / C::RC, pf = 4 * (c - pr * C::RC);
+            const int gy = min(max(iy0 + pr, 0), H - 1), gf = min(max(if0 + pf, 0), WC - 4);
             const unsigned off = (unsigned)(gy * WC + gf);
-            if constexpr (IN_MODE == 1) st[k] = img8[off];
-            else st[k] = ((const unsigned *)img8)[off];
+            if constexpr (IN_MODE == 1) st[k][0] = *(const unsigned *)(img8 + off);
+            else {
+                const u32x4 v = *(const u32x4 *)(img8 + (size_t)off * 4);
+                st[k][0] = v[0]; st[k][1] = v[1]; st[k][2] = v[2]; st[k][3] = v[3];
+            }
         }
-#pragma unroll
-        for (int k = 0; k < C::STAGE_REGS; ++k) {
-            int e = k * 256 + (int)threadIdx.x;
-            e = e < C::ELEMS ? e : C::ELEMS - 1;
-            const int pr = e / C::ROWF, pf = e - pr * C::ROWF;
-            const bool inside = (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(if0 + pf) < (unsigned)WC;
-            st[k] = inside ? st[k] : ((IN_MODE == 1) ? 0x100u : __builtin_bit_cast(unsigned, pre_sub));
-        }
+    };
+    auto chunk_inside = [&](int k, int iy0, int if0) {
+        int c = k * 256 + (int)threadIdx.x;
+        c = c < C::CHUNKS ? c : C::CHUNKS - 1;
+        const int pr = c / C::RC, pf = 4 * (c - pr * C::RC);
+        return (unsigned)(iy0 + pr) < (unsigned)H && (unsigned)(if0 + pf) < (unsigned)WC;
     };
 
     int tile = blockIdx.x;
@@ -567,34 +575,39 @@ __global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict
         tile_coords(tile, img, oy0, ox0);
         const int nxt = tile + (int)gridDim.x;
         const bool has_next = nxt < total;                              // block-uniform
-        const float *xp = (const float *)(smem + C::A1_BYTES + (PLAIN ? (it & 1) * C::XP_BYTES : 0));
+        const float *xp = (const float *)(smem + C::A1_BYTES + ((PLAIN && XB == 2) ? (it & 1) * C::XP_BYTES : 0));
         if constexpr (PLAIN) {
             // Counted wait (vmcnt counts stores too and retires in order): this tile's DMA was issued a tile ago; behind it the wave
-            // issued that tile's stores: two per L1 unit slot when a1 is kept and eight of L2.
-            constexpr int S = (WRITE_A1 ? 2 * C::UPW : 0) + 8;
+            // issued that tile's stores: three of L1's activation when it is kept and eight of L2.
+            constexpr int S = (WRITE_A1 ? 3 : 0) + 8;
             if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             __builtin_amdgcn_s_barrier();                               // also: every wave has left the previous tile's phases (a1p and the other patch buffer are free)
-            if (has_next) dma_x(nxt, (it + 1) & 1);
+            if (XB == 2 && has_next) dma_x(nxt, (it + 1) & 1);
         } else {
-            unsigned stage[C::STAGE_REGS];
+            unsigned stage[C::ROUNDS][SW];
             load_regs(tile, stage);
             // the previous tile's L1 phase (the readers of xp) ended at its second barrier: xp is free
+            const int iy0 = (oy0 - 1) * 2 - pad_lo, if0 = (ox0 * 2 - 4) * CIN;
 #pragma unroll
-            for (int k = 0; k < C::STAGE_REGS; ++k) {
-                const int e = k * 256 + (int)threadIdx.x;
-                if (e < C::ELEMS) {
-                    if constexpr (IN_MODE == 1) ((float *)xp)[e] = stage[k] > 255u ? 0.f : ((float)stage[k] - pre_sub) / pre_div;
-                    else ((float *)xp)[e] = (__builtin_bit_cast(float, stage[k]) - pre_sub) / pre_div;
+            for (int k = 0; k < C::ROUNDS; ++k) {
+                const int c = k * 256 + (int)threadIdx.x;
+                const bool inside = chunk_inside(k, iy0, if0);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float raw;
+                    if constexpr (IN_MODE == 1) raw = (float)((stage[k][0] >> (8 * e)) & 0xFFu);
+                    else raw = __builtin_bit_cast(float, stage[k][e]);
+                    v[e] = inside ? (raw - pre_sub) / pre_div : 0.f;
                 }
+                if (c < C::CHUNKS) *(f32x4 *)((float *)xp + 4 * c) = v;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();                               // also: every wave has left the previous tile's L2 phase (a1p is free)
         }
 
         // ---- L1 on this wave's units of 16 patch pixels (two units' taps in flight: unrolled further the kernel spills)
-        __amdgpu_buffer_rsrc_t a1rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a1out + (size_t)img * H2 * W2 * UBD_C), 0,
-                                                                        (int)((unsigned)H2 * (unsigned)W2 * (UBD_C * 2u)), 0x00020000);
         // branch-free bodies (masked lanes and the slots past the last unit write to a spare corner of the patch buffer / an out-of-range
         // offset), so that the scheduler can run two units' LDS reads, FMA chains and MFMAs against each other
 #pragma unroll 2
@@ -604,12 +617,12 @@ __global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict
             const bool valid = p < PW * PW;
             const int pp = valid ? p : PW * PW - 1;
             const int pr = pp / PW, pc = pp - pr * PW;
-            const float *xb = xp + (2 * pr * C::XP + 2 * pc) * CIN + cb;
+            const float *xb = xp + 2 * pr * C::ROWF + (2 * pc + dx0) * CIN + cb;
             float dwv = 0.f;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) dwv = fmaf(xb[(ky * C::XP + kx) * CIN], dwk1[ky * 3 + kx], dwv);
+                for (int kx = 0; kx < 3; ++kx) dwv = fmaf(xb[ky * C::ROWF + kx * CIN], dwk1[ky * 3 + kx], dwv);
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             const float dr = round16<T>(dwv);
             f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw1a, dr, z4, 0, 0, 0);
@@ -623,16 +636,26 @@ __global__ __launch_bounds__(256, 3) void sep12_16_kernel(const void *__restrict
             const int spare = PW * PW * (UBD_C * 2) + 8 * lane;          // 512 of the 832 bytes behind the last patch pixel
             *(u32x2 *)(a1p + (valid ? pp * (UBD_C * 2) + 8 * q : spare)) = o0;
             *(u32x2 *)(a1p + ((valid && q < 2) ? pp * (UBD_C * 2) + 32 + 8 * q : spare)) = o1;
-            if constexpr (WRITE_A1) {
-                // the tile's own 16 x 16 pixels leave for memory; exactly two stores per slot (masked lanes: out-of-range offset)
-                const bool own = valid && inmap && pr >= 1 && pr <= 16 && pc >= 1 && pc <= 16;
-                const unsigned off = own ? (unsigned)((gy * W2 + gx) * (UBD_C * 2) + 8 * q) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b64(o0, a1rs, (int)off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(o1, a1rs, (int)((own && q < 2) ? off + 32u : 0x80000000u), 0, 0);
-            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        if constexpr (PLAIN && XB == 1) { if (has_next) dma_x(nxt, 0); }   // one patch buffer: free now, filled during the L2 phase
+
+        if constexpr (WRITE_A1) {
+            // the tile's own 16 x 16 pixels of L1's activation leave for memory: patch rows 1..16, columns 1..16 = 768 contiguous
+            // bytes per row in LDS and in the map; three 16-byte pieces per thread (masked pieces: out-of-range offset)
+            __amdgpu_buffer_rsrc_t a1rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a1out + (size_t)img * H2 * W2 * UBD_C), 0,
+                                                                            (int)((unsigned)H2 * (unsigned)W2 * (UBD_C * 2u)), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int c = k * 256 + (int)threadIdx.x;
+                const int row = c / 48, cc = c - row * 48;
+                const u32x4 v = *(const u32x4 *)(a1p + ((row + 1) * PW + 1) * (UBD_C * 2) + cc * 16);
+                const int gy = oy0 + row, gx = ox0 + cc / 3;
+                const bool in = gy < H2 && gx < W2;
+                __builtin_amdgcn_raw_buffer_store_b128(v, a1rs, in ? (gy * W2 + ox0) * (UBD_C * 2) + cc * 16 : (int)0x80000000u, 0, 0);
+            }
+        }
 
         // ---- L2 on this wave's four tile rows
 #pragma unroll
@@ -1000,9 +1023,15 @@ static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1,
     const long tiles = (long)n * ((H2 + 15) / 16) * ((W2 + 15) / 16);
     long grid = (long)h->num_cus * 3;                          // three blocks per CU (registers; LDS 50 KiB with two patch buffers)
     if (grid > tiles) grid = tiles;
+    long grid4 = (long)h->num_cus * 4;
+    if (grid4 > tiles) grid4 = tiles;
+    // inference: one patch buffer and four blocks per CU (34 KiB, 120 registers); train step: two buffers, three blocks (0.172 -> 0.169 ms for
+    // cfg5 / 1.200 -> 1.192 ms for the bf16 train step against the other assignment)
+    const int xb = write_a1 ? 2 : 1;
 #define UBD_SEP12_LAUNCH(PLAIN, WR)                                                                                                   \
-    hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T>), dim3(grid), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
-                       bias2, n, H, W, H2, W2, pad_lo, sub, div)
+    do { if (xb == 1) hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T, 1>), dim3(grid4), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
+                       bias2, n, H, W, H2, W2, pad_lo, sub, div); else hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T, 2>), dim3(grid), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
+                       bias2, n, H, W, H2, W2, pad_lo, sub, div); } while (0)
     // fp32 pixels fed as they are, offsets inside one image below 2^31: LDS-DMA
     const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31);
     if constexpr (IN_MODE == 0) {
