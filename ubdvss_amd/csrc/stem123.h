@@ -74,12 +74,23 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // queue below, where the blocks that had no image have meanwhile taken its share (tickets).  One launch instead of a second
     // stream with two events per step: round 3 measured 10 us of idle forward stream behind every event record and a placement
     // race between the postprocess blocks and this kernel's whole-CU blocks.
+#ifdef UBD_STAMPS   // diagnostic build only: the block's time line on the 100-MHz clock all CUs share (tools/stamps_stem_blocks.py)
+#define S123_BLOCK_STAMP(k) do { if (stamps && threadIdx.x == 0 && (k) < 32) stamps[(size_t)gridDim.x * 8 * 16 * 8 + (size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S123_BLOCK_STAMP(k) do {} while (0)
+#endif
+    S123_BLOCK_STAMP(0);
     if (pj.n > 0) {
         for (int im = (int)blockIdx.x; im < pj.n; im += (int)gridDim.x) {
             pp_image_lds<C::NT, true>((int *)smem, pj, im);
             __syncthreads();
         }
     }
+    S123_BLOCK_STAMP(1);
+    // the block's first strips: the ticket is requested before anything else (an atomic round trip to the far L2) and consumed
+    // after the weight loads below have been issued
+    int t0_early = 0;
+    if (threadIdx.x == 0) t0_early = __hip_atomic_fetch_add(ticket, (((W4 + 15) >> 4) >= 3 ? 1 : 4 - ((W4 + 15) >> 4)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float *a1p = smem;
     float *l2 = a1p + X::A1_FLOATS;
     float *xp = l2 + C::L2_FLOATS;
@@ -101,22 +112,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // L1's eleven per-lane values (lane (i, q): input channel q, zero weights for q >= C_in) sit in an LDS table and are
     // re-read at the start of every phase 0b: kept in VGPRs across phase A they cost 11 spilled registers
     float *w1t = carry_buf + C::CARRY_FLOATS;
-    for (int e = threadIdx.x; e < 64 * 12; e += C::NT) {
-        const int ln = e / 12, k = e - ln * 12;
-        w1t[e] = k < 9 ? frag1[UBD_SEP_FRAG_FLOATS + (k * 6) * 64 + ln] : (k < 11 ? frag1[(k - 9) * 64 + ln] : 0.f);
-    }
     float *bt = w1t + 64 * 12;                                     // [0,32): L1's bias (24 + zeros), [32,64): L3's
-    if (threadIdx.x < 64) bt[threadIdx.x] = (threadIdx.x & 31) < UBD_C ? (threadIdx.x < 32 ? bias1 : bias3)[threadIdx.x & 31] : 0.f;
-    for (int e = threadIdx.x; e < C::W3PW_FLOATS; e += C::NT) {
-        const int nt = e >> 9, ln = (e >> 3) & 63, s = e & 7, lq = ln >> 4, li = ln & 15;
-        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
-        w3pw[e] = s < 6 ? frag3[((ch % 6) * 2 + nt) * 64 + 16 * (ch / 6) + li] : 0.f;
-    }
-    for (int e = threadIdx.x; e < C::W3DW_FLOATS; e += C::NT) {
-        const int lq = e / 72, r = e - lq * 72, t = r >> 3, s = r & 7;
-        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
-        w3dw[e] = s < 6 ? frag3[UBD_SEP_FRAG_FLOATS + (t * 6 + ch % 6) * 64 + 16 * (ch / 6)] : 0.f;
-    }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 b2A = *(const f32x4 *)(bias2 + 4 * q), b2B = q < 2 ? *(const f32x4 *)(bias2 + 16 + 4 * q) : z4;
 
@@ -243,8 +239,8 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     const int l2w = (rb * C::LC + pos) * C::LP + 4 * q;
     const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;
 
-    if (threadIdx.x == 0) {                                                          // the block's first D strips
-        const int t0 = __hip_atomic_fetch_add(ticket, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {                                                          // the block's first D strips (requested at the top)
+        const int t0 = t0_early;
         ring[0] = t0; ring[1] = t0 + 1; ring[2] = t0 + 2;                            // only the first D are this block's: the rest are overwritten before use
     }
     __syncthreads();
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             }
         }
     };
-    if (cur.ls >= strips) { check_out(); return; }                                   // block-uniform: nothing left
+    if (cur.ls >= strips) { S123_BLOCK_STAMP(2); check_out(); return; }              // block-uniform: nothing left
     tpos nx1 = advance(cur);
     int pending = 0;                                                                 // ticket in flight (thread 0)
 #ifdef UBD_STAMPS   // diagnostic build only: s_memtime at the phase boundaries, lane 0 of every wave, first 16 tiles of the block
@@ -355,9 +351,26 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
     };
 
-    // ---- first tile: patch -> LDS, L1
-    if constexpr (PLAIN) { dma_x(cur); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    else { load_x(cur); convert_x(cur); }
+    // ---- first tile: patch -> LDS, L1.  The LDS weight tables are filled while the patch is on its way (and not at all by a block
+    // that found no strip left).  L1's eleven per-lane values, the biases of L1 / L3, L3's pointwise and depthwise tables:
+    if constexpr (PLAIN) dma_x(cur); else load_x(cur);
+    for (int e = threadIdx.x; e < 64 * 12; e += C::NT) {
+        const int ln = e / 12, k = e - ln * 12;
+        w1t[e] = k < 9 ? frag1[UBD_SEP_FRAG_FLOATS + (k * 6) * 64 + ln] : (k < 11 ? frag1[(k - 9) * 64 + ln] : 0.f);
+    }
+    if (threadIdx.x < 64) bt[threadIdx.x] = (threadIdx.x & 31) < UBD_C ? (threadIdx.x < 32 ? bias1 : bias3)[threadIdx.x & 31] : 0.f;
+    for (int e = threadIdx.x; e < C::W3PW_FLOATS; e += C::NT) {
+        const int nt = e >> 9, ln = (e >> 3) & 63, s = e & 7, lq = ln >> 4, li = ln & 15;
+        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+        w3pw[e] = s < 6 ? frag3[((ch % 6) * 2 + nt) * 64 + 16 * (ch / 6) + li] : 0.f;
+    }
+    for (int e = threadIdx.x; e < C::W3DW_FLOATS; e += C::NT) {
+        const int lq = e / 72, r = e - lq * 72, t = r >> 3, s = r & 7;
+        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+        w3dw[e] = s < 6 ? frag3[UBD_SEP_FRAG_FLOATS + (t * 6 + ch % 6) * 64 + 16 * (ch / 6)] : 0.f;
+    }
+    if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else convert_x(cur);
     __syncthreads();
     phase0b(cur);
     __syncthreads();
@@ -368,6 +381,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     for (int it = 0;; ++it) {
         S123_STAMP(0);
         const bool new_strip = cur.tx == 0;                                          // block-uniform
+        if (new_strip) S123_BLOCK_STAMP(4 + cur.ord);
         if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
         const bool has_next = nx1.ls < strips;                                       // block-uniform
@@ -499,5 +513,6 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         cur = nx1;
         nx1 = advance(nx1);
     }
+    S123_BLOCK_STAMP(2);
     check_out();
 }
