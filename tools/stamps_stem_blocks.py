@@ -33,15 +33,18 @@ for k in (0, 1, 32):
     b = st.cpu().numpy().astype(np.int64)[nblk * 8 * 16 * 8:].reshape(nblk, 32)
     t0 = b[:, 0].min()
     us = lambda v: (v - t0) / 100.0
-    nstr = (b[:, 4:] > 0).sum(1)
+    nstr = (b[:, 4:28] > 0).sum(1)
     print(f"--- {nimg} images, postprocess of {k} maps inside: kernel span {us(b[:, 2].max()):.1f} us; strips per block: "
           + ", ".join(f"{c} x {int((nstr == c).sum())}" for c in sorted(set(nstr))))
     for name, sel in (("postprocess blocks", np.arange(nblk) < k), ("other blocks", np.arange(nblk) >= k)):
         if not sel.any(): continue
         print(f"  {name:18s} entry {us(b[sel, 0]).mean():6.1f}  job done {us(b[sel, 1]).mean():6.1f}  first strip {us(b[sel, 4]).mean():6.1f}  "
               f"end mean {us(b[sel, 2]).mean():6.1f} max {us(b[sel, 2]).max():6.1f}  strips mean {nstr[sel].mean():.2f}")
-    d = np.diff(b[:, 4:], axis=1)
-    d = d[(b[:, 5:] > 0)]
+    o = (np.arange(nblk) >= k) & (nstr > 0)
+    print("  prologue of the blocks without a job (us after entry): ticket + ring barrier %.2f, patch requested + tables filled %.2f, patch landed + barrier %.2f, first L1 phase + barrier %.2f"
+          % tuple(((b[o, j] - b[o, 0]) / 100.0).mean() for j in (3, 28, 29, 30)))
+    d = np.diff(b[:, 4:28], axis=1)
+    d = d[(b[:, 5:28] > 0)]
     print(f"  strip period: median {np.median(d) / 100:.1f} us, p10 {np.percentile(d, 10) / 100:.1f}, p90 {np.percentile(d, 90) / 100:.1f}")
     last = np.array([b[i, 4 + nstr[i] - 1] for i in range(nblk) if nstr[i] > 0])
     print(f"  last strip starts: min {us(last.min()):.1f} median {us(np.median(last)):.1f} max {us(last.max()):.1f}")

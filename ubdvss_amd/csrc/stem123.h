@@ -87,10 +87,16 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
     }
     S123_BLOCK_STAMP(1);
-    // the block's first strips: the ticket is requested before anything else (an atomic round trip to the far L2) and consumed
-    // after the weight loads below have been issued
+    // The block's first D strips are its own without asking: strips b D .. b D + D - 1 (256 blocks drawing their first ticket from
+    // one counter at the same moment took 2.6 us of every block's prologue in the stamps).  A block that had a postprocess job comes
+    // up late and alone: it draws tickets like everybody does later -- and the first tickets handed out are the slots those blocks
+    // did not take (ticket_ls below).  Requested before anything else (an atomic round trip to the far L2), consumed after the
+    // weight loads below have been issued.
+    const int Dc = ((W4 + 15) >> 4) >= 3 ? 1 : 4 - ((W4 + 15) >> 4);
+    const int njob = pj.n > 0 ? (pj.n < (int)gridDim.x ? pj.n : (int)gridDim.x) : 0;
+    auto ticket_ls = [&](int k) { return k < njob * Dc ? k : k + ((int)gridDim.x - njob) * Dc; };   // ticket -> logical strip
     int t0_early = 0;
-    if (threadIdx.x == 0) t0_early = __hip_atomic_fetch_add(ticket, (((W4 + 15) >> 4) >= 3 ? 1 : 4 - ((W4 + 15) >> 4)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && (int)blockIdx.x < njob) t0_early = __hip_atomic_fetch_add(ticket, Dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float *a1p = smem;
     float *l2 = a1p + X::A1_FLOATS;
     float *xp = l2 + C::L2_FLOATS;
@@ -240,10 +246,12 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;
 
     if (threadIdx.x == 0) {                                                          // the block's first D strips (requested at the top)
-        const int t0 = t0_early;
-        ring[0] = t0; ring[1] = t0 + 1; ring[2] = t0 + 2;                            // only the first D are this block's: the rest are overwritten before use
+        const bool had_job = (int)blockIdx.x < njob;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ring[j] = had_job ? ticket_ls(t0_early + j) : (int)blockIdx.x * D + j;   // only the first D are this block's: the rest are overwritten before use
     }
     __syncthreads();
+    S123_BLOCK_STAMP(3);
     tpos cur = strip_pos(0, 0);
     // The counter resets itself: every block checks out through a second counter, and the last one out -- by then nobody draws
     // tickets any more -- zeroes both for the next launch on this workspace (stream order; the host zeroes them only before
@@ -354,26 +362,37 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // ---- first tile: patch -> LDS, L1.  The LDS weight tables are filled while the patch is on its way (and not at all by a block
     // that found no strip left).  L1's eleven per-lane values, the biases of L1 / L3, L3's pointwise and depthwise tables:
     if constexpr (PLAIN) dma_x(cur); else load_x(cur);
-    for (int e = threadIdx.x; e < 64 * 12; e += C::NT) {
-        const int ln = e / 12, k = e - ln * 12;
-        w1t[e] = k < 9 ? frag1[UBD_SEP_FRAG_FLOATS + (k * 6) * 64 + ln] : (k < 11 ? frag1[(k - 9) * 64 + ln] : 0.f);
-    }
-    if (threadIdx.x < 64) bt[threadIdx.x] = (threadIdx.x & 31) < UBD_C ? (threadIdx.x < 32 ? bias1 : bias3)[threadIdx.x & 31] : 0.f;
-    for (int e = threadIdx.x; e < C::W3PW_FLOATS; e += C::NT) {
-        const int nt = e >> 9, ln = (e >> 3) & 63, s = e & 7, lq = ln >> 4, li = ln & 15;
-        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
-        w3pw[e] = s < 6 ? frag3[((ch % 6) * 2 + nt) * 64 + 16 * (ch / 6) + li] : 0.f;
-    }
-    for (int e = threadIdx.x; e < C::W3DW_FLOATS; e += C::NT) {
-        const int lq = e / 72, r = e - lq * 72, t = r >> 3, s = r & 7;
-        const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
-        w3dw[e] = s < 6 ? frag3[UBD_SEP_FRAG_FLOATS + (t * 6 + ch % 6) * 64 + 16 * (ch / 6)] : 0.f;
+    {   // every thread's (up to) six table entries: all loads first, then the stores -- one memory round trip (as loops of
+        // load -> store the fills took 1.8 us of the prologue)
+        static_assert(64 * 12 <= 2 * C::NT && C::W3PW_FLOATS <= 2 * C::NT && C::W3DW_FLOATS <= C::NT, "table entries per thread");
+        auto w1_entry = [&](int e) {
+            const int ln = e / 12, k = e - ln * 12;
+            return k < 9 ? frag1[UBD_SEP_FRAG_FLOATS + (k * 6) * 64 + ln] : (k < 11 ? frag1[(k - 9) * 64 + ln] : 0.f);
+        };
+        auto w3pw_entry = [&](int e) {
+            const int nt = e >> 9, ln = (e >> 3) & 63, s = e & 7, lq = ln >> 4, li = ln & 15;
+            const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+            return s < 6 ? frag3[((ch % 6) * 2 + nt) * 64 + 16 * (ch / 6) + li] : 0.f;
+        };
+        auto w3dw_entry = [&](int e) {
+            const int lq = e / 72, r = e - lq * 72, t = r >> 3, s = r & 7;
+            const int ch = s < 4 ? 4 * lq + s : 16 + 2 * lq + (s - 4);
+            return s < 6 ? frag3[UBD_SEP_FRAG_FLOATS + (t * 6 + ch % 6) * 64 + 16 * (ch / 6)] : 0.f;
+        };
+        const int t = (int)threadIdx.x;
+        const int e1 = t + C::NT < 64 * 12 ? t + C::NT : t, e3 = t + C::NT < C::W3PW_FLOATS ? t + C::NT : t, ed = t < C::W3DW_FLOATS ? t : 0;
+        const float v0 = w1_entry(t), v1 = w1_entry(e1), v2 = w3pw_entry(t), v3 = w3pw_entry(e3), v4 = w3dw_entry(ed);
+        const float v5 = (t & 31) < UBD_C ? (t < 32 ? bias1 : bias3)[t & 31] : 0.f;
+        w1t[t] = v0; w1t[e1] = v1; w3pw[t] = v2; w3pw[e3] = v3; w3dw[ed] = v4;
+        if (t < 64) bt[t] = v5;
     }
     if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else convert_x(cur);
     __syncthreads();
+    S123_BLOCK_STAMP(29);
     phase0b(cur);
     __syncthreads();
+    S123_BLOCK_STAMP(30);
     // Per tile t (two block barriers): [request the input patch of t + 1] -> phase A(t) -> [patch of t + 1 complete in LDS] -> barrier
     // -> phase B(t) on waves 0-3 beside phase 0b(t + 1) (waves 4-7 take twice the units) -> barrier.  Phase 0b of the next tile
     // touches nothing phase B reads (the inherited L2 column is moved at the start of phase A instead), so the four waves that
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         S123_STAMP(0);
         const bool new_strip = cur.tx == 0;                                          // block-uniform
         if (new_strip) S123_BLOCK_STAMP(4 + cur.ord);
-        if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (new_strip && threadIdx.x == 0) pending = ticket_ls(__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
         const bool has_next = nx1.ls < strips;                                       // block-uniform
         const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
