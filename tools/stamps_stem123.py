@@ -31,3 +31,11 @@ per_tile = s[:, 0, 3:14, 0] - s[:, 0, 2:13, 0]
 print("tile period (wave 0): median", np.median(per_tile), "p10", np.percentile(per_tile, 10), "p90", np.percentile(per_tile, 90))
 tot = s[:, :, 13, 6].max() - s[:, :, 2, 0].min()
 print("all segments sum (median, wave 0):", np.median(seg[:, 0, its, :].sum(-1)))
+# units of two tiles: even tiles start a unit, odd tiles end one
+for par, name in ((0, "first tile of a unit (even)"), (1, "last tile of a unit (odd)")):
+    sl = slice(2 + par, 14, 2)
+    print(name)
+    for w in (0, 3, 4, 6, 7):
+        print(f"  wave {w}: " + "  ".join(f"{names[k]} {np.median(seg[:, w, sl, k]):7.0f}" for k in range(7)))
+    nxt = s[:, 0, 3 + par:15:2, 0] - s[:, 0, 2 + par:14:2, 0]
+    print("  tile period (wave 0): median", np.median(nxt), " mean", nxt.mean())
