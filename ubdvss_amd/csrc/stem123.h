@@ -401,7 +401,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         S123_STAMP(0);
         const bool new_strip = cur.tx == 0;                                          // block-uniform
         if (new_strip) S123_BLOCK_STAMP(4 + cur.ord);
-        if (new_strip && threadIdx.x == 0) pending = ticket_ls(__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the raw ticket: arithmetic on it here would wait for the round trip
         const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
         const bool has_next = nx1.ls < strips;                                       // block-uniform
         const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             l1_finish(nx1, std::integral_constant<int, 2>{}, tap, 2);
         }
         S123_STAMP(6);
-        if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = pending;       // visible after the barrier below and the next tile's
+        if (new_strip && threadIdx.x == 0) ring[(cur.ord + D) & 3] = ticket_ls(pending);       // visible after the barrier below and the next tile's
         __syncthreads();                                                             // a1 patch of the next tile complete; phase B is over
         S123_STAMP(7);
         cur = nx1;
