@@ -1027,7 +1027,7 @@ static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1,
     if (grid4 > tiles) grid4 = tiles;
     // inference: one patch buffer and four blocks per CU (34 KiB, 120 registers); train step: two buffers, three blocks (0.172 -> 0.169 ms for
     // cfg5 / 1.200 -> 1.192 ms for the bf16 train step against the other assignment)
-    const int xb = write_a1 ? 2 : 1;
+    int xb = write_a1 ? 2 : 1;
 #define UBD_SEP12_LAUNCH(PLAIN, WR)                                                                                                   \
     do { if (xb == 1) hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T, 1>), dim3(grid4), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
                        bias2, n, H, W, H2, W2, pad_lo, sub, div); else hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T, 2>), dim3(grid), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
@@ -1040,6 +1040,7 @@ static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1,
             return;
         }
     }
+    xb = 2;                                                    // register-staged input: the three-blocks-per-CU build (128 registers would spill); one patch buffer either way
     if (write_a1) UBD_SEP12_LAUNCH(false, true); else UBD_SEP12_LAUNCH(false, false);
 #undef UBD_SEP12_LAUNCH
 }
