@@ -84,7 +84,7 @@ class ModelRunner:
         assert not rescale or (meta_infos is not None and len(images) == len(meta_infos))
         x = np.asarray(images)
         if x.dtype != np.uint8:
-            x = x.astype(np.float32)
+            x = x.astype(np.float32, copy=False)        # no second 100-MB host copy when the batch is float32 already
         # float images arrive already preprocessed, as in the reference; uint8 images are raw pixels and take the
         # NetConfig preprocessing fused into the first layer (one rule for every entry point)
         xt = torch.from_numpy(np.ascontiguousarray(x)).to(model.device)

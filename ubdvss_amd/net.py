@@ -366,7 +366,7 @@ class Model:
         and get ``NetConfig``'s preprocessing fused into the first layer, exactly like ``predict_on_device``."""
         x = np.asarray(images)
         if x.dtype != np.uint8:
-            x = x.astype(np.float32)
+            x = x.astype(np.float32, copy=False)
         xt = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
         return self.predict_on_device(xt).cpu().numpy()
 
