@@ -620,15 +620,25 @@ def main():
         # tools/gpu_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads)
         traffic = None
         try:
-            vals = {}
-            pmc_file = "r03_pmc_dilconv_wino.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_dilconv_wino.txt")) else "r02_pmc_dilconv_wino.txt"
-            for ln in open(os.path.join(ROOT, "profiles", pmc_file)):
-                parts = ln.split()
-                if len(parts) >= 2:
-                    vals[parts[0]] = float(parts[1])
-            traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / 1e6, 1)     # MB per launch
+            # per-kernel table of tools/gpu_pmc_traffic.sh (read MB already doubled, write MB): the row of the <0> instantiation
+            # alone -- the name filter of tools/gpu_pmc.sh also matches the last layer's <2> (head fused, 2 MB written)
+            for ln in open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_fwd_fp32.txt")):
+                if ln.startswith("void dilconv_wino_kernel<0"):
+                    parts = ln.split()
+                    traffic = round(float(parts[-2]) + float(parts[-1]), 1)
         except Exception:
             traffic = None
+        if traffic is None:                                   # older profile sets: counters of all dilconv_wino launches of a pass
+            try:
+                vals = {}
+                pmc_file = "r03_pmc_dilconv_wino.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_dilconv_wino.txt")) else "r02_pmc_dilconv_wino.txt"
+                for ln in open(os.path.join(ROOT, "profiles", pmc_file)):
+                    parts = ln.split()
+                    if len(parts) >= 2:
+                        vals[parts[0]] = float(parts[1])
+                traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / 1e6, 1)     # MB per launch
+            except Exception:
+                traffic = None
         # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary (full-size launches only: the
         # batch-1 latency leg launches it on 1 x 128 x 128 maps for a few microseconds)
         profile_avg_us, profile_file = None, None
@@ -649,7 +659,7 @@ def main():
                 break
         roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
-                    "traffic": traffic, "traffic_unit": "MB/launch (PMC, profiles/r03_pmc_dilconv_wino.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
+                    "traffic": traffic, "traffic_unit": "MB/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_pmc_traffic_fwd_fp32.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
                     "profile_avg_us": profile_avg_us, "profile_file": profile_file,
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
                     "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
