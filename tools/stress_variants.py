@@ -2,6 +2,8 @@
   * bf16 / fp16 forward: LDS-staged dilated kernel vs direct kernel (UBD_DILCONV16=direct)
   * bf16 train step: data gradient fused into the weight-gradient kernel vs the two-kernel path (UBD_DILBWD=split)
   * fp32 inference: one-kernel stem vs three kernels (UBD_STEM=fused123 / unfused), fp32 and uint8 input
+  * 16-bit passes: L1 -> L2 in one kernel vs two kernels (UBD_STEM16=split), forward (fp32 and uint8 input) and bf16 train step
+(UBD_VARIANT_RANDOM_SHAPES=n adds n random shapes)
 on ragged and non-square shapes (sides are multiples of 4, maps not multiples of 16, narrow sub-grids)."""
 import os, sys
 import numpy as np, torch
@@ -9,9 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
 torch.cuda.set_device(0)
 shapes = [(1, 68, 140), (2, 100, 76), (1, 132, 260), (1, 516, 36), (2, 36, 516), (3, 200, 328), (1, 1028, 68), (2, 260, 260), (1, 64, 64), (5, 128, 192)]
+_rng = np.random.default_rng(int(os.environ.get("UBD_VARIANT_SEED", "3")))
+for _ in range(int(os.environ.get("UBD_VARIANT_RANDOM_SHAPES", "0"))):
+    shapes.append((int(_rng.integers(1, 7)), 4 * int(_rng.integers(4, 100)), 4 * int(_rng.integers(4, 100))))
 bad = 0
 def model(env, **kw):
-    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM"): os.environ.pop(k, None)
+    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM", "UBD_STEM16"): os.environ.pop(k, None)
     os.environ.update(env)
     return Model(NetConfig(grey=False), seed=7, **kw)
 for (n, h, w) in shapes:
@@ -29,12 +34,20 @@ for (n, h, w) in shapes:
         t = Trainer(model(env, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y); g.append(t.grads.clone())
     ok = torch.equal(g[0], g[1]) and bool(torch.isfinite(g[0]).all()); bad += not ok
     print(f"{n}x{h}x{w} bf16 train fused == split: {ok}", flush=True)
+    t = Trainer(model({"UBD_STEM16": "split"}, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y)
+    ok = torch.equal(g[0], t.grads); bad += not ok
+    print(f"{n}x{h}x{w} bf16 train, L1 -> L2 in one kernel == two kernels: {ok}", flush=True)
     x8 = torch.from_numpy(np.random.default_rng(n * h).integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
     for name, inp in (("fp32", x), ("uint8", x8)):
         a = model({"UBD_STEM": "fused123"}).predict_on_device(inp).clone()
         b = model({"UBD_STEM": "unfused"}).predict_on_device(inp).clone()
         ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
         print(f"{n}x{h}x{w} fp32 net, {name} input, stem fused123 == unfused: {ok}", flush=True)
+        for dt in ("bfloat16", "float16"):
+            a = model({}, dtype=dt).predict_on_device(inp).clone()
+            b = model({"UBD_STEM16": "split"}, dtype=dt).predict_on_device(inp).clone()
+            ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
+            print(f"{n}x{h}x{w} {dt} net, {name} input, L1 -> L2 in one kernel == two kernels: {ok}", flush=True)
 # ---- repeat runs at the headline sizes: every launch of the persistent kernels must reproduce the first one bit for bit
 REPS = int(os.environ.get("UBD_VARIANT_REPEATS", "200"))
 x = torch.from_numpy(synthetic.noise_images(5, 32, 512, 512, 3)).cuda()
