@@ -110,6 +110,29 @@ def test_ragged_and_tiny_maps_vs_oracle():
         _compare(_model(2), lg2, 2, min_area=1, cap=4200)
 
 
+def test_random_shape_soak_vs_oracle():
+    """Random map sizes (1 .. 160 per side: below, at and above the 16384-pixel limit of the one-launch form), random density, random
+    morphology (noise, closed / opened noise, blobs with holes), min_area 0 / 5, with and without classes: every case bit-exact against
+    the oracle through the fixture's three code paths.  UBD_PP_SOAK_CASES scales it (default 24 cases per path)."""
+    rng = np.random.default_rng(2024)
+    for case in range(int(os.environ.get("UBD_PP_SOAK_CASES", "24"))):
+        h, w = int(rng.integers(1, 161)), int(rng.integers(1, 161))
+        n = int(rng.integers(1, 5))
+        p = float(rng.uniform(0.05, 0.95))
+        m = rng.random((n, h, w)) < p
+        kind = int(rng.integers(0, 4))
+        if h >= 3 and w >= 3:
+            for i in range(n):
+                if kind == 1: m[i] = ndi.binary_closing(m[i])
+                elif kind == 2: m[i] = ndi.binary_opening(m[i])
+                elif kind == 3: m[i] = ndi.binary_dilation(ndi.binary_erosion(m[i], iterations=2), iterations=3) & ~(rng.random((h, w)) < 0.02)
+        n_cls = int(rng.choice([0, 0, 3]))
+        lg = np.where(m[..., None], 1.0, -1.0).astype(np.float32)
+        if n_cls:
+            lg = np.concatenate([lg, rng.normal(0, 1, (n, h, w, n_cls)).astype(np.float32)], axis=-1)
+        _compare(_model(n_cls), lg, n_cls, min_area=int(rng.choice([0, 5])), cap=8192)
+
+
 def test_isolated_pixel_grids_on_odd_sizes():
     """Most components a map can hold: isolated pixels on every other row and column = ceil(h/2) * ceil(w/2) external
     components, which exceeds h*w/4 when a side is odd (127 x 127: 4096).  Every one has contourArea 0, so min_area -1

@@ -4,7 +4,6 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ubdvss_amd import NetConfig, Model, ModelRunner, synthetic
-from oracle import net_numpy as onet      # weights initialiser only (a tool, not the product)
 torch.cuda.set_device(0)
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
 bad = 0
@@ -33,7 +32,6 @@ for case in range(cases):
     if n_img * hh * ww > 36 * 512 * 512: n_img = max(1, 36 * 512 * 512 // (hh * ww))
     cfg = NetConfig(class_names=[f"c{i}" for i in range(n_cls)] if n_cls else None, grey=False)
     model = Model(cfg, seed=5 + case)
-    model.set_weights(onet.init_weights(41 + case, 3, n_cls, bias_scale=0.3))
     serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
     batches = []
     for k in range(4):
