@@ -61,6 +61,38 @@ def test_vs_numpy_oracle(cin, ncls, fml, n, hh, ww):
     _check(lg, ref)
 
 
+def test_random_shape_soak_vs_oracle(monkeypatch):
+    """Random batch sizes and image sides (multiples of 4 from 16 to 160: tiles cut by both borders, maps narrower than a tile, dilation
+    sub-grids of one pixel), grey / RGB, with / without classes, both padding rules, float and uint8 input, every stem variant (the
+    one-kernel stem is forced on half of the cases: UBD_STEM is read when the handle is created).  UBD_FWD_SOAK_CASES scales it."""
+    from ubdvss_amd.net import PreprocessingType
+    rng = np.random.default_rng(77)
+    for case in range(int(os.environ.get("UBD_FWD_SOAK_CASES", "16"))):
+        cin, ncls, fml = int(rng.choice([1, 3])), int(rng.choice([0, 0, 2])), bool(rng.integers(0, 2))
+        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(4, 41)), 4 * int(rng.integers(4, 41))
+        u8 = bool(rng.integers(0, 2))
+        stem = str(rng.choice(["fused123", "fused", "unfused", ""]))
+        if stem: monkeypatch.setenv("UBD_STEM", stem)
+        else: monkeypatch.delenv("UBD_STEM", raising=False)
+        w = onet.init_weights(300 + case, cin, ncls, bias_scale=0.25)
+        cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml,
+                        preprocessing=PreprocessingType.MOBILENET_LIKE if u8 else PreprocessingType.NONE)
+        m = Model(cfg)
+        m.set_weights(w)
+        if u8:
+            x8 = rng.integers(0, 256, (n, hh, ww, cin), dtype=np.uint8)
+            ref = onet.forward((x8.astype(np.float64) - 127.5) / 127.5, w, fml)
+            lg = m.predict(x8)
+        else:
+            x = synthetic.noise_images(case, n, hh, ww, cin)
+            ref = onet.forward(x.astype(np.float64), w, fml)
+            lg = m.predict(x)
+        try:
+            _check(lg, ref)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: cin {cin} classes {ncls} fml {fml} {n} x {hh} x {ww} uint8 {u8} UBD_STEM={stem!r}: {e}")
+
+
 def test_identity_kernels_kat():
     """centre-tap identity kernels in L4..L9 leave the (non-negative) L3 output unchanged, so the
     logits equal head(L3 output): isolates halo / dilation addressing."""

@@ -87,6 +87,17 @@ def test_forward16_vs_oracle(dtype, cin, ncls, fml, n, hh, ww):
     _run(dtype, cin, ncls, fml, n, hh, ww, 50 + cin + ncls)
 
 
+def test_forward16_random_shape_soak():
+    """Random small shapes (sides multiples of 4 from 16 to 160, 1-3 images, grey / RGB, with / without classes, both padding rules,
+    both 16-bit types) against the rounding-aware and the fp64 oracle, same gates as above.  UBD_FWD16_SOAK_CASES scales it."""
+    rng = np.random.default_rng(99)
+    for case in range(int(os.environ.get("UBD_FWD16_SOAK_CASES", "12"))):
+        dtype = str(rng.choice(["bfloat16", "float16"]))
+        cin, ncls, fml = int(rng.choice([1, 3])), int(rng.choice([0, 0, 2])), bool(rng.integers(0, 2))
+        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(4, 41)), 4 * int(rng.integers(4, 41))
+        _run(dtype, cin, ncls, fml, n, hh, ww, 400 + case)
+
+
 def test_cfg5_shape_fp16_1024():
     """configs[4]: 1024x1024 fp16 forward with dilation rates 1,2,4,8,16(,1); batch reduced to 2 for the oracle."""
     _run("float16", 3, 0, True, 2, 1024, 1024, 77)
