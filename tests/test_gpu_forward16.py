@@ -138,7 +138,12 @@ def _train_step_16bit_case(dtype, tol64, cin, ncls, fml, n, hh, ww):
     by backward hooks).  A storage rounding can flip by one 16-bit ulp between two correct evaluations that accumulate
     differently (fp32 vs fp64), and such flips compound down the layers, so there are two gates:
       * against the oracle evaluated in fp32, like the kernels: every weight-gradient tensor within 5e-3 (relative L2);
-      * against the oracle evaluated in fp64: within `tol64` (the fp32-vs-fp64 oracle spread itself reaches 2e-2)."""
+      * against the oracle evaluated in fp64: within `tol64` (the fp32-vs-fp64 oracle spread itself reaches 2e-2).
+    The shapes of these tests are fixed on purpose: a random-shape soak of this comparison (round 3) tripped on small maps where the
+    16-bit logits of the kernel and of the oracle rank two near-tied hard negatives differently -- the bias gradient of the head
+    then still agrees to 1e-6 (the two candidates weigh the same) while every other tensor moves by 0.3-2 % (k = 318 of 828 pixels;
+    tests/diag_train16_case.py prints the per-tensor figures, and the two ORACLE evaluations differ by as much on a neighbouring
+    case).  The top-k choice is discontinuous; fp32 logits agree to 1e-6 and the fp32 soak (test_gpu_train.py) has no such cases."""
     from oracle import net_torch as otorch
     from ubdvss_amd import Trainer, Adam
     cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml)

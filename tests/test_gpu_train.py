@@ -47,6 +47,20 @@ def test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww):
     assert off == g.size
 
 
+def test_gradients_random_shape_soak():
+    """fp32 train step on random small shapes (sides multiples of 4 from 32 to 128, 1-3 images, grey / RGB, with / without classes, both
+    padding rules) against the fp64 autograd oracle, same gates as above.  UBD_TRAIN_SOAK_CASES scales it (default 4)."""
+    import os
+    rng = np.random.default_rng(123)
+    for case in range(int(os.environ.get("UBD_TRAIN_SOAK_CASES", "4"))):
+        cin, ncls, fml = int(rng.choice([1, 3])), int(rng.choice([0, 0, 2])), bool(rng.integers(0, 2))
+        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, 33)), 4 * int(rng.integers(8, 33))
+        try:
+            test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: cin {cin} classes {ncls} fml {fml} {n} x {hh} x {ww}: {e}")
+
+
 def test_gradients_direct_dilated_kernel_path(monkeypatch):
     """fp32 train step with UBD_DILCONV=direct: forward and data gradient of the dilated layers on the implicit-GEMM kernel."""
     monkeypatch.setenv("UBD_DILCONV", "direct")
