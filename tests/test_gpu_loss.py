@@ -44,6 +44,26 @@ def test_random_vs_oracle(n_cls, n, h, w):
     _check(yt, yp, n_cls > 0)
 
 
+def test_random_shape_soak_vs_oracle():
+    """Random pixel counts (from a single row to 96 x 96 x 5: one chunk per block up to many), class counts 0-8, logit scales from
+    saturating to tiny, label densities from nearly empty to nearly full, and quantised logits (massive ties at the k-th value).
+    UBD_LOSS_SOAK_CASES scales it (default 12)."""
+    rng = np.random.default_rng(4242)
+    for case in range(int(os.environ.get("UBD_LOSS_SOAK_CASES", "12"))):
+        n, h, w = int(rng.integers(1, 6)), int(rng.integers(1, 97)), int(rng.integers(1, 97))
+        n_cls = int(rng.choice([0, 0, 1, 3, 8]))
+        yt = (rng.random((n, h, w)) < rng.uniform(0.01, 0.99)).astype(np.int32)
+        if n_cls:
+            yt = yt * rng.integers(1, n_cls + 1, (n, h, w)).astype(np.int32)
+        yp = rng.normal(rng.uniform(-2, 2), rng.choice([0.05, 1.0, 3.0, 12.0]), (n, h, w, 1 + n_cls)).astype(np.float32)
+        if rng.random() < 0.4:
+            yp[..., 0] = np.round(yp[..., 0] * 2) / 2              # quantised detection logits: ties at the threshold of the top-k
+        try:
+            _check(yt, yp, n_cls > 0)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {n} x {h} x {w}, {n_cls} classes: {e}")
+
+
 def test_degenerate_and_ties():
     rng = np.random.default_rng(0)
     yp = rng.normal(0, 1, (1, 16, 16, 1)).astype(np.float32)
