@@ -299,7 +299,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_tiecount_kernel(const float *
     __shared__ double s_red[LOSS_BLOCK / 64];
     __shared__ unsigned s_part[256];
     __shared__ loss_sel s_sel;
-    const unsigned T = loss_select_block(hdr, hist2, 2, npix_total, s_part, &s_sel).prefix;    // final threshold bits
+    const loss_sel fin = loss_select_block(hdr, hist2, 2, npix_total, s_part, &s_sel);
+    const unsigned T = fin.prefix;                                                              // final threshold bits
+    // every element equal to the threshold is selected (the bin's count == the number still needed: always, unless the k-th value
+    // repeats): nobody needs tie ranks -- the gradient kernel tests the same condition and does not read the counts
+    if (hist2[T & 1023u] == fin.k_rem) return;
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
     int c = 0;
     long p = lo + threadIdx.x;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
                                                                loss_hdr *hdr, const unsigned *__restrict__ blockties,
                                                                const float *__restrict__ ce_buf, float *__restrict__ dlogits,
                                                                long npix_total, const unsigned *__restrict__ rank_ties, int rank,
-                                                               int raw_ties, float *__restrict__ loss4)
+                                                               int raw_ties, float *__restrict__ loss4, const unsigned *__restrict__ hist2)
 {
     // raw_ties: blockties holds the per-block COUNTS (no loss_tiescan launch): the block sums the counts in front of it itself.
     // loss4 != nullptr: the last block out also evaluates the loss values (no loss_finalize launch).  Both are set on one GPU /
@@ -392,45 +396,12 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
     const float w_cls = (float)(1.0 / n_pos);
     const int n_cls = k_out - 1;
     const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < npix ? lo + chunk : npix;
-    unsigned tie_base;                                  // ties before this iteration of this block
-    if (raw_ties) {
-        const double before = block_reduce_sum(threadIdx.x < blockIdx.x ? (double)blockties[threadIdx.x] : 0.0, s_red);   // grid <= LOSS_MAX_BLOCKS <= block size
-        if (threadIdx.x == 0) s_wave_ties[0] = (unsigned)before;          // the sum is valid in thread 0: hand it to everybody
-        __syncthreads();
-        tie_base = s_wave_ties[0];
-        __syncthreads();
-    } else {
-        tie_base = blockties[blockIdx.x];
-    }
-    for (int j = 0; j < rank; ++j) tie_base += rank_ties[j];    // batch-global mode: the ranks before this one hold the lower flat indices
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double s_hard = 0, s_cls = 0;
     int c_correct = 0;
-    for (long base = lo; base < hi; base += blockDim.x) {
-        const long p = base + threadIdx.x;
-        const bool active = p < hi;
-        unsigned bits = 0;
-        if (active) bits = __float_as_uint(ce_buf[p]);
-        const bool is_tie = active && (bits == T);
-        // rank of this tie among all ties in flat-index order
-        const unsigned long long bal = __ballot(is_tie);
-        const unsigned before_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) s_wave_ties[wid] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned before_waves = 0, total_iter = 0;
-        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) {
-            const unsigned c = s_wave_ties[w2];
-            if (w2 < wid) before_waves += c;
-            total_iter += c;
-        }
-        const unsigned tie_rank = tie_base + before_waves + before_in_wave;
-        tie_base += total_iter;
-        if (!active) continue;
-        const float x = logits[p * k_out];
-        const int yt = y_true[p];
+    // one pixel: hard-negative sum, gradient of the detection logit, classification part
+    auto pixel = [&](long p, unsigned bits, bool sel, float x, int yt) {
         const float z = yt > 0 ? 1.f : 0.f;
-        const bool sel = (bits > T) || (is_tie && tie_rank < need_eq);
         if (sel) s_hard += (double)__uint_as_float(bits);
         const float xc = fminf(fmaxf(x, LOGIT_LO), LOGIT_HI);
         const bool inside = (x >= LOGIT_LO) && (x <= LOGIT_HI);
@@ -459,6 +430,64 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
                 for (int c = 0; c < n_cls; ++c) dlogits[p * k_out + 1 + c] = 0.f;
             }
         }
+    };
+    // Every element equal to the threshold is selected when the threshold bin of the last histogram holds exactly the number still
+    // needed (always, unless the k-th value repeats, e.g. an exact 0): then no tie needs a rank, and the pass is a plain stream --
+    // no ballots, no two block barriers per trip, no prefix over the blocks' tie counts (loss_tiecount_kernel has returned early on
+    // the same test and left them unwritten).  In the batch-global mode histogram and need_eq are global, so is the test.
+    if (hist2[T & 1023u] == need_eq) {
+        long p = lo + threadIdx.x;
+        for (; p + 3 * (long)blockDim.x < hi; p += 4 * (long)blockDim.x) {        // four pixels' loads in flight
+            unsigned b[4];
+            float x[4];
+            int yt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long pu = p + u * (long)blockDim.x;
+                b[u] = __float_as_uint(ce_buf[pu]); x[u] = logits[pu * k_out]; yt[u] = y_true[pu];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pixel(p + u * (long)blockDim.x, b[u], b[u] >= T, x[u], yt[u]);
+        }
+        for (; p < hi; p += blockDim.x) {
+            const unsigned b = __float_as_uint(ce_buf[p]);
+            pixel(p, b, b >= T, logits[p * k_out], y_true[p]);
+        }
+    } else {
+    unsigned tie_base;                                  // ties before this iteration of this block
+    if (raw_ties) {
+        const double before = block_reduce_sum(threadIdx.x < blockIdx.x ? (double)blockties[threadIdx.x] : 0.0, s_red);   // grid <= LOSS_MAX_BLOCKS <= block size
+        if (threadIdx.x == 0) s_wave_ties[0] = (unsigned)before;          // the sum is valid in thread 0: hand it to everybody
+        __syncthreads();
+        tie_base = s_wave_ties[0];
+        __syncthreads();
+    } else {
+        tie_base = blockties[blockIdx.x];
+    }
+    for (int j = 0; j < rank; ++j) tie_base += rank_ties[j];    // batch-global mode: the ranks before this one hold the lower flat indices
+    for (long base = lo; base < hi; base += blockDim.x) {
+        const long p = base + threadIdx.x;
+        const bool active = p < hi;
+        unsigned bits = 0;
+        if (active) bits = __float_as_uint(ce_buf[p]);
+        const bool is_tie = active && (bits == T);
+        // rank of this tie among all ties in flat-index order
+        const unsigned long long bal = __ballot(is_tie);
+        const unsigned before_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) s_wave_ties[wid] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before_waves = 0, total_iter = 0;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) {
+            const unsigned c = s_wave_ties[w2];
+            if (w2 < wid) before_waves += c;
+            total_iter += c;
+        }
+        const unsigned tie_rank = tie_base + before_waves + before_in_wave;
+        tie_base += total_iter;
+        if (!active) continue;
+        pixel(p, bits, (bits > T) || (is_tie && tie_rank < need_eq), logits[p * k_out], y_true[p]);
+    }
     }
     double r = block_reduce_sum(s_hard, s_red);
     if (threadIdx.x == 0 && r != 0) atomicAdd(&hdr->sum_hard, r);
@@ -528,13 +557,13 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
         hipLaunchKernelGGL(loss_tiescan_kernel, dim3(1), dim3(1024), 0, st, blockties, cgrid);
         if ((rc = ubd_comm_allgather_u32(h, blockties + cgrid, rankties, st))) return rc;     // this rank's tie count -> everyone
         hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
-                           npix_total, rankties, rank, 0, (float *)nullptr);
+                           npix_total, rankties, rank, 0, (float *)nullptr, hist + 4096);
         if ((rc = ubd_comm_allreduce_raw(h, &hdr->sum_hard, 2, UBD_RED_F64, st))) return rc;
         if ((rc = ubd_comm_allreduce_raw(h, &hdr->cls_correct, 1, UBD_RED_I32, st))) return rc;
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, hdr, npix_total, k_out - 1, loss);
     } else {                                             // one launch: prefix of the tie counts, gradient, loss values
         hipLaunchKernelGGL(loss_grad_kernel, dim3(cgrid), dim3(LOSS_GRAD_BLOCK), 0, st, logits, k_out, y_true, npix, chunk, hdr, blockties, ce, dlogits,
-                           npix_total, rankties, rank, 1, loss);
+                           npix_total, rankties, rank, 1, loss, hist + 4096);
     }
     UBD_CHECK_HIP(hipGetLastError());
     return 0;
