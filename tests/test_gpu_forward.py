@@ -316,3 +316,34 @@ def test_fused_stem_path(monkeypatch):
         for mode in ("fused", "fused123"):
             assert np.abs(outs[(mode, cin, ncls, fml, n, hh, ww)] - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), (mode, cin, fml, hh, ww)
         assert np.array_equal(outs[("fused123", cin, ncls, fml, n, hh, ww)], outs[("fused123_few_cus", cin, ncls, fml, n, hh, ww)])   # tile -> block assignment is irrelevant
+
+
+@pytest.mark.parametrize("few_cus", [False, True])
+def test_unfused_call_then_prepacked_fused_call_on_a_poisoned_workspace(monkeypatch, few_cus):
+    """ADVICE r3 (high): a forward pass that takes the three separate stem kernels packs the weights and stores the packed key;
+    the NEXT call on the same workspace is sent as UBD_IN_PREPACKED and may qualify for the one-kernel stem, whose strip-ticket /
+    check-out counters live in the workspace (torch.empty: garbage).  They must have been zeroed by the call that packed,
+    whichever stem variant it ran.  Real shapes (8 x 512^2 = 256 strips < 2 x 256 CUs, then 32 x 256^2 = 512 strips) and a
+    two-CU handle (1 x 28 x 512 = 2 strips, then 4 x 32 x 64 = 8 strips)."""
+    if few_cus:
+        monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
+        shapes = ((1, 28, 512), (4, 32, 64))
+    else:
+        shapes = ((8, 512, 512), (32, 256, 256))
+    cfg = NetConfig(grey=False)
+    w = onet.init_weights(77, 3, 0, bias_scale=0.2)
+    m = Model(cfg); m.set_weights(w)
+    lib, h = m._lib, m._h
+    (na, ha, wa), (nb, hb, wb) = shapes
+    nbytes = max(lib.ubd_forward_workspace_bytes(h, na, ha, wa), lib.ubd_forward_workspace_bytes(h, nb, hb, wb))
+    m._ws = torch.full((int(nbytes),), 0xA5, dtype=torch.uint8, device="cuda")      # poisoned: tickets = 0xA5A5A5A5 (negative)
+    xa = torch.from_numpy(synthetic.noise_images(3, na, ha, wa, 3)).cuda()
+    xb = torch.from_numpy(synthetic.noise_images(4, nb, hb, wb, 3)).cuda()
+    m.predict_on_device(xa)                                       # unfused stem, packs
+    assert m._packed_key is not None
+    got = m.predict_on_device(xb)                                 # prepacked + one-kernel stem
+    fresh = Model(cfg); fresh.set_weights(w)
+    assert torch.equal(got, fresh.predict_on_device(xb))
+    assert torch.equal(m.predict_on_device(xb), got)              # and the counters reset themselves for the call after
+    if few_cus:
+        _check(got.cpu().numpy(), onet.forward(xb.cpu().numpy().astype(np.float64), w))

@@ -22,6 +22,8 @@ def front_end(request, monkeypatch):
     ONE-LANE form of the box fit (UBD_PP_SERIAL_TAIL: hull clean-up and rotating calipers on lane 0 over LDS arrays, what hulls
     of more than 64 vertices take; the other two variants run the wave-uniform register form), "global" = the multi-launch
     global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    from ubdvss_amd import segmap_manager
+    segmap_manager._reset_handles()          # the switches are read when a handle is created
     monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
     monkeypatch.delenv("UBD_PP_SPLIT", raising=False)
     monkeypatch.delenv("UBD_PP_SERIAL_TAIL", raising=False)
@@ -30,7 +32,8 @@ def front_end(request, monkeypatch):
     elif request.param == "lds_split":
         monkeypatch.setenv("UBD_PP_SPLIT", "1")
         monkeypatch.setenv("UBD_PP_SERIAL_TAIL", "1")
-    return request.param
+    yield request.param
+    segmap_manager._reset_handles()          # no handle created under a switch outlives the test
 
 
 def _model(ncls=0, cin=3):

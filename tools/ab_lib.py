@@ -1,12 +1,12 @@
 """A/B of two builds of the library inside ONE process on one box (box-to-box timing differences reach 10 %): bf16 train step
-and the cfg5 fp16 forward with libubd_hip.so vs libubd_hip_old.so, interleaved."""
+and the cfg5 fp16 forward with two builds kept under tools/_ab/ (git-ignored scratch; cp ubdvss_amd/libubd_hip.so tools/_ab/new.so), interleaved."""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np, torch
     sys.path.insert(0, ROOT)
     from ubdvss_amd import _lib
-    _lib.LIB_PATH = os.path.join(ROOT, "ubdvss_amd", sys.argv[2])
+    _lib.LIB_PATH = sys.argv[2] if os.path.isabs(sys.argv[2]) else os.path.join(ROOT, "tools", "_ab", sys.argv[2])
     from ubdvss_amd import NetConfig, Model, ModelRunner, Trainer, Adam, synthetic
     torch.cuda.set_device(0)
     def timed(fn, reps):
@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     for rep in range(2):
-        for lib in (sys.argv[1:] or ["libubd_hip_old.so", "libubd_hip.so"]):       # other builds: names inside ubdvss_amd/
+        for lib in (sys.argv[1:] or ["old.so", "new.so"]):       # other builds: names inside tools/_ab/
             env = dict(os.environ)
             name = lib
             if "@" in lib:                                                    # libname@VAR=value: the child runs with that variable set

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Diagnostic build: libubd_hip_diag.so = the product sources + -DUBD_STAMPS (in-kernel s_memtime stamps, an extra
-# exported ubd_debug_set_stamps).  Never loaded by the package; tools/stamps_*.py load it explicitly.
+# exported ubd_debug_set_stamps).  Written to tools/_ab/ (git-ignored scratch, emptied before the round ends). Never loaded by the package; tools/stamps_*.py load it explicitly.
 set -e
 cd "$(dirname "$0")/../ubdvss_amd/csrc"
-mkdir -p _obj_diag
+OBJ=../../tools/_ab/_obj_diag
+mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
 pids=()
 for f in api forward fwd16 wino postprocess loss backward train comm raster; do
@@ -11,9 +12,9 @@ for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
   [ "$f" = "raster" ] && extra="-ffp-contract=off"
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
-  ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj_diag/$f.o ) &
+  ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../${DIAG_OUT:-libubd_hip_diag.so} _obj_diag/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_ab/${DIAG_OUT:-libubd_hip_diag.so} $OBJ/*.o -ldl
 echo "built ${DIAG_OUT:-libubd_hip_diag.so}"

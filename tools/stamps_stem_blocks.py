@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ubdvss_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "ubdvss_amd", "libubd_hip_diag.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "_ab", "libubd_hip_diag.so")
 from ubdvss_amd import NetConfig, Model, synthetic
 torch.cuda.set_device(0)
 lib = _lib.load()

@@ -53,6 +53,11 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         { const char *c = getenv("UBD_TEST_NUM_CUS"); if (c && atoi(c) > 0) h->num_cus = atoi(c); }
         { const char *b = getenv("UBD_DILBWD"); h->split_dilbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_STEM16"); h->split_stem16 = (b && strcmp(b, "split") == 0) ? 1 : 0; }
+        // postprocess test hooks (multi-launch front end at any map size / separate tail launches / LDS poisoning + forest integrity
+        // check / one-lane box fit / the 512-thread block shape the job has inside the stem kernel)
+        h->pp_global = getenv("UBD_PP_GLOBAL") != nullptr; h->pp_split = getenv("UBD_PP_SPLIT") != nullptr;
+        h->pp_poison = getenv("UBD_PP_POISON") != nullptr; h->pp_serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr;
+        h->pp_threads_512 = getenv("UBD_PP_THREADS_512") != nullptr;
         { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }
     }
     // Keras model.get_weights() order

@@ -759,7 +759,13 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     float *wfrag = (float *)(ws + L.off_wfrag);
     float *a1 = (float *)(ws + L.off_a1), *a2 = (float *)(ws + L.off_a2);
 
-    if (!prepacked) launch_pack(h, params, wfrag, st);
+    if (!prepacked) {
+        launch_pack(h, params, wfrag, st);
+        // strip tickets of the one-kernel stem ([0]) and its check-out counter ([16]): the kernel leaves both at zero, so they are
+        // zeroed whenever the caller does not vouch for the workspace -- whichever stem variant THIS call runs (the next, prepacked
+        // call on the same workspace may qualify for the one-kernel stem when this one does not, e.g. 8 x 512^2 then 32 x 256^2)
+        UBD_CHECK_HIP(hipMemsetAsync(ws + L.off_tickets, 0, 256, st));
+    }
 
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
@@ -782,11 +788,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
         memset(&pj, 0, sizeof(pj));                              // n = 0: no postprocess job rides along
         if (pp_job) pj = *pp_job;
         const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
-        // strip tickets of the one-kernel stem ([0]) and its check-out counter ([16]): the kernel leaves both at zero, so they are
-        // zeroed here only when the caller does not vouch for the workspace (UBD_IN_PREPACKED: intact since the previous
-        // ubd_forward of this handle, which then left the counters at zero as well)
-        int *ticket = (int *)(ws + L.off_tickets);
-        if (!prepacked) UBD_CHECK_HIP(hipMemsetAsync(ticket, 0, 256, st));
+        int *ticket = (int *)(ws + L.off_tickets);               // zeroed with the weight pack above; the kernel resets them itself
 #ifdef UBD_STAMPS
 #define S123_STAMP_ARG , g_ubd_stamps
 #else

@@ -528,10 +528,10 @@ int ubd_pp_fill_job(ubd_handle *hd, const float *logits, int n, int map_h, int m
     pp_layout_compute(n, map_h, map_w, cap, n_cls, &L);
     if (workspace_bytes < L.total) { ubd_set_error("ubd_postprocess: workspace too small (%zu < %zu)", workspace_bytes, L.total); return -1; }
     const long hw = (long)map_h * map_w;
-    if (hw > PP_LDS_MAX_HW || (PP_LDS_MAX_HW % threads) != 0 || getenv("UBD_PP_GLOBAL") || getenv("UBD_PP_SPLIT") || !pp_tail_fits(map_h, map_w, L.root_cap)) return 0;
+    if (hw > PP_LDS_MAX_HW || (PP_LDS_MAX_HW % threads) != 0 || hd->pp_global || hd->pp_split || !pp_tail_fits(map_h, map_w, L.root_cap)) return 0;
     char *ws = (char *)workspace;
     a->logits = logits; a->n = n; a->k_out = hd->k_out; a->h = map_h; a->w = map_w; a->cap = cap; a->n_cls = n_cls; a->root_cap = L.root_cap;
-    a->poison = getenv("UBD_PP_POISON") != nullptr; a->serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr; a->scale = scale; a->thr = logit_threshold; a->min_area = min_area;
+    a->poison = hd->pp_poison; a->serial_tail = hd->pp_serial_tail; a->scale = scale; a->thr = logit_threshold; a->min_area = min_area;
     a->binary_map = binary_map; a->g_nroots = (int *)(ws + L.off_nroots); a->g_nkept = (int *)(ws + L.off_nkept);
     a->g_roots = (int *)(ws + L.off_roots); a->stage = (int *)(ws + L.off_stage); a->ymax = (int *)(ws + L.off_ymax); a->rows = (int *)(ws + L.off_rows);
     a->vote = (float *)(ws + L.off_vote); a->quads = quads; a->classes = classes; a->counts = counts;
@@ -566,10 +566,9 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
     int grid = (int)((npix + 255) / 256);
     const int gmax = hd->num_cus * 8;
     if (grid > gmax) grid = gmax;
-    // test hooks, read per call (SegmapManager.postprocess keeps its handles): the multi-launch front end at any map size; LDS
-    // poisoning + forest integrity check of the one-launch front end
-    const bool force_global = getenv("UBD_PP_GLOBAL") != nullptr;
-    const int pp_poison = getenv("UBD_PP_POISON") != nullptr;
+    // test hooks (read once, in ubd_create): the multi-launch front end at any map size; LDS poisoning + forest integrity check
+    const bool force_global = hd->pp_global != 0;
+    const int pp_poison = hd->pp_poison;
     // one launch for the whole postprocess when a wave's box scratch (12 h + 4 ints) fits the dead part of the block's LDS
     bool fused_tail = false;
     if (hw <= PP_LDS_MAX_HW && !force_global) {
@@ -579,10 +578,10 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
             UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
             hd->pp_lds_attr_set = 1;
         }
-        fused_tail = pp_tail_fits(map_h, map_w, L.root_cap) && getenv("UBD_PP_SPLIT") == nullptr;   // UBD_PP_SPLIT: test hook, separate tail launches
+        fused_tail = pp_tail_fits(map_h, map_w, L.root_cap) && !hd->pp_split;   // UBD_PP_SPLIT: test hook, separate tail launches
         pp_lds_args a;
         a.logits = logits; a.n = n; a.k_out = hd->k_out; a.h = map_h; a.w = map_w; a.cap = cap; a.n_cls = n_cls; a.root_cap = L.root_cap;
-        a.poison = pp_poison; a.serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr; a.scale = scale; a.thr = logit_threshold; a.min_area = min_area;
+        a.poison = pp_poison; a.serial_tail = hd->pp_serial_tail; a.scale = scale; a.thr = logit_threshold; a.min_area = min_area;
         a.binary_map = binary_map; a.g_nroots = nroots; a.g_nkept = nkept; a.g_roots = roots; a.stage = stage; a.ymax = ymax; a.rows = rows;
         a.vote = vote; a.quads = quads; a.classes = classes; a.counts = counts;
         a.g_owner = (!fused_tail && n_cls > 0) ? owner : nullptr;
@@ -592,7 +591,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
 #else
         a.stamps = nullptr;
 #endif
-        if (fused_tail && getenv("UBD_PP_THREADS_512")) {        // diagnostics: the block shape the job has inside the stem kernel (512 threads)
+        if (fused_tail && hd->pp_threads_512) {        // diagnostics: the block shape the job has inside the stem kernel (512 threads)
             static bool attr512 = false;
             if (!attr512) { UBD_CHECK_HIP(hipFuncSetAttribute((const void *)pp_front_lds_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_MAX_BYTES)); attr512 = true; }
             hipLaunchKernelGGL((pp_front_lds_kernel<true, 512>), dim3(n), dim3(512), pp_front_lds_bytes(hw, L.root_cap), st, a);
@@ -617,7 +616,7 @@ extern "C" int ubd_postprocess(ubd_handle *hd, const float *logits, int n, int m
         size_t lds = (size_t)waves * (12 * map_h + 4) * sizeof(int);
         while (lds > 64 * 1024 && waves > 1) { waves /= 2; lds /= 2; }
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(64 * waves), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale, getenv("UBD_PP_SERIAL_TAIL") != nullptr);
+            hipLaunchKernelGGL(pp_boxes_wave_kernel, dim3(n), dim3(64 * waves), lds, st, n, map_h, map_w, nkept, stage, ymax, rows, cap, scale, hd->pp_serial_tail != 0);
         } else {                                       // very tall maps: serial per-object fallback in global memory
             const long total = (long)n * cap;
             int bgrid = (int)((total + 63) / 64);

@@ -13,16 +13,26 @@ from . import _lib
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 _handles = {}
-_workspaces = {}          # (device, bytes bucket) -> uint8 tensor: the static entry points reuse their scratch between calls
+_workspaces = {}          # (device, stream) -> uint8 tensor: the static entry points reuse their scratch between calls
 
 
 def _workspace(device, nbytes):
-    """Device scratch of at least nbytes, kept per device (grown when a bigger request comes; never shrunk)."""
-    ws = _workspaces.get(str(device))
+    """Device scratch of at least nbytes, kept per (device, current stream): calls on one stream are ordered, two streams
+    never share a scratch (grown when a bigger request comes; never shrunk)."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[str(device)] = ws
+        _workspaces[key] = ws
     return ws
+
+
+def _reset_handles():
+    """Destroys the cached C-ABI handles (they read the UBD_* test switches when they are created)."""
+    lib = _lib.load()
+    for h in _handles.values():
+        lib.ubd_destroy(h)
+    _handles.clear()
 
 
 def _handle(n_classes, device):
