@@ -38,7 +38,72 @@ BYTES_PER_IMAGE_FP32 = 50.40e6            # layer-wise compulsor
 FLOP_PER_IMAGE = 1.1627e9
 PEAK_MFMA_F32 = 157.3                     # TFLOP/s, MI355X_MICROARCH.md (f32-input MFMA = vector peak)
 PEAK_HBM = 8000.0                         # GB/s
-SETTLE_STEPS = 300                        # untimed steps (settle + warm-up) before any timed region: clock ramp after idle
+SETTLE_STEPS = 300                        # untimed steps (settle + warm-up) before EVERY timed region: clock ramp after idle
+RING = 4                                  # distinct input batches the timed loops rotate over (4 x 100.7 MB > 256 MB Infinity Cache)
+
+
+def timed_events(fn, reps, settle=SETTLE_STEPS):
+    """Mean time of one call of fn in ms (HIP events on torch's current stream = the launch stream of every call here), after
+    `settle` untimed calls: each leg of the line comes after an idle gap (synthetic data generation, allocation), and the chip
+    needs a few hundred back-to-back launches before its clocks are where a long run holds them."""
+    for _ in range(max(1, settle)):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources the library was built from: the committed profile summaries carry the fingerprint of
+    the sources they were measured on (profiles/*_profile_meta.json, tools/profile_meta.py)."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ubdvss_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ubdvss_amd", "csrc", "*.h"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def committed_profile(kernel_prefix):
+    """(traffic MB per launch, average launch us, file names, whether the profile was taken on the sources of this build) from
+    the NEWEST committed profile set under profiles/ -- values measured in another run and labelled as such on the line."""
+    import csv
+    traffic = avg_us = None
+    files = {}
+    meta = {}
+    for rnd in ("r04", "r03", "r02"):
+        if traffic is None:
+            try:
+                for ln in open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_fwd_fp32.txt")):
+                    if ln.startswith(kernel_prefix):
+                        parts = ln.split()
+                        traffic = round(float(parts[-2]) + float(parts[-1]), 1)      # read MB (FETCH_SIZE already doubled) + written MB
+                        files["traffic"] = f"profiles/{rnd}_pmc_traffic_fwd_fp32.txt"
+            except (OSError, ValueError, IndexError):
+                pass
+        if avg_us is None:
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{rnd}_bench_kernel_stats.csv")) as f:
+                    for row in csv.DictReader(f):
+                        if row["Name"].startswith(kernel_prefix):
+                            avg_us = round(float(row.get("FullSizeAverageNs") or row["AverageNs"]) / 1e3, 2)   # full-size launches only
+                            files["avg"] = f"profiles/{rnd}_bench_kernel_stats.csv"
+                            break
+            except (OSError, KeyError, ValueError):
+                pass
+        if not meta:
+            try:
+                meta = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_profile_meta.json")))
+                meta["round"] = rnd
+            except (OSError, ValueError):
+                meta = {}
+    fresh = bool(meta) and meta.get("csrc_sha16") == csrc_sha16() and all(v.startswith(f"profiles/{meta['round']}_") for v in files.values())
+    return traffic, avg_us, files, fresh
 
 
 def parse():
@@ -395,12 +460,33 @@ def main():
     runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024, pipelined=True)
 
     # synthetic batch resident in HBM: stripe-textured rectangles on noise
-    labels = synthetic.rectangle_maps(3 + rank, BATCH, SIDE // 4, SIDE // 4)
-    x = torch.from_numpy(synthetic.textured_images(4 + rank, labels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
-    rect_logits = torch.from_numpy(synthetic.logits_from_maps(labels, 0, seed=5)).to(dev)
+    # The timed loops walk a RING of distinct input batches (RING x 100.7 MB > the 256 MB Infinity Cache), so a step reads its
+    # images from HBM like a real stream of fresh batches would; the figure for ONE re-fed tensor is reported beside it.
+    ring_labels = [synthetic.rectangle_maps(3 + rank + 101 * k, BATCH, SIDE // 4, SIDE // 4) for k in range(RING)]
+    xs = [torch.from_numpy(synthetic.textured_images(4 + rank + 101 * k, ring_labels[k], 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
+          for k in range(RING)]
+    labels, x = ring_labels[0], xs[0]
+    input_ring_mb = round(sum(t.numel() * t.element_size() for t in xs) / 1e6, 1)
+    rect_logits = [torch.from_numpy(synthetic.logits_from_maps(ring_labels[k], 0, seed=5 + k)).to(dev) for k in range(2)]
+    step_no = [0]
 
     def step():
-        return runner.predict_on_device(model, x)
+        step_no[0] += 1
+        return runner.predict_on_device(model, xs[step_no[0] % RING])
+
+    def timed_wall(fn, k):
+        """K calls of fn between barrier + synchronize brackets, wall clock, MAX over ranks -> seconds."""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        sync_all()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     def sync_all():
         runner.flush()                                            # pipelined runner: the last batch's postprocess is still owed
@@ -429,28 +515,42 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH * args.steps / elapsed
     # spread of the (short) timed region: five more blocks of K steps, same brackets; `value` stays the first block
-    block_ms = []
-    for _ in range(5):
-        sync_all()
-        tb0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        bt = time.perf_counter() - tb0
-        if dist is not None:
-            t = torch.tensor([bt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bt = float(t.item())
-        block_ms.append(bt / args.steps * 1e3)
+    block_ms = [timed_wall(step, args.steps) / args.steps * 1e3 for _ in range(5)]
+    # the same step re-fed ONE tensor (rounds 1-3 measured this): x + activations fit the Infinity Cache, the images come from MALL
+    single_ms = timed_wall(lambda: runner.predict_on_device(model, x), args.steps) / args.steps * 1e3
+    # the same pipelined step with the in-stem postprocess job fed RECTANGLE maps (1-8 objects per map) instead of
+    # the previous batch's logits (random-init weights: one blob per image): forward(batch k) + postprocess(rectangle maps) enqueued
+    # together through ubd_forward_postprocess, exactly as the runner does
+    runner.flush()
+    rect_out = [model.alloc_postprocess_outputs(BATCH, SIDE // 4, SIDE // 4, 1024) for _ in range(2)]
+    rect_dst = torch.empty((BATCH, SIDE // 4, SIDE // 4, model.k_out), dtype=torch.float32, device=dev)
+
+    def rect_step():
+        step_no[0] += 1
+        k = step_no[0] & 1
+        job = {"logits": rect_logits[k], "logit_threshold": runner.logit_threshold, "scale": 4, "min_area": cfg.get_min_pixels_for_detection(),
+               "cap": 1024, "outputs": rect_out[k]}
+        model.predict_on_device(xs[step_no[0] % RING], out=rect_dst, postprocess=job)
+
+    for _ in range(50):
+        rect_step()
+    rect_ms = timed_wall(rect_step, args.steps) / args.steps * 1e3
+    rect_counts = rect_out[0][3].cpu().numpy()
 
     # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), batch/GPU = --train-batch:
     #      configs[2] / configs[3] name bf16 activations (fp32 master weights, fp32 accumulation); the fp32
     #      variant is measured beside it
     def time_train(dtype, n_cls=0):
         tb = args.train_batch
-        tlabels = synthetic.rectangle_maps(30 + rank, tb, SIDE // 4, SIDE // 4, n_classes=n_cls)
-        tx = torch.from_numpy(synthetic.textured_images(31 + rank, tlabels, 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
-        ty = torch.from_numpy(tlabels).to(dev)
+        tlabels = [synthetic.rectangle_maps(30 + rank + 101 * k, tb, SIDE // 4, SIDE // 4, n_classes=n_cls) for k in range(RING)]
+        txs = [torch.from_numpy(synthetic.textured_images(31 + rank + 101 * k, tlabels[k], 4, C_IN).astype(np.float32) / 127.5 - 1.0).to(dev)
+               for k in range(RING)]
+        tys = [torch.from_numpy(t).to(dev) for t in tlabels]
+        tno = [0]
+
+        def tstep():
+            tno[0] += 1
+            trainer.train_step_on_device(txs[tno[0] % RING], tys[tno[0] % RING])
         tcfg = cfg if n_cls == 0 else NetConfig(class_names=[f"class{i}" for i in range(n_cls)], grey=False)
         tmodel = Model(tcfg, dtype=dtype, seed=1)
         comm_kind = "single GPU"
@@ -469,17 +569,9 @@ def main():
         trainer = Trainer(tmodel, Adam(lr=1e-3))
         trainer.broadcast_weights()
         for _ in range(max(1, args.warmup) + max(0, SETTLE_STEPS - args.warmup)):
-            trainer.train_step_on_device(tx, ty)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.train_step_on_device(tx, ty)
-        sync_all()
-        tel = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([tel], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tel = float(t.item())
+            tstep()
+        tel = timed_wall(tstep, args.steps)
+        tel_single = timed_wall(lambda: trainer.train_step_on_device(txs[0], tys[0]), args.steps)
         bpe = 4.0 if dtype == "float32" else 2.0
         e_fwd = SIDE * SIDE * (C_IN + 45 + (1 + n_cls) / 16.0)                    # E_fwd elements per image
         train_bytes_per_image = (3 * e_fwd - SIDE * SIDE * C_IN) * bpe             # E_train = 3 E_fwd - H W C_in
@@ -488,8 +580,10 @@ def main():
                "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
                "parallelism": comm_kind,
                "loss_last": round(float(trainer.loss[0]), 5),
-               "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4)}
-        del trainer, tmodel, tx, ty
+               "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4),
+               "input_ring_MB": round(sum(t.numel() * t.element_size() for t in txs) / 1e6, 1),
+               "ms_per_step_single_tensor": round(tel_single / args.steps * 1e3, 4), "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup)}
+        del trainer, tmodel, txs, tys
         torch.cuda.empty_cache()
         return res
 
@@ -504,28 +598,28 @@ def main():
     def time_cfg5():
         n5, side5 = 8, 1024
         m5 = Model(cfg, dtype="float16", seed=1)
-        x5 = torch.from_numpy(synthetic.noise_images(7 + rank, n5, side5, side5, C_IN)).to(dev)
-        for _ in range(max(2, args.warmup)):
-            m5.predict_on_device(x5)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x5s = [torch.from_numpy(synthetic.noise_images(7 + rank + 101 * k, n5, side5, side5, C_IN)).to(dev) for k in range(RING)]
+        no5 = [0]
+
+        def step5():
+            no5[0] += 1
+            m5.predict_on_device(x5s[no5[0] % RING])
+
         reps5 = max(5, min(args.steps, 200))
-        e0.record()
-        for _ in range(reps5):
-            m5.predict_on_device(x5)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps5
+        ms = timed_events(step5, reps5)                    # clock settle inside, like every leg
+        ms_single = timed_events(lambda: m5.predict_on_device(x5s[0]), reps5, settle=50)
         # E_fwd = H W (C_in + 45 + K/16) elements of 2 bytes = 100.79 MB per image -- the figure `frac` is quoted on.
         # The image is FED as fp32 here (12.6 MB instead of 6.3 MB per image): the bytes actually moved are given beside it.
         bytes_img = side5 * side5 * (C_IN + 45 + 1 / 16.0) * 2.0
         bytes_img_fed = side5 * side5 * C_IN * 4.0 + side5 * side5 * 45.0 * 2.0 + (side5 // 4) ** 2 * 4.0
         res = {"workload": "configs[4]: batch=8 1024x1024x3 fp16 forward, dilations {1,2,4,8,16,1}", "ms_per_batch": round(ms, 4),
-               "images_per_s": round(n5 / ms * 1e3, 1), "dtype": "f16",
+               "images_per_s": round(n5 / ms * 1e3, 1), "dtype": "f16", "clock_settle_steps": SETTLE_STEPS,
+               "input_ring_MB": round(sum(t.numel() * t.element_size() for t in x5s) / 1e6, 1), "ms_per_batch_single_tensor": round(ms_single, 4),
                "roofline": {"bound": "hbm", "achieved": round(n5 * bytes_img / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s",
                             "frac": round(n5 * bytes_img / (ms * 1e-3) / 1e9 / PEAK_HBM, 4),
                             "note": "algorithmic bytes per SURVEY 8(d): 100.79 MB per image (every element 2 bytes)",
                             "frac_with_fp32_image_and_logits_as_fed": round(n5 * bytes_img_fed / (ms * 1e-3) / 1e9 / PEAK_HBM, 4)}}
-        del m5, x5
+        del m5, x5s
         torch.cuda.empty_cache()
         return res
 
@@ -543,6 +637,9 @@ def main():
                "reference_claim_ms": {"512": 50, "1024": 150, "source": "README_RU.md:9-10, 'cpu (4 cores)', unverified"}}
         for side in (512, 1024):
             xz = np.zeros((1, side, side, 1), np.float32)
+            xs_ = torch.from_numpy(xz).to(dev)
+            for _ in range(SETTLE_STEPS):                             # clock settle (every leg gets it); then the reference's protocol
+                gm.predict_on_device(xs_)
             gm.predict(xz)
             torch.cuda.synchronize()
             t0 = time.time(); gm.predict(xz); first = (time.time() - t0) * 1e3
@@ -584,20 +681,19 @@ def main():
     line = None
     if rank == 0:
         # ---- parts: net only / postprocess only (rectangle maps) -- HIP events on the launch stream
-        def timed(fn, reps):
-            fn(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record(); torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
-
+        timed = timed_events                                  # SETTLE_STEPS untimed calls in front of every timed region
         reps = max(5, min(args.steps, 200))
-        net_ms = timed(lambda: model.predict_on_device(x), reps)
+        net_no = [0]
+
+        def net_step():
+            net_no[0] += 1
+            model.predict_on_device(xs[net_no[0] % RING])
+
+        net_ms = timed(net_step, reps)
+        net_single_ms = timed(lambda: model.predict_on_device(x), reps, settle=50)
         logits = model.predict_on_device(x)
         post_ms = timed(lambda: model.postprocess_on_device(logits, runner.logit_threshold, 4, 5, cap=1024), reps)
-        post_rect_ms = timed(lambda: model.postprocess_on_device(rect_logits, runner.logit_threshold, 4, 5, cap=1024), reps)
+        post_rect_ms = timed(lambda: model.postprocess_on_device(rect_logits[0], runner.logit_threshold, 4, 5, cap=1024), reps)
         counts = out[4].cpu().numpy()
 
         # ---- roofline of the dominant kernel: one dense dilated layer on the real L3 activations
@@ -616,51 +712,18 @@ def main():
         t_layer = float(np.mean(layer_ms)) * 1e-3
         flop_layer = 2.0 * 216 * 24 * n * mh * mw
         bytes_layer = 2.0 * n * mh * mw * 24 * 4
-        # HBM traffic of one launch from the PMC run committed under profiles/ (separate --pmc passes of
-        # tools/gpu_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads)
-        traffic = None
-        try:
-            # per-kernel table of tools/gpu_pmc_traffic.sh (read MB already doubled, write MB): the row of the <0> instantiation
-            # alone -- the name filter of tools/gpu_pmc.sh also matches the last layer's <2> (head fused, 2 MB written)
-            for ln in open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_fwd_fp32.txt")):
-                if ln.startswith("void dilconv_wino_kernel<0"):
-                    parts = ln.split()
-                    traffic = round(float(parts[-2]) + float(parts[-1]), 1)
-        except Exception:
-            traffic = None
-        if traffic is None:                                   # older profile sets: counters of all dilconv_wino launches of a pass
-            try:
-                vals = {}
-                pmc_file = "r03_pmc_dilconv_wino.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_dilconv_wino.txt")) else "r02_pmc_dilconv_wino.txt"
-                for ln in open(os.path.join(ROOT, "profiles", pmc_file)):
-                    parts = ln.split()
-                    if len(parts) >= 2:
-                        vals[parts[0]] = float(parts[1])
-                traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / 1e6, 1)     # MB per launch
-            except Exception:
-                traffic = None
-        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary (full-size launches only: the
-        # batch-1 latency leg launches it on 1 x 128 x 128 maps for a few microseconds)
-        profile_avg_us, profile_file = None, None
-        for cand in ("r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv"):
-            try:
-                import csv
-                with open(os.path.join(ROOT, "profiles", cand)) as f:
-                    for row in csv.DictReader(f):
-                        if row["Name"].startswith("void dilconv_wino_kernel<0"):
-                            profile_avg_us = round(float(row["AverageNs"]) / 1e3, 2)
-                            if "FullSizeAverageNs" in row and row["FullSizeAverageNs"]:
-                                profile_avg_us = round(float(row["FullSizeAverageNs"]) / 1e3, 2)
-                            profile_file = "profiles/" + cand
-                            break
-            except (OSError, KeyError, ValueError):
-                continue
-            if profile_avg_us is not None:
-                break
+        # HBM traffic per launch and the kernel's average duration in the rocprofv3 summary: NOT measured in this run -- parsed
+        # from the newest committed profile set and labelled with its files and with whether those profiles were taken on the
+        # kernel sources this library was built from
+        traffic, profile_avg_us, profile_files, profile_fresh = committed_profile("void dilconv_wino_kernel<0")
         roofline = {"bound": "mfma", "kernel": "dilconv_wino_kernel<0> (Winograd F(2x2,3x3) fp32 MFMA; FLOPs counted as direct conv)", "achieved": round(flop_layer / t_layer / 1e12, 3),
                     "peak": PEAK_MFMA_F32, "unit": "TFLOP/s", "frac": round(flop_layer / t_layer / 1e12 / PEAK_MFMA_F32, 4),
-                    "traffic": traffic, "traffic_unit": "MB/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/r03_pmc_traffic_fwd_fp32.txt; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
-                    "profile_avg_us": profile_avg_us, "profile_file": profile_file,
+                    "frac_profile": (round(flop_layer / (profile_avg_us * 1e-6) / 1e12 / PEAK_MFMA_F32, 4) if profile_avg_us else None),
+                    "traffic": traffic, "traffic_unit": "MB/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE; algorithmic 100.7 MB)", "avg_launch_us": round(t_layer * 1e6, 2),
+                    "profile_avg_us": profile_avg_us,
+                    "from_committed_profile": {"fields": ["traffic", "profile_avg_us", "frac_profile"], "files": profile_files,
+                                               "taken_on_the_sources_of_this_build": profile_fresh},
+                    "clock_settle_launches": SETTLE_STEPS,
                     "per_dilation_us": [round(v * 1e3, 2) for v in layer_ms],
                     "algorithmic_gbps": round(bytes_layer / t_layer / 1e9, 1)}
         fwd_hbm = {"bound": "hbm", "achieved": round(BATCH * BYTES_PER_IMAGE_FP32 / (net_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM,
@@ -682,14 +745,18 @@ def main():
             "ms_per_step_spread": {"blocks_of_K_steps_after_the_timed_one": [round(v, 4) for v in block_ms],
                                    "min": round(min(block_ms), 4), "median": round(float(np.median(block_ms)), 4), "max": round(max(block_ms), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup),
+            "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup), "input_ring_MB": input_ring_mb,
+            "ms_per_step_single_tensor": round(single_ms, 4),
+            "ms_per_step_rect_maps": round(rect_ms, 4),
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
             "roofline": roofline, "roofline_forward_pass": fwd_hbm, "cpu_baseline": cpu, "train_step": train, "train_step_8_classes": train_cls8, "train_step_f32": train_f32, "forward_fp16_cfg5": cfg5, "latency_batch1": latency, "pcie_inclusive_host_numpy": host_path,
-            "parts": {"net_ms": round(net_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
+            "parts": {"net_ms": round(net_ms, 4), "net_ms_single_tensor": round(net_single_ms, 4), "postprocess_ms_on_net_maps": round(post_ms, 4),
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
-                      "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max())},
+                      "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max()),
+                      "rect_maps_objects_found_mean": float(rect_counts.mean()), "rect_maps_objects_found_max": int(rect_counts.max()),
+                      "clock_settle_launches": SETTLE_STEPS},
         }
     if dist is not None and not args.no_train:
         # configs[3].  The headline number above must not depend on this leg: if the multi-rank exchange stalls (it cannot be
