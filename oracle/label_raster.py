@@ -6,8 +6,10 @@ in the reference tree).  This plain-Python restatement of that rule is PINNED ag
 tests/test_oracle_raster.py: identical on every quadrilateral tried -- convex, concave, self-intersecting, with repeated or
 collinear corners, partly outside the canvas (round 3: the corner-joining rule is restated for every local corner, not
 only the top / bottom one of a convex quad; 0 differences on 50 000 arbitrary quads on four canvas sizes).  Known exception:
-a quad whose OPPOSITE corners coincide (a zero-area fold, four edges in one point) differs from Pillow by 1-3 pixels at that
-point in about 1 % of the cases; the host mirror rejects such markup loudly instead of rasterising it.  The device kernel
+a quad whose OPPOSITE corners coincide (a zero-area fold, four edges in one point) differs from Pillow inside one row (a
+fragment of that row's span: median 2 pixels, 90th percentile 10) in about 4 % of random such quads; round 4 tried to infer
+that rule too (edge-index vs intersection-index targets, parity of the intersection count, polygon adjacency: none
+reproduces Pillow 12.2) -- the device builder draws such markup with this rule and logs it (strict_markup refuses it).  The device kernel
 (ubdvss_amd/csrc/raster.hip) implements exactly this function and is compared with Pillow itself on the GPU box.
 """
 import math

@@ -52,6 +52,20 @@ def main():
                         logits_f64=ref64, c_in=3, n_classes=2, fml=1,
                         logits_bfloat16=onet.forward(x.astype(np.float64), w, act_dtype="bfloat16").astype(np.float32),
                         logits_float16=onet.forward(x.astype(np.float64), w, act_dtype="float16").astype(np.float32))
+    # ---- the use_bn=True branch (net.py:248-250): 59 arrays in get_weights() order (conv arrays, gamma, beta, moving mean, moving
+    #      variance per hidden layer; head last) -- same file name and keys as tests/golden/make_reference_golden.py writes
+    rng = np.random.default_rng(17)
+    wb = onet.init_weights(63, 3, 0, bias_scale=0.3)
+    wbn, i = [], 0
+    for n_conv in (3, 3, 3, 2, 2, 2, 2, 2, 2):
+        wbn += wb[i:i + n_conv]
+        wbn += [rng.uniform(0.5, 1.5, 24).astype(np.float32), rng.normal(0, 0.3, 24).astype(np.float32),
+                rng.normal(0, 0.5, 24).astype(np.float32), rng.uniform(0.2, 2.0, 24).astype(np.float32)]
+        i += n_conv
+    wbn += wb[i:]
+    xb = synthetic.noise_images(61, 2, 96, 128, 3)
+    np.savez_compressed(os.path.join(HERE, "net_bn_rgb.npz"), x=xb, logits=onet.forward_bn(xb.astype(np.float64), wbn).astype(np.float32),
+                        **{"w%02d" % k: a for k, a in enumerate(wbn)})
     # ---- postprocess: rectangle maps -> quads
     maps = synthetic.rectangle_maps(3, 8, 128, 128, n_classes=4)
     lg = synthetic.logits_from_maps(maps, 4, seed=5, noise=0.0)     # deterministic: rebuilt from the maps by the tests

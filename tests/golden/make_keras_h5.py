@@ -61,6 +61,10 @@ def save_weights_to_hdf5_group(g, layers, rng, **dset_kw):
         lg.attrs["weight_names"] = [w.encode("utf8") for w, _ in weights]
         for wname, shape in weights:
             val = rng.uniform(-1, 1, shape).astype(np.float32)
+            if wname.endswith("moving_variance:0"):              # a variance is positive; gamma near one
+                val = rng.uniform(0.2, 2.0, shape).astype(np.float32)
+            elif wname.endswith("gamma:0"):
+                val = rng.uniform(0.5, 1.5, shape).astype(np.float32)
             d = lg.create_dataset(wname, val.shape, dtype=val.dtype, **dset_kw)
             d[:] = val
 

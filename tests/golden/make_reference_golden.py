@@ -16,6 +16,9 @@ consume through UBD_GOLDEN_DIR (tests/conftest.py).  What it pins, by reference 
   net.py:278-314 (+ :225-252)   logits of the built Keras model for given get_weights()  -> net_*.npz, cfg1_logits.npy
   losses.py:33-126              detection / total loss values and tf.gradients           -> loss_case.npz, manifest
   utils.py:51-60, segmap_manager.py:41-69   cv2 contours -> quads -> class vote            -> manifest post_rect / post_stress
+  net.py:248-250 (use_bn=True)  logits of a model built with BatchNormalization layers   -> net_bn_rgb.npz (round 4)
+  net.py:443-494 (load_model)   a model.h5 written by ubdvss_amd/keras_h5_writer.py, opened by the REFERENCE's own
+                                NetManager.load_model and run: proves the weight interchange back to the reference (round 4)
 Only this repo's numpy-only helpers (synthetic.py, oracle/net_numpy.py) are loaded besides the reference, by file
 path, to rebuild the seeded inputs; nothing of the reference is copied anywhere.
 """
@@ -133,6 +136,47 @@ def main():
     np.savez_compressed(os.path.join(args.out_dir, "loss_case.npz"), y_true=d["y_true"], y_pred=d["y_pred"],
                         g_det=np.asarray(g_det, np.float32), g_all=np.asarray(g_all, np.float32))
     manifest["loss_case"] = dict(det=float(np.mean(v_det)), total=float(np.mean(v_all)))
+
+    # ---- round 4: the use_bn=True branch of conv_bn (net.py:248-250; the reference's own builder never passes use_bn, so the
+    #      graph is built here from the reference's conv_bn with use_bn=True, layer for layer as net.py:292-311 does)
+    from keras.layers import Input, Conv2D                                            # noqa: E402
+    from keras.models import Model as KModel                                          # noqa: E402
+    rng = np.random.default_rng(17)
+    inp = Input(shape=(None, None, 3))
+    t = ref_net.conv_bn(inp, 24, strides=(2, 2), separable=True, use_strides_compatible_with_fml=True, use_bn=True)
+    t = ref_net.conv_bn(t, 24, dilation_rate=1, separable=True, use_bn=True)
+    t = ref_net.conv_bn(t, 24, strides=(2, 2), separable=True, use_strides_compatible_with_fml=True, use_bn=True)
+    for dil in (1, 2, 4, 8, 16, 1):
+        t = ref_net.conv_bn(t, 24, dilation_rate=dil, separable=False, use_bn=True)
+    bn_model = KModel(inputs=inp, outputs=Conv2D(1, (1, 1), padding='same', activation=None)(t))
+    wbn = []
+    for a in bn_model.get_weights():                                                   # get_weights() order = the 59-array list the tests use
+        wbn.append(rng.normal(0, 0.3, a.shape).astype(np.float32))
+    names = [v.name for v in bn_model.weights]
+    for i, nm in enumerate(names):
+        if "moving_variance" in nm: wbn[i] = rng.uniform(0.2, 2.0, wbn[i].shape).astype(np.float32)
+        if "gamma" in nm: wbn[i] = rng.uniform(0.5, 1.5, wbn[i].shape).astype(np.float32)
+    bn_model.set_weights(wbn)
+    xb = synthetic.noise_images(61, 2, 96, 128, 3)
+    np.savez_compressed(os.path.join(args.out_dir, "net_bn_rgb.npz"), x=xb, logits=bn_model.predict(xb).astype(np.float32),
+                        **{"w%02d" % i: a for i, a in enumerate(wbn)})
+    manifest["net_bn_rgb"] = dict(weight_names=names)
+
+    # ---- round 4: weight interchange BACK to the reference: a file written by this repo's pure-Python HDF5 writer, opened by the
+    #      reference's NetManager.load_model (net.py:443-494 -> keras.models.load_model) and run
+    kw = _load_by_path("ubd_keras_h5_writer", os.path.join(REPO, "ubdvss_amd", "keras_h5_writer.py"))
+    back_dir = os.path.join(args.out_dir, "written_by_ubdvss_amd")
+    os.makedirs(back_dir, exist_ok=True)
+    d = np.load(os.path.join(HERE, "net_rgb_det.npz"))
+    wl = onet.unflatten_weights(d["params"], 3, 0)
+    kw.write_keras_model(os.path.join(back_dir, "inference_model.h5"), wl, 3, 0, bool(d["fml"]), True)
+    mgr = ref_net.NetManager(back_dir, ref_net.NetConfig(None, fml_compatible=bool(d["fml"]), grey=False))
+    mgr.load_model()
+    lg_back = mgr.get_keras_model().predict(d["x"]).astype(np.float32)
+    model = build_reference_model(ref_net, args.out_dir, 3, 0, int(d["fml"]))
+    model.set_weights(keras_weight_list(d["params"], model))
+    assert np.array_equal(lg_back, model.predict(d["x"]).astype(np.float32)), "the reference computes different logits from the written file"
+    manifest["h5_written_by_ubdvss_amd_loads_in_reference"] = True
 
     # files that do not depend on the reference travel unchanged (HDF5 reader fixtures, 16-bit oracle fixtures)
     for fn in os.listdir(HERE):

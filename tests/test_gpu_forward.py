@@ -274,7 +274,13 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
     got = mgr2.get_keras_model().predict(x)
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
     mgr2.save_model(7)                                        # net.py:418-420: numbered snapshot + current model
-    assert (tmp_path / "model007.npz").exists() and (tmp_path / "model.npz").exists()
+    assert (tmp_path / "model007.h5").exists() and (tmp_path / "model.h5").exists()       # Keras files, like the reference's
+    w7, names7 = keras_h5.read_keras_weights(str(tmp_path / "model007.h5"))
+    assert all(np.array_equal(a, b) for a, b in zip(w7, w)) and names7[0] == "separable_conv2d_1/depthwise_kernel:0"
+    mgr2.save_inference()                                     # net.py:422-427: model_weights.h5 + inference_model.h5
+    assert (tmp_path / "model_weights.h5").exists()
+    mgr4 = NetManager(str(tmp_path)); mgr4.load_model()       # picks the inference model this package just wrote
+    assert torch.equal(mgr4.get_keras_model().params, mgr2.get_keras_model().params)
     other = tmp_path / "other"; other.mkdir()
     mgr3 = NetManager(str(other), NetConfig(grey=False, max_image_side=1024))
     cfg3 = mgr3.load_another_model(str(tmp_path))

@@ -341,23 +341,27 @@ def test_postprocess_stress_in_pipelined_runner():
     """The same check inside ModelRunner(pipelined=True) -- the bench's headline path: the postprocess of batch k runs in the
     first blocks of the stem kernel of batch k+1 (512-thread blocks, LDS shared with the stem, other blocks of the kernel
     already convolving).  300 steps over a ring of batches at the headline shape (32 x 512 x 512); every step's lists equal the
-    serial runner's lists of that batch."""
+    serial runner's lists of that batch, and -- directly, not through the serial HIP path -- the ORACLE's lists (oracle/cv_post.c
+    on the host-thresholded logits of the batch)."""
     cfg = NetConfig(grey=False)
     model = Model(cfg, seed=5)
     w = onet.init_weights(41, 3, 0, bias_scale=0.3)
     model.set_weights(w)
     serial, piped = ModelRunner(cfg, max_objects_per_image=4200), ModelRunner(cfg, pipelined=True, max_objects_per_image=4200)
-    batches, ref = [], []
+    batches, ref, oracle = [], [], []
     for k in range(4):
         labels = synthetic.rectangle_maps(170 + k, 32, 128, 128)
         b = torch.from_numpy(synthetic.textured_images(180 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
         batches.append(b)
-        _, bmap, quads, _, counts = serial.predict_on_device(model, b)
+        lg, bmap, quads, _, counts = serial.predict_on_device(model, b)
         ref.append((bmap.clone(), quads.clone(), counts.clone()))
+        oq, oc = _oracle_lists(np.where(lg.cpu().numpy() > serial.logit_threshold, 1.0, -1.0).astype(np.float32), cfg.get_min_pixels_for_detection(), 4200)
+        oracle.append((torch.from_numpy(oq).cuda(), torch.from_numpy(oc).cuda()))
     torch.cuda.synchronize()
+    assert sum(int(o[1].sum()) for o in oracle) > 0                # the oracle found objects on these maps
     assert model._lib.ubd_num_cus(model._h) * 2 <= 32 * 32        # 1024 strips: the one-kernel stem (and the in-kernel postprocess) is in use
     pending = None
-    bad = []
+    bad, bad_oracle = [], []
     for it in range(300):
         k = it % 4
         out = piped.predict_on_device(model, batches[k])
@@ -368,9 +372,12 @@ def test_postprocess_stress_in_pipelined_runner():
             live = torch.arange(quads.shape[1], device="cuda")[None, :, None] < ref[pk][2][:, None, None]
             if not (torch.equal(bmap, ref[pk][0]) and torch.equal(counts, ref[pk][2]) and bool(((quads == ref[pk][1]) | ~live).all())):
                 bad.append(it - 1)
+            if not (torch.equal(counts, oracle[pk][1]) and bool(((quads == oracle[pk][0]) | ~live).all())):     # the pipelined lists vs the oracle's
+                bad_oracle.append(it - 1)
         pending = (k, out)
     piped.synchronize()
     assert not bad, bad[:10]
+    assert not bad_oracle, bad_oracle[:10]
 
 
 @pytest.mark.parametrize("grey,u8", [(False, False), (False, True), (True, False), (True, True)])

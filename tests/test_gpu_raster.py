@@ -104,8 +104,37 @@ def test_fractional_markup_equals_pillow():
         assert np.array_equal(got, _pil_maps((192, 160), markups, scale)), scale
 
 
-def test_folded_quads_are_refused():
+def test_folded_quads_are_drawn_and_refused_only_on_request(caplog):
+    """A quad whose opposite corners coincide on the map (a point / folded segment annotation): the reference draws whatever
+    ImageDraw.polygon draws (segmap_manager.py:93-103).  The device builder draws it too (no exception in the data
+    path) and logs it; Pillow's corner joining at a point where FOUR edges meet is the one piece of its fill rule that is not
+    restated, so the result is held to: identical to Pillow for at least 93 % of such quads (observed: 96 %), and for the others
+    different inside ONE row only (a fragment of that row's span; observed median 2 pixels, 90th percentile 10).
+    strict_markup=True refuses such markup."""
+    import logging
+    rng = np.random.default_rng(46)
+    markups = []
+    while len(markups) < 600:
+        q = rng.integers(-4, 60, 8)
+        if len(markups) % 2: q[4:6] = q[0:2]
+        else: q[6:8] = q[2:4]
+        markups.append([ObjectMarkup(q)])
+    with caplog.at_level(logging.WARNING):
+        got = SegmapManager.build_segmentation_maps_on_device((56, 48), markups, scale=1).cpu().numpy()
+    assert "opposite corners coincide" in caplog.text
+    ref = _pil_maps((56, 48), markups, 1)
+    same = 0
+    for i in range(len(markups)):
+        diff = np.argwhere(got[i] != ref[i])
+        if len(diff) == 0:
+            same += 1
+            continue
+        assert len(set(diff[:, 0].tolist())) == 1, (markups[i][0].bbox, diff.tolist())      # one row
+    print(f"folded quads identical to Pillow: {same} of {len(markups)}")
+    assert same >= 0.93 * len(markups)
     with pytest.raises(ValueError, match="opposite corners"):
-        SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 40, 12, 8, 8, 20, 50])]], scale=4)
+        SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 40, 12, 8, 8, 20, 50])]], scale=4, strict_markup=True)
+    lab = SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 8, 8, 8, 8, 8, 8])]], scale=4).cpu().numpy()   # a point annotation
+    assert lab.sum() == 1 and lab[0, 2, 2] == 1
     with pytest.raises(ValueError, match="quadrilateral"):
         SegmapManager.build_segmentation_maps_on_device((64, 64), [[ObjectMarkup([8, 8, 40, 12, 8, 30])]], scale=4)

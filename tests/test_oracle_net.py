@@ -127,3 +127,15 @@ def test_batchnorm_fold_equals_the_bn_branch():
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())       # fp32 rounding of the folded arrays
         with pytest.raises(ValueError):
             fold_batchnorm(wbn[:-1])
+
+
+def test_golden_bn_case(golden_dir):
+    """tests/golden/net_bn_rgb.npz: input, the 59 get_weights() arrays of a use_bn=True model and its logits (generated by the
+    oracle here; by the reference's conv_bn(use_bn=True) graph when UBD_GOLDEN_DIR points at make_reference_golden.py's output)."""
+    from ubdvss_amd.net import fold_batchnorm
+    d = np.load(os.path.join(golden_dir, "net_bn_rgb.npz"))
+    wbn = [d["w%02d" % k] for k in range(59)]
+    ref = onet.forward_bn(d["x"].astype(np.float64), wbn)
+    assert np.abs(ref - d["logits"]).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    got = onet.forward(d["x"].astype(np.float64), fold_batchnorm(wbn))
+    assert np.abs(got - d["logits"]).max() <= 2e-5 * max(1.0, np.abs(ref).max())

@@ -9,7 +9,8 @@
 // [round-half-up(left), round-half-down(right)], horizontal edges drawn as they are, and the single pixel of a top / bottom
 // corner -- any two edges leaning to the same side that start (last row: end) in one point -- joined to the span of the
 // neighbouring row.  Bit-identical to Pillow 12.2 on convex, concave and self-intersecting quadrilaterals alike (0 differences
-// on 50 000 arbitrary quads); the one exception, a quad whose opposite corners coincide, is rejected by the host mirror.
+// on 50 000 arbitrary quads); the one exception, a quad whose opposite corners coincide (four edges in one point), is drawn with the same rule and logged by the host mirror
+// (about 4 % of random such quads then differ from Pillow inside one row; strict_markup refuses them).
 // Markup is float64 (rescaled / augmented quads are fractional): the division by the scale and _proper_round's comparisons
 // and floor / ceil run in double precision exactly as numpy / math do in the reference.
 //

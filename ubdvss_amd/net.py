@@ -273,6 +273,13 @@ class Model:
             raise ValueError("weight file was saved for a different architecture")
         self.params.copy_(torch.from_numpy(d["params"]))
 
+    def save_keras_h5(self, path, whole_model=True):
+        """The file ``keras.Model.save`` (``whole_model``) or ``save_weights`` writes for this architecture (net.py:418-427):
+        the reference's ``NetManager.load_model`` / ``keras.models.load_model`` reads it (ubdvss_amd.keras_h5_writer)."""
+        from . import keras_h5_writer
+        keras_h5_writer.write_keras_model(path, self.get_weights(), self.c_in, self.n_classes,
+                                          bool(self.net_config.is_fml_compatible()), whole_model)
+
     def load_keras_weights(self, path):
         """Weights exported from the reference's Keras model (net.py:418-494 keeps them in HDF5, which needs h5py):
         run ``np.savez(path, *model.get_weights())`` once in the Keras environment; the arrays arrive as arr_0, arr_1,
@@ -403,11 +410,14 @@ class Model:
 
 
 class NetManager:
-    """Builds / saves / loads the model (net.py:255-494) with the reference's method names and arguments.  Writes this
-    package's own format (flat fp32 ``.npz`` + pickled NetConfig); reads that and the reference's Keras ``.h5`` files."""
+    """Builds / saves / loads the model (net.py:255-494) with the reference's method names, arguments and FILES: models are
+    written as Keras 2.2 HDF5 (``keras.Model.save`` layout, ubdvss_amd.keras_h5_writer -- the reference's ``load_model`` opens
+    them) next to the pickled NetConfig, and read back from there; a Keras ``.h5`` the reference wrote and the ``.npz`` files
+    of earlier versions of this package are read too."""
 
-    CURRENT_MODEL_FILENAME = "model.npz"
-    INFERENCE_MODEL_FILENAME = "inference_model.npz"
+    CURRENT_MODEL_FILENAME = "model.h5"
+    INFERENCE_MODEL_FILENAME = "inference_model.h5"
+    MODEL_WEIGHTS_FILENAME = "model_weights.h5"
     PICKLED_CONFIG_FILENAME = "config.pkl"
 
     def __init__(self, log_dir, net_config=None):
@@ -430,15 +440,18 @@ class NetManager:
         return self._model
 
     def save_model(self, step=None):
-        """net.py:418-420: a numbered snapshot ``model{step:03d}`` plus the current model (``step`` may be omitted
-        here; the reference requires it)."""
+        """net.py:418-420: a numbered snapshot ``model{step:03d}.h5`` plus the current model ``model.h5``, both in the layout
+        of ``keras.Model.save`` (``step`` may be omitted here; the reference requires it).  Also writes config.pkl."""
         if step is not None:
-            self._model.save_weights(os.path.join(self._log_dir, "model{:03d}.npz".format(step)))
-        self._model.save_weights(os.path.join(self._log_dir, self.CURRENT_MODEL_FILENAME))
+            self._model.save_keras_h5(os.path.join(self._log_dir, "model{:03d}.h5".format(step)))
+        self._model.save_keras_h5(os.path.join(self._log_dir, self.CURRENT_MODEL_FILENAME))
         self.save_config()
 
-    def save_inference(self):                           # net.py:422-427
-        self._model.save_weights(os.path.join(self._log_dir, self.INFERENCE_MODEL_FILENAME))
+    def save_inference(self):
+        """net.py:422-427: ``model_weights.h5`` (``save_weights`` layout) and ``inference_model.h5`` (``save`` layout; the
+        reference rebuilds the graph in between to drop the optimizer -- there is no graph to rebuild here)."""
+        self._model.save_keras_h5(os.path.join(self._log_dir, self.MODEL_WEIGHTS_FILENAME), whole_model=False)
+        self._model.save_keras_h5(os.path.join(self._log_dir, self.INFERENCE_MODEL_FILENAME))
 
     def load_another_model(self, another_log_dir, dtype="float32"):
         """net.py:429-441: model and architecture-dependent configuration from ``another_log_dir``, the
@@ -458,14 +471,14 @@ class NetManager:
 
     def load_model(self, path_to_model=None, dtype="float32"):
         """net.py:443-466: models live in the log dir next to their config, so ``path_to_model`` must stay None (the
-        reference asserts the same); preference: inference model, then current model; within each, this package's
-        ``.npz`` before a Keras ``.h5`` written by the reference (read by ubdvss_amd.keras_h5, no h5py needed)."""
+        reference asserts the same); preference: inference model, then current model; within each, the Keras ``.h5`` (written
+        by the reference or by this package; read by ubdvss_amd.keras_h5, no h5py needed) before a legacy ``.npz``."""
         assert path_to_model is None, "Programmer! Models are stored in log_dir, near their config. " \
                                       "If you load model from other location model and config will not match most likely."
         candidates = []
         for name in (self.INFERENCE_MODEL_FILENAME, self.CURRENT_MODEL_FILENAME):
             stem = os.path.splitext(name)[0]
-            candidates += [stem + ".npz", stem + ".h5"]
+            candidates += [stem + ".h5", stem + ".npz"]
         for name in candidates:
             cand = os.path.join(self._log_dir, name)
             if os.path.exists(cand):
