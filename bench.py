@@ -401,7 +401,8 @@ def dry_run(args, world, rank):
                 raise RuntimeError("injected: train leg failed on this rank")
             gg = torch.full((8,), float(rank + 1))
             dist.all_reduce(gg)                          # the (stub) exchange step of every train step
-            return {"parallelism": "native communicator" if native else "torch.distributed fallback", "grad_sum": float(gg[0])}
+            return {"parallelism": "native communicator" if native else "torch.distributed fallback", "grad_sum": float(gg[0]),
+                    "batch_per_gpu": args.train_batch, "global_batch": args.train_batch * world}
 
         rc = guarded_dp_leg(dist, line, leg, float(os.environ.get("UBD_BENCH_TRAIN_TIMEOUT_S", "240")))
         dist.destroy_process_group()
@@ -576,7 +577,7 @@ def main():
         e_fwd = SIDE * SIDE * (C_IN + 45 + (1 + n_cls) / 16.0)                    # E_fwd elements per image
         train_bytes_per_image = (3 * e_fwd - SIDE * SIDE * C_IN) * bpe             # E_train = 3 E_fwd - H W C_in
         res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
-               "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb,
+               "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb, "global_batch": tb * world,
                "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
                "parallelism": comm_kind,
                "loss_last": round(float(trainer.loss[0]), 5),

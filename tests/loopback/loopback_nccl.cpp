@@ -6,9 +6,12 @@
 //
 // Semantics kept from NCCL: collectives are matched by call order per communicator; the result is the SUM over ranks in rank
 // order (deterministic), visible to work enqueued on `stream` after the call.  Simplification: the call blocks the host
-// thread until all ranks have arrived (it synchronises `stream` first), which is stricter than NCCL's stream-ordered
-// enqueue and therefore cannot hide an ordering bug that real RCCL would expose -- except overlap itself, which only the
-// driver's multi-GPU run can show.  Never linked into or loaded by the product unless UBD_RCCL_LIB names it.
+// thread until all ranks have arrived and synchronises `stream` first.  That is NOT a stricter test than NCCL's stream-ordered
+// enqueue -- it is a weaker one for ordering: a missing cross-stream dependency (e.g. between the fused all-reduce on the
+// communication stream, the stem backward on the caller's stream and ubd_comm_finish) is MASKED by the host-side
+// synchronisation.  These tests therefore check the collective ARITHMETIC and call matching (who sums what, in which order,
+// with which counts), not event ordering or overlap; the first real exercise of the ordering is bench.py's N > 1 leg on RCCL.
+// Never linked into or loaded by the product unless UBD_RCCL_LIB names it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <condition_variable>

@@ -19,6 +19,12 @@ def _run(args, env_extra=None, timeout=300):
     return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+def _line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-400:], r.stderr[-800:])    # printed exactly once, by exactly one of watchdog / main path
+    return json.loads(lines[0])
+
+
 def test_self_launch_two_ranks_dry_run():
     r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-800:]
@@ -27,6 +33,16 @@ def test_self_launch_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_rccl"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
     assert d["scaling"] == "weak" and d["value"] > 0
+
+
+def test_self_launch_eight_ranks_dry_run():
+    """configs[3]'s world size: `bench.py --gpus 8` starts EIGHT ranks, the backend connects eight of them, the (stub) gradient
+    exchange sums over eight, and the train leg reports the global batch 512 = 64 x 8."""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    d = _line(r)
+    assert d["n_gpus"] == 8 and d["n_ranks_rccl"] == 8 and d["scaling"] == "weak"
+    assert d["train_step"] == {"parallelism": "native communicator", "grad_sum": 36.0, "batch_per_gpu": 64, "global_batch": 512}
 
 
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
@@ -41,23 +57,17 @@ def test_launcher_world_size_mismatch_is_an_error():
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
 
 
-def _line(r):
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, (r.stdout[-400:], r.stderr[-800:])    # printed exactly once, by exactly one of watchdog / main path
-    return json.loads(lines[0])
-
-
 def test_train_leg_control_flow_two_ranks():
     """The data-parallel train leg's control flow (bench.guarded_dp_leg / agree_on_native_comm) under gloo with a stubbed
     trainer: all good; one rank without a native communicator -> every rank falls back together; one rank stalls -> the
     watchdog prints the headline line with the reason and the run exits NON-zero; the leg raises on one rank -> non-zero."""
     r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-800:]
-    assert _line(r)["train_step"] == {"parallelism": "native communicator", "grad_sum": 3.0}
+    assert _line(r)["train_step"] == {"parallelism": "native communicator", "grad_sum": 3.0, "batch_per_gpu": 64, "global_batch": 128}
 
     r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], {"UBD_BENCH_DRY_FAULT": "attach_fail"})
     assert r.returncode == 0, r.stderr[-800:]
-    assert _line(r)["train_step"] == {"parallelism": "torch.distributed fallback", "grad_sum": 3.0}
+    assert _line(r)["train_step"] == {"parallelism": "torch.distributed fallback", "grad_sum": 3.0, "batch_per_gpu": 64, "global_batch": 128}
     assert "native RCCL communicator unavailable" in r.stderr
 
     r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], {"UBD_BENCH_DRY_FAULT": "stall", "UBD_BENCH_TRAIN_TIMEOUT_S": "4"})

@@ -7,7 +7,12 @@ stand-in for the six RCCL entry points comm.hip resolves (UBD_RCCL_LIB).  What i
   * UBD_COMM_GLOBAL_LOSS: the loss of losses.py:86-126 over the GLOBAL batch (top-k of the flattened batch of both ranks, global
     n_pos / n_neg / means) equals the oracle's loss on the concatenated batch, d loss / d logits of each shard equals the
     oracle's gradient slice, the summed parameter gradients equal a single-handle run on the whole batch;
-  * explicit ubd_allreduce_grads / ubd_broadcast_params with two ranks.
+  * explicit ubd_allreduce_grads / ubd_broadcast_params with two ranks;
+  * round 4: the same three paths with EIGHT ranks (configs[3]'s world size) on tiny shapes -- fused all-reduce = the rank-order
+    sum of eight shard gradients, the batch-global top-k with its k-th value repeated in several shards, broadcast from a
+    non-zero root.
+The stand-in synchronises the host and the stream around every collective: these tests check the collective ARITHMETIC and the
+matching of calls across ranks, not cross-stream event ordering or overlap (tests/loopback/loopback_nccl.cpp).
 """
 import ctypes
 import os
@@ -217,3 +222,104 @@ def test_two_ranks_broadcast(loopback):
     outs = _ranks(world, body)
     assert not torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][0]) and torch.equal(outs[1][1], outs[1][0])
+
+
+# ---------------------------------------------------------------------------------------------- eight ranks (configs[3])
+def test_eight_ranks_fused_allreduce_is_the_rank_order_sum(loopback):
+    """world = 8 as in configs[3] (64 images per GPU there; 1 image of 64 x 64 per rank here): ubd_train_step with the fused
+    two-segment all-reduce leaves, on every rank, g0 + g1 + ... + g7 added in rank order (fp32), and Adam with 1 / 8 gives the
+    same parameters everywhere."""
+    world, cfg = 8, NetConfig(grey=False)
+    x, y = _batch(world, 64, 91)
+    alone = []
+    for r in range(world):
+        tr = Trainer(Model(cfg, dtype="bfloat16", seed=3), Adam(lr=1e-3))
+        tr.backward_on_device(x[r:r + 1], y[r:r + 1])
+        torch.cuda.synchronize()
+        alone.append(tr.grads.clone())
+    want = alone[0].clone()
+    for r in range(1, world):
+        want = want + alone[r]
+    uid = _uid()
+
+    def body(r):
+        m = Model(cfg, dtype="bfloat16", seed=3 + r)             # eight different initialisations: rank 0's must win
+        _attach(m, uid, r, world, _lib.UBD_COMM_FUSED)
+        assert _lib.load().ubd_comm_world(m._h) == 8
+        tr = Trainer(m, Adam(lr=1e-3))
+        tr.broadcast_weights(src=0)
+        tr.backward_on_device(x[r:r + 1], y[r:r + 1])
+        torch.cuda.current_stream().synchronize()
+        g = tr.grads.clone()
+        tr.apply_gradients()
+        torch.cuda.current_stream().synchronize()
+        return g, m.params.clone()
+    outs = _ranks(world, body)
+    for r in range(world):
+        assert torch.equal(outs[r][0], want), (r, float((outs[r][0] - want).abs().max()))
+        assert torch.equal(outs[r][1], outs[0][1])
+
+
+def test_eight_ranks_global_topk_with_the_kth_value_in_several_shards(loopback):
+    """losses.py:99-116 over eight shards: logits quantised to halves, so the k-th largest masked-negative loss value repeats in
+    EVERY shard and the tf.nn.top_k tie rule (lower flat index first) has to cut through the rank order; vs the oracle on the
+    concatenated batch and vs one handle on the whole batch."""
+    world = 8
+    rng = np.random.default_rng(18)
+    n, h, w = 8, 16, 24
+    labels = synthetic.rectangle_maps(73, n, h, w)
+    lg = rng.normal(0, 1.5, (n, h, w, 1)).astype(np.float32)
+    lg[..., 0] = np.round(lg[..., 0] * 2) / 2
+    uid = _uid()
+    cfg = NetConfig(grey=False)
+    lib = _lib.load()
+
+    def body(r):
+        m = Model(cfg, seed=1)
+        _attach(m, uid, r, world, _lib.UBD_COMM_GLOBAL_LOSS)
+        lt = torch.from_numpy(lg[r:r + 1]).cuda().contiguous()
+        yt = torch.from_numpy(labels[r:r + 1]).cuda().contiguous()
+        loss = torch.zeros(16, device="cuda")
+        grad = torch.empty_like(lt)
+        ws = torch.empty(int(lib.ubd_loss_workspace_bytes(m._h, 1, h, w)), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.ubd_loss(m._h, lt.data_ptr(), yt.data_ptr(), 1, h, w, loss.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                ws.numel(), m._stream()), "ubd_loss")
+        torch.cuda.current_stream().synchronize()
+        return loss.cpu().numpy(), grad.cpu().numpy()
+    outs = _ranks(world, body)
+    got_grad = np.concatenate([o[1] for o in outs], axis=0)
+    for r in range(1, world):
+        assert np.array_equal(outs[r][0], outs[0][0])
+    ref_loss, ref_grad = oloss.total_loss(labels[..., None], lg.astype(np.float64), False)
+    assert abs(float(outs[0][0][0]) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    assert np.abs(got_grad - ref_grad).max() <= 2e-5 * np.abs(ref_grad).max()
+    assert np.array_equal(got_grad[..., 0] != 0, ref_grad[..., 0] != 0)          # the same hard negatives, tie rule across ranks incl.
+    # the k-th value really does repeat across shards: the hard-negative weight appears on SOME but not ALL elements that carry it
+    from ubdvss_amd import losses
+    whole_loss, whole_grad = losses.loss_and_grad(labels, lg)
+    assert np.array_equal(got_grad != 0, whole_grad.cpu().numpy() != 0)
+    assert np.allclose(outs[0][0][:8], whole_loss.cpu().numpy()[:8], rtol=2e-6, atol=1e-7)
+    k = int(outs[0][0][3])
+    neg = (labels == 0)
+    x0 = lg[..., 0]
+    ce = np.maximum(x0, 0) + np.log1p(np.exp(-np.abs(x0)))
+    kth = np.sort(ce[neg])[::-1][k - 1]
+    shards_with_kth = sum(int(np.any(np.isclose(ce[r][neg[r]], kth, rtol=0, atol=1e-7))) for r in range(world))
+    assert shards_with_kth >= 2, shards_with_kth
+
+
+def test_eight_ranks_broadcast_from_a_non_zero_root(loopback):
+    world, cfg = 8, NetConfig(grey=False)
+    uid = _uid()
+
+    def body(r):
+        m = Model(cfg, seed=40 + r)
+        _attach(m, uid, r, world, 0)
+        before = m.params.clone()
+        Trainer(m).broadcast_weights(src=5)
+        torch.cuda.current_stream().synchronize()
+        return before, m.params.clone()
+    outs = _ranks(world, body)
+    assert not torch.equal(outs[0][0], outs[5][0])
+    for r in range(world):
+        assert torch.equal(outs[r][1], outs[5][0])
