@@ -345,7 +345,7 @@ def test_postprocess_stress_in_pipelined_runner():
     on the host-thresholded logits of the batch)."""
     cfg = NetConfig(grey=False)
     model = Model(cfg, seed=5)
-    w = onet.init_weights(41, 3, 0, bias_scale=0.3)
+    w = onet.init_weights(41, 3, 0, bias_scale=0.0)               # (with bias_scale 0.3 these weights give all-negative maps: nothing to find)
     model.set_weights(w)
     serial, piped = ModelRunner(cfg, max_objects_per_image=4200), ModelRunner(cfg, pipelined=True, max_objects_per_image=4200)
     batches, ref, oracle = [], [], []
@@ -358,7 +358,7 @@ def test_postprocess_stress_in_pipelined_runner():
         oq, oc = _oracle_lists(np.where(lg.cpu().numpy() > serial.logit_threshold, 1.0, -1.0).astype(np.float32), cfg.get_min_pixels_for_detection(), 4200)
         oracle.append((torch.from_numpy(oq).cuda(), torch.from_numpy(oc).cuda()))
     torch.cuda.synchronize()
-    assert sum(int(o[1].sum()) for o in oracle) > 0                # the oracle found objects on these maps
+    assert sum(int(o[1].sum()) for o in oracle) > 100              # the oracle found objects on these maps (several per image)
     assert model._lib.ubd_num_cus(model._h) * 2 <= 32 * 32        # 1024 strips: the one-kernel stem (and the in-kernel postprocess) is in use
     pending = None
     bad, bad_oracle = [], []
