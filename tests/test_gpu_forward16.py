@@ -270,9 +270,10 @@ def test_forward16_staged_dilated_kernel_equals_direct(monkeypatch, dtype, n, hh
 @pytest.mark.parametrize("cin,fml,u8,n,hh,ww", [(3, True, False, 2, 256, 256), (3, False, False, 3, 72, 104), (1, True, True, 2, 136, 200),
                                                 (3, True, True, 1, 512, 384), (1, False, False, 2, 64, 36)])
 def test_fused_stem16_equals_split(monkeypatch, dtype, cin, fml, u8, n, hh, ww):
-    """L1 -> L2 of the 16-bit pass in one kernel (L2's input patch computed from the image, operation for operation as the L1
-    kernel does) against the two-kernel pass (UBD_STEM16=split, read when the handle is created): bit-identical logits -- fml and
-    'same' padding, grey and RGB, float and uint8 + preprocessing input, ragged maps (tiles cut by both map borders)."""
+    """The stem of the 16-bit pass in ONE kernel (default: L1 -> L2 -> L3, sep123_16.h; UBD_STEM16=fused12: L1 -> L2 fused + L3
+    alone) against the three-kernel pass (UBD_STEM16=split, read when the handle is created): the fused kernels compute their
+    inputs' patches in LDS operation for operation as the separate kernels compute them: bit-identical logits -- fml and 'same'
+    padding, grey and RGB, float and uint8 + preprocessing input, ragged maps (tiles cut by both map borders)."""
     from ubdvss_amd.net import PreprocessingType
     cfg = NetConfig(grey=(cin == 1), fml_compatible=fml,
                     preprocessing=PreprocessingType.MOBILENET_LIKE if u8 else PreprocessingType.NONE)
@@ -281,15 +282,16 @@ def test_fused_stem16_equals_split(monkeypatch, dtype, cin, fml, u8, n, hh, ww):
     else:
         x = torch.from_numpy(synthetic.noise_images(3, n, hh, ww, cin)).cuda()
     out = {}
-    for mode in ("fused", "split"):
-        if mode == "split":
-            monkeypatch.setenv("UBD_STEM16", "split")
+    for mode in ("fused", "fused12", "split"):
+        if mode != "fused":
+            monkeypatch.setenv("UBD_STEM16", mode)
         else:
             monkeypatch.delenv("UBD_STEM16", raising=False)
         m = Model(cfg, dtype=dtype, seed=11)
         out[mode] = m.predict_on_device(x).clone()
         assert torch.isfinite(out[mode]).all()
-    assert torch.equal(out["fused"], out["split"])
+    assert torch.equal(out["fused12"], out["split"])
+    assert torch.equal(out["fused"], out["split"]), float((out["fused"] - out["split"]).abs().max())
 
 
 @pytest.mark.parametrize("n,hh,ww", [(2, 256, 256), (3, 72, 104)])
@@ -302,9 +304,9 @@ def test_bf16_train_fused_stem_equals_split(monkeypatch, n, hh, ww):
     x = torch.from_numpy(synthetic.textured_images(6, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
     y = torch.from_numpy(labels).cuda()
     grads, loss = {}, {}
-    for mode in ("fused", "split"):
-        if mode == "split":
-            monkeypatch.setenv("UBD_STEM16", "split")
+    for mode in ("fused", "fused12", "split"):
+        if mode != "fused":
+            monkeypatch.setenv("UBD_STEM16", mode)
         else:
             monkeypatch.delenv("UBD_STEM16", raising=False)
         m = Model(cfg, dtype="bfloat16", seed=9)
@@ -312,5 +314,6 @@ def test_bf16_train_fused_stem_equals_split(monkeypatch, n, hh, ww):
         t.backward_on_device(x, y)
         grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
         assert torch.isfinite(grads[mode]).all()
-    assert torch.equal(loss["fused"], loss["split"])
-    assert torch.equal(grads["fused"], grads["split"])
+    for mode in ("fused", "fused12"):               # a1 and a2 are stored by the fused kernels too: every pixel once, same bits
+        assert torch.equal(loss[mode], loss["split"]), mode
+        assert torch.equal(grads[mode], grads["split"]), (mode, float((grads[mode] - grads["split"]).abs().max()))

@@ -7,7 +7,7 @@ OBJ=../../tools/_ab/_obj_diag
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train comm raster; do
+for f in ${DIAG_FILES:-api forward fwd16 wino postprocess loss backward train comm raster}; do
   extra=""
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
   [ "$f" = "raster" ] && extra="-ffp-contract=off"

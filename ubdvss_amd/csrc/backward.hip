@@ -941,6 +941,7 @@ static int launch_head_wgrad(const ubd_handle *h, const void *a9, const float *d
 struct train_prologue_args {
     pack_args pa;
     pack_bwd_args pb;
+    pack_sep16_args ps;
     size_t off0, layer_stride, n_params, loss_zero_words;
     float *wfrag32, *bfrag, *grads;
     unsigned *wfrag16, *frag16t, *loss_zero;
@@ -950,7 +951,10 @@ __global__ __launch_bounds__(256) void train_prologue16_kernel(const float *__re
 {
     const int part = (int)blockIdx.x / 48, vtid = ((int)blockIdx.x % 48) * 256 + (int)threadIdx.x, vthreads = 48 * 256;
     if (part == 0) pack_weights_body(params, a.wfrag32, a.pa, vtid, vthreads);
-    else if (part == 1) pack16_body<T>(params, a.wfrag16, a.off0, a.layer_stride, 0, vtid, vthreads);
+    else if (part == 1) {
+        pack16_body<T>(params, a.wfrag16, a.off0, a.layer_stride, 0, vtid, vthreads);
+        pack_sep16_ready_body<T>(params, a.wfrag16 + UBD_NUM_DIL * UBD_DIL16_FRAG_U32, a.ps, vtid, vthreads);
+    }
     else if (part == 2) pack_bwd_body(params, a.bfrag, a.pb, vtid, vthreads);
     else pack16_body<T>(params, a.frag16t, a.off0, a.layer_stride, 1, vtid, vthreads);
     const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gthreads = (size_t)gridDim.x * 256;
@@ -1143,6 +1147,7 @@ extern "C" int ubd_train_step(ubd_handle *h, const float *params, const void *im
         for (int s = 0; s < 3; ++s) { a.pa.off_sep_dw[s] = h->off_sep_dw[s]; a.pa.off_sep_pw[s] = h->off_sep_pw[s]; a.pb.off_sep_pw[s] = h->off_sep_pw[s]; }
         for (int k = 0; k < UBD_NUM_DIL; ++k) { a.pa.off_dil_k[k] = h->off_dil_k[k]; a.pb.off_dil_k[k] = h->off_dil_k[k]; }
         a.pa.c_in = a.pb.c_in = h->cfg.c_in;
+        a.ps = ubd_pack_sep16_args(h);
         a.off0 = h->off_dil_k[0]; a.layer_stride = h->off_dil_k[1] - h->off_dil_k[0];
         a.n_params = h->n_params; a.loss_zero_words = ubd_loss_zero_bytes() / 4;
         a.wfrag32 = (float *)(ws + T.fwd16.off_wfrag32); a.wfrag16 = (unsigned *)(ws + T.fwd16.off_wfrag16);

@@ -202,6 +202,7 @@ size_t ubd_forward16_workspace_bytes(int n, int H, int W);
 int ubd_pack16_workspace(ubd_handle *h, const float *params, char *ws, size_t ws_bytes, hipStream_t st);
 int ubd_forward16(ubd_handle *h, const float *params, const void *images, int in_dtype, int preprocessing, int n, int H, int W,
                   float *logits, char *ws, size_t ws_bytes, hipStream_t st);
+#define UBD_SEP16_READY_U32 (2 * 10 * 64 * 4)      // L2, L3 of the 16-bit pass: per-lane ready operands [layer 2][slot 10][lane 64] x 4 dwords (pack.h pack_sep16_ready_body)
 #define UBD_DIL16_FRAG_U32 (7 * 2 * 64 * 4)          // 16-bit dilated layer: [chunk 7][nt 2][lane 64] x 4 dwords (8 halves)
 void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, const void *mask, int d,
                           const void *in, void *out, int n, int H4, int W4, hipStream_t st, float *logits3 = nullptr);

@@ -79,9 +79,12 @@ __device__ __forceinline__ unsigned mask_pk16(unsigned m)
 
 // ------------------------------------------------------------------------------------ pack (pack.h)
 template <typename T>
-__global__ void pack16_kernel(const float *__restrict__ params, unsigned *__restrict__ out, size_t off0, size_t layer_stride, int transpose)
+__global__ void pack16_kernel(const float *__restrict__ params, unsigned *__restrict__ out, size_t off0, size_t layer_stride, int transpose,
+                              pack_sep16_args sa, int with_sep)
 {
     pack16_body<T>(params, out, off0, layer_stride, transpose, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+    // forward fragments: followed by the ready operands of L2 / L3 for the one-kernel stem (sep123_16.h)
+    if (with_sep) pack_sep16_ready_body<T>(params, out + UBD_NUM_DIL * UBD_DIL16_FRAG_U32, sa, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // ------------------------------------------------------------------------------------ shared epilogue
@@ -687,6 +690,15 @@ __global__ __launch_bounds__(256, XB == 1 ? 4 : 3) void sep12_16_kernel(const vo
     }
 }
 
+#include "sep123_16.h"
+#ifdef UBD_STAMPS
+static unsigned long long *g_s123_stamps = nullptr;
+extern "C" void ubd_debug_set_stamps_s123(void *p) { g_s123_stamps = (unsigned long long *)p; }
+#define S123_16_STAMP_ARG , g_s123_stamps
+#else
+#define S123_16_STAMP_ARG
+#endif
+
 // ------------------------------------------------------------------------------------ dilated layers
 struct a16_frags { u32x4 v[7]; u32x2 m0, m1; };
 
@@ -969,7 +981,7 @@ void ubd_fwd16_layout_compute(int n, int H, int W, int training, ubd_fwd16_layou
 {
     size_t off = 0;
     L->off_wfrag32 = off; off += ubd_align_up((size_t)UBD_FWD_DIRECT_FLOATS * sizeof(float), 256);
-    L->off_wfrag16 = off; off += ubd_align_up((size_t)UBD_NUM_DIL * UBD_DIL16_FRAG_U32 * sizeof(unsigned), 256);
+    L->off_wfrag16 = off; off += ubd_align_up(((size_t)UBD_NUM_DIL * UBD_DIL16_FRAG_U32 + UBD_SEP16_READY_U32) * sizeof(unsigned), 256);   // + ready operands of L2 / L3
     const size_t a = ubd_align_up((size_t)n * (H / 2) * (W / 2) * UBD_C * 2, 256);
     const size_t b = ubd_align_up((size_t)n * (H / 4) * (W / 4) * UBD_C * 2, 256);
     L->off_a1 = off; off += a;
@@ -1045,6 +1057,30 @@ static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1,
 #undef UBD_SEP12_LAUNCH
 }
 
+template <int CIN, int IN_MODE, typename T>
+static void launch_sep123(const ubd_handle *h, const void *x, unsigned short *a1, unsigned short *a2, unsigned short *a3, const float *frag1,
+                          const float *bias1, const unsigned *ready23, const float *bias2, const float *bias3, int n, int H, int W, int pad_lo,
+                          float sub, float div, bool write_a12, hipStream_t st)
+{
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    const long tiles = (long)n * ((H4 + 7) / 8) * ((W4 + 7) / 8);
+    long grid = (long)h->num_cus * 3;                          // three blocks per CU (54 KB of LDS each)
+    if (grid > tiles) grid = tiles;
+#define UBD_SEP123_LAUNCH(PLAIN, WR)                                                                                                        \
+    hipLaunchKernelGGL((sep123_16_kernel<CIN, IN_MODE, PLAIN, WR, T>), dim3(grid), dim3(256), 0, st, x, a1, a2, a3, frag1, bias1, (const u32x4 *)ready23, \
+                       bias2, bias3, n, H, W, H2, W2, H4, W4, pad_lo, sub, div S123_16_STAMP_ARG)
+    // fp32 pixels fed as they are, offsets inside one image below 2^31: LDS-DMA
+    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31);
+    if constexpr (IN_MODE == 0) {
+        if (plain) {
+            if (write_a12) UBD_SEP123_LAUNCH(true, true); else UBD_SEP123_LAUNCH(true, false);
+            return;
+        }
+    }
+    if (write_a12) UBD_SEP123_LAUNCH(false, true); else UBD_SEP123_LAUNCH(false, false);
+#undef UBD_SEP123_LAUNCH
+}
+
 static unsigned magic_u32(unsigned d) { return d <= 1u ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 template <typename T>
@@ -1088,12 +1124,21 @@ void ubd_launch_dilconv16(const ubd_handle *h, int epi, const unsigned *frag, co
 }
 
 // packed 16-bit fragments of all six dilated layers (transpose = 1: data-gradient kernels)
+pack_sep16_args ubd_pack_sep16_args(const ubd_handle *h)
+{
+    pack_sep16_args sa;
+    for (int l = 0; l < 2; ++l) { sa.off_dw[l] = h->off_sep_dw[1 + l]; sa.off_pw[l] = h->off_sep_pw[1 + l]; }
+    return sa;
+}
+
+// transpose = 0: `out` is the forward fragment region (dilated fragments + the ready operands of L2 / L3 behind them)
 void ubd_launch_pack16(const ubd_handle *h, const float *params, unsigned *out, int transpose, hipStream_t st)
 {
+    const pack_sep16_args sa = ubd_pack_sep16_args(h);
     if (h->cfg.dtype == UBD_BF16)
-        hipLaunchKernelGGL((pack16_kernel<__bf16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose);
+        hipLaunchKernelGGL((pack16_kernel<__bf16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose, sa, transpose == 0);
     else
-        hipLaunchKernelGGL((pack16_kernel<_Float16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose);
+        hipLaunchKernelGGL((pack16_kernel<_Float16>), dim3(48), dim3(256), 0, st, params, out, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], transpose, sa, transpose == 0);
 }
 
 template <typename T>
@@ -1108,7 +1153,7 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     in_dtype &= ~UBD_IN_PREPACKED;
     if (!prepacked) {
         ubd_launch_pack_direct(h, params, wfrag, st);                  // fp32 depthwise / pointwise fragments
-        hipLaunchKernelGGL((pack16_kernel<T>), dim3(48), dim3(256), 0, st, params, wfrag16, h->off_dil_k[0], h->off_dil_k[1] - h->off_dil_k[0], 0);
+        ubd_launch_pack16(h, params, wfrag16, 0, st);
     }
     const int per_sep = UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS;
     const float *sf0 = wfrag, *sf1 = wfrag + per_sep, *sf2 = wfrag + 2 * per_sep;
@@ -1116,7 +1161,19 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
     float sub = 0.f, div = 1.f;
     if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
     const bool u8 = in_dtype == UBD_IN_U8;
-    if (h->split_stem16) {
+    unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
+    if (h->split_stem16 == 0) {
+        // L1 -> L2 -> L3 in one kernel (sep123_16.h): neither a1 nor a2 is read back; the train step keeps both for the backward pass
+        const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
+        const unsigned *ready23 = wfrag16 + (size_t)UBD_NUM_DIL * UBD_DIL16_FRAG_U32;
+        if (h->cfg.c_in == 1) {
+            if (u8) launch_sep123<1, 1, T>(h, images, a1, a2, cur, sf0, b0, ready23, b1, b2, n, H, W, pad_s2, sub, div, !inference, st);
+            else launch_sep123<1, 0, T>(h, images, a1, a2, cur, sf0, b0, ready23, b1, b2, n, H, W, pad_s2, sub, div, !inference, st);
+        } else {
+            if (u8) launch_sep123<3, 1, T>(h, images, a1, a2, cur, sf0, b0, ready23, b1, b2, n, H, W, pad_s2, sub, div, !inference, st);
+            else launch_sep123<3, 0, T>(h, images, a1, a2, cur, sf0, b0, ready23, b1, b2, n, H, W, pad_s2, sub, div, !inference, st);
+        }
+    } else if (h->split_stem16 == 1) {
         if (h->cfg.c_in == 1) {
             if (u8) launch_sep16<1, 2, 1, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
             else launch_sep16<1, 2, 0, T>(h, images, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sub, div, st);
@@ -1136,8 +1193,8 @@ static int forward16_impl(ubd_handle *h, const float *params, const void *images
             else launch_sep12<3, 0, T>(h, images, a1, a2, sf0, b0, sf1, b1, n, H, W, pad_s2, sub, div, !inference, st);
         }
     }
-    unsigned short *cur = (unsigned short *)(ws + L.off_acts[0]);
-    launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
+    if (h->split_stem16 != 0)
+        launch_sep16<UBD_C, 2, 2, T>(h, a2, cur, sf2, params + h->off_sep_b[2], n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st);
     // inference with a single output channel: the head rides in the epilogue of L9 and L9's activation is never written
     const bool fuse_head = inference && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {

@@ -80,6 +80,41 @@ __device__ __forceinline__ void pack16_body(const float *__restrict__ params, un
     }
 }
 
+// Ready-to-use per-lane operands of the 24-channel separable layers L2 and L3 for the one-kernel 16-bit stem (sep123_16.h), which
+// loads them per phase instead of keeping both layers' sets in registers: layer l (0: L2, 1: L3), slot s, lane (i = lane & 15,
+// q = lane >> 4), 4 dwords.  Slots 0..4: tap-folded diagonal depthwise fragments of channels 0..15 (two taps x 16 channels per
+// MFMA: k-slot 8q + e <-> tap 2j + (q >> 1), channel 8 (q & 1) + e == row i), slots 5..7: channels 16..23 (four taps x 8 channels:
+// k-group q <-> tap 4j + q, row i = 4 qq + r <-> channel 16 + 2 qq + r, r < 2), slots 8, 9: the pointwise A operands of the two N
+// tiles (k-slot 8q + e <-> this lane's channels 4q..4q+3, 16+2q, 17+2q; zeros for e = 6, 7) -- exactly what sepconv16_kernel<24, S>
+// (fwd16.hip) builds in its prologue from the fp32 fragments.
+struct pack_sep16_args { size_t off_dw[2], off_pw[2]; };
+pack_sep16_args ubd_pack_sep16_args(const ubd_handle *h);      // fwd16.hip
+template <typename T>
+__device__ __forceinline__ void pack_sep16_ready_body(const float *__restrict__ params, unsigned *__restrict__ out, const pack_sep16_args &a, int vtid, int vthreads)
+{
+    for (int idx = vtid; idx < UBD_SEP16_READY_U32; idx += vthreads) {
+        const int dw = idx & 3, lane = (idx >> 2) & 63, sl = (idx >> 8) % 10, l = (idx >> 8) / 10;
+        const int i = lane & 15, q = lane >> 4;
+        const float *kdw = params + a.off_dw[l], *kpw = params + a.off_pw[l];      // [tap][24] and [ch][24]
+        unsigned short h[2] = {0, 0};
+        if (sl < 5) {
+            const int ts = 2 * sl + (q >> 1), e0 = i - 8 * (q & 1);
+            if (ts < 9 && e0 >= 0 && e0 < 8 && (e0 >> 1) == dw) h[e0 & 1] = ubd_to_bits16<T>(kdw[ts * UBD_C + i]);
+        } else if (sl < 8) {
+            const int ts = 4 * (sl - 5) + q, r = i & 3, e = 2 * (i >> 2) + r;
+            if (ts < 9 && r < 2 && (e >> 1) == dw) h[e & 1] = ubd_to_bits16<T>(kdw[ts * UBD_C + 16 + e]);
+        } else if (dw < 3) {
+            const int nt = sl - 8, co = i + 16 * nt;
+            for (int e = 0; e < 2; ++e) {
+                const int s = 2 * dw + e;
+                const int ch = s < 4 ? 4 * q + s : 16 + 2 * q + (s - 4);
+                h[e] = ubd_to_bits16<T>(co < UBD_C ? kpw[(size_t)ch * UBD_C + co] : 0.f);
+            }
+        }
+        out[idx] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    }
+}
+
 // Backward weight fragments:
 //   dgrad[L][t'][j][nt][lane] = W_L[8-t'][co' ][ci']   with ci' = input channel of the dgrad conv
 //        (= forward output channel) from (j, q) as in the forward packing, co' = (lane&15)+16nt
