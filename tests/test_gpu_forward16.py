@@ -317,3 +317,36 @@ def test_bf16_train_fused_stem_equals_split(monkeypatch, n, hh, ww):
     for mode in ("fused", "fused12"):               # a1 and a2 are stored by the fused kernels too: every pixel once, same bits
         assert torch.equal(loss[mode], loss["split"]), mode
         assert torch.equal(grads[mode], grads["split"]), (mode, float((grads[mode] - grads["split"]).abs().max()))
+
+
+@pytest.mark.parametrize("n,hh,ww,ncls", [(2, 256, 256, 0), (3, 72, 104, 0), (2, 64, 96, 3), (1, 40, 36, 0)])
+def test_bf16_chained_partial_sum_reduction_equals_the_batched_launches(monkeypatch, n, hh, ww, ncls):
+    """bf16 train step: every weight-gradient kernel totals, at its end, the per-block partial rows of the producer in front of it
+    (backward.hip rp_reduce_tail; the last producer's rows go to one small stand-alone launch) instead of two batched reduction
+    launches per pass (UBD_REDUCE=batched).  Same rows, same order of additions: loss and gradients are bit-identical."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=False)
+    labels = synthetic.rectangle_maps(25, n, hh // 4, ww // 4, n_classes=ncls)
+    x = torch.from_numpy(synthetic.textured_images(26, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads, loss = {}, {}
+    for mode in ("chained", "batched"):
+        if mode == "batched":
+            monkeypatch.setenv("UBD_REDUCE", "batched")
+        else:
+            monkeypatch.delenv("UBD_REDUCE", raising=False)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
+        assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
+        t.backward_on_device(x, y)
+        nh = 25 * (1 + ncls)                                     # head kernel + bias gradients: with classes their block sums use LDS float atomics
+        assert torch.equal(t.grads[:-nh], grads[mode][:-nh])
+        if ncls == 0:
+            assert torch.equal(t.grads, grads[mode])
+    assert torch.equal(loss["chained"], loss["batched"])
+    assert torch.equal(grads["chained"][:-nh], grads["batched"][:-nh])
+    if ncls == 0:
+        assert torch.equal(grads["chained"], grads["batched"])
+    else:
+        assert torch.allclose(grads["chained"][-nh:], grads["batched"][-nh:], rtol=1e-5, atol=1e-9)

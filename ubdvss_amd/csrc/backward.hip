@@ -87,41 +87,71 @@ struct rp_job {
 };
 struct rp_batch { rp_job job[RP_MAX_JOBS]; int njobs; };
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const rp_batch B)
+// One block's share of a job: RP_COLS consecutive elements x (256 / RP_COLS) row groups.  Loads in flight per thread: 32 while the
+// matrix has that many rows per group left, then 8, then 1 -- the additions happen in the order of the plain 8-wide loop either way
+// (acc[u] takes rows ty + G u, + 8 G, + 16 G, ... one after the other), so the stand-alone kernel and the in-kernel tail below give
+// the same bits.  s: 256 floats of LDS.
+__device__ __forceinline__ void rp_reduce_group(const rp_job &J, int blk, float *s)
 {
-    int j = 0;
-#pragma unroll
-    for (int k = 1; k < RP_MAX_JOBS; ++k)
-        if (k < B.njobs && (int)blockIdx.x >= B.job[k].block0) j = k;            // block-uniform
-    const float *__restrict__ part = B.job[j].part;
-    float *__restrict__ out0 = B.job[j].out0, *__restrict__ out1 = B.job[j].out1, *__restrict__ out2 = B.job[j].out2;
-    const int nblocks = B.job[j].nblocks, count = B.job[j].count, n0 = B.job[j].n0, n1 = B.job[j].n1;
-    const int blk = (int)blockIdx.x - B.job[j].block0;
-    // block = RP_COLS consecutive elements x (256 / RP_COLS) row groups; 8 independent loads in flight per thread.
-    // 16 columns per block: 5208-element rows give 326 blocks (one per CU and more) instead of 82.
+    const float *__restrict__ part = J.part;
+    const int nblocks = J.nblocks, count = J.count, n0 = J.n0, n1 = J.n1;
     constexpr int G = 256 / RP_COLS;
-    __shared__ float s[G][RP_COLS];
     const int tx = threadIdx.x % RP_COLS, ty = threadIdx.x / RP_COLS;
     const int e = blk * RP_COLS + tx;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < count) {
         int b = ty;
+        for (; b + 31 * G < nblocks; b += 32 * G) {
+            float v[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[k][u] = part[(size_t)(b + G * (8 * k + u)) * count + e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += v[k][u];
+        }
         for (; b + 7 * G < nblocks; b += 8 * G) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(b + G * u) * count + e];
         }
         for (; b < nblocks; b += G) acc[0] += part[(size_t)b * count + e];
     }
-    s[ty][tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    s[ty * RP_COLS + tx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (ty == 0 && e < count) {
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < G; ++g) v += s[g][tx];           // fixed order: deterministic
-        if (e < n0) out0[e] = v;
-        else if (e < n0 + n1) out1[e - n0] = v;
-        else out2[e - n0 - n1] = v;
+        for (int g = 0; g < G; ++g) v += s[g * RP_COLS + tx];           // fixed order: deterministic
+        if (e < n0) J.out0[e] = v;
+        else if (e < n0 + n1) J.out1[e - n0] = v;
+        else J.out2[e - n0 - n1] = v;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const rp_batch B)
+{
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < RP_MAX_JOBS; ++k)
+        if (k < B.njobs && (int)blockIdx.x >= B.job[k].block0) j = k;            // block-uniform
+    // block = RP_COLS consecutive elements x (256 / RP_COLS) row groups.
+    // 16 columns per block: 5208-element rows give 326 blocks (one per CU and more) instead of 82.
+    __shared__ float s[256];
+    rp_reduce_group(B.job[j], (int)blockIdx.x - B.job[j].block0, s);
+}
+
+// bf16 train step: a weight-gradient kernel ends by totalling the partial rows of the producer IN FRONT of it (complete: stream
+// order) -- the rows are microseconds old and still in the Infinity Cache, every block takes one or two column groups with
+// 32 loads in flight, and the two stand-alone reduction launches of a pass (15.8 us each: 92 MB read back from memory) disappear.
+// part == nullptr: nothing to do.  s: 256 floats of LDS that nobody else touches any more (the caller has passed a barrier).
+__device__ __forceinline__ void rp_reduce_tail(const rp_job &J, float *s)
+{
+    if (J.part == nullptr) return;                                               // kernel-uniform
+    const int ngroups = (J.count + RP_COLS - 1) / RP_COLS;
+    for (int g = (int)blockIdx.x; g < ngroups; g += (int)gridDim.x) rp_reduce_group(J, g, s);
 }
 
 // Sum the four waves' 224 x 32 accumulator sets and write this block's row of the partial-sum matrix
@@ -812,6 +842,19 @@ struct rp_queue {
     size_t used, cap;                                          // floats
 };
 static void rp_init(rp_queue *q, float *base, size_t cap_floats) { q->b.njobs = 0; q->nblocks = 0; q->base = base; q->used = 0; q->cap = cap_floats; }
+// bf16 pass: the job queued last is handed to the NEXT producer kernel, which totals it at its end (rp_reduce_tail) -- rp_take_prev
+// removes it from the batch (or returns an empty job); whatever is still queued when rp_flush is called goes to the stand-alone kernel
+static rp_job rp_take_prev(rp_queue *q)
+{
+    rp_job j;
+    memset(&j, 0, sizeof(j));
+    if (q->b.njobs > 0) {
+        j = q->b.job[--q->b.njobs];
+        q->nblocks = j.block0;
+        j.block0 = 0;
+    }
+    return j;
+}
 static int rp_flush(rp_queue *q, hipStream_t st)
 {
     if (q->b.njobs > 0) hipLaunchKernelGGL(reduce_partials_kernel, dim3(q->nblocks), dim3(256), 0, st, q->b);
@@ -902,12 +945,13 @@ static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const un
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
     int grid = h->num_cus * C::BLOCKS_PER_CU;
     if (grid > tiles) grid = (int)tiles;
+    const rp_job prev = h->chain_reduce ? rp_take_prev(rq) : rp_job{};
     float *partials = rp_add(rq, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
     if (!partials) return -1;
     if (in_u8)
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
     else
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div SB_STAMP_ARG);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
     return 0;
 }
 
@@ -1016,6 +1060,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             int gw = h->num_cus * (tw == 8 ? 3 : 2);                // 16 x 16 tiles: two blocks per CU (LDS); the same grid in the split mode (same order of the partial sums)
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
+            const rp_job prev = h->chain_reduce ? rp_take_prev(&rq) : rp_job{};   // the head's / the layer above's partial rows: totalled at the end of this kernel
             float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
             if (!partials) return -1;
             // 16-wide tiles: weight gradient AND data gradient of the layer from the same staged tiles (bwd16.h); UBD_DILBWD=split (a
@@ -1023,18 +1068,22 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const unsigned *wt = frag16t + (size_t)k * UBD_DIL16_FRAG_U32;
             const bool fuse_dx = tw == 16 && !h->split_dilbwd;     // 8-wide tiles (dilation 16 on 128-wide maps): fused 75 us vs 38 + 33 us apart (two blocks per CU instead of three)
             if (tw == 8 && fuse_dx)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1] WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
             else if (tw == 8)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev WG_STAMP_ARG);
             else if (fuse_dx)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1] WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
             else
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev WG_STAMP_ARG);
             if (!fuse_dx) ubd_launch_dilconv16(h, 1, wt, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }
-        rp_flush(&rq, st);
-        if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
+        // chained reduction: the first dilated layer's rows are totalled at the end of L3's kernel below, so the dilated + head segment
+        // is final (and its all-reduce may start) one kernel later than with the stand-alone reduction
+        if (!h->chain_reduce) {
+            rp_flush(&rq, st);
+            if (ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
+        }
         // separable layers: G1 / G2 are built tile-wise in LDS from the bf16 dDW tensor of the layer above (sepbwd16.h)
         const int pad2 = h->cfg.fml_compatible ? 1 : 0;
         const float *dw0 = params + h->off_sep_dw[0], *dw1 = params + h->off_sep_dw[1], *dw2 = params + h->off_sep_dw[2];
@@ -1042,6 +1091,7 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         unsigned short *ddw3 = (unsigned short *)(ws + T.off_ddw3), *ddw2 = (unsigned short *)(ws + T.off_gb[0]);
         if (launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
                                        grads + h->off_sep_b[2], &rq, n, H2, W2, H4, W4, pad2, H4, W4, 0, 0.f, 1.f, st)) return -1;
+        if (h->chain_reduce && ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
         if (launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, (const unsigned short *)a2, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
                                        grads + h->off_sep_b[1], &rq, n, H2, W2, H2, W2, 1, H4, W4, pad2, 0.f, 1.f, st)) return -1;
         float sub = 0.f, div = 1.f;

@@ -156,7 +156,7 @@ __device__ __forceinline__ unsigned wg_relu_mask2(unsigned g, unsigned m)
 template <typename T, int TW, bool DX>
 __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d,
-                                                             const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout
+                                                             const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout, const rp_job prev
 #ifdef UBD_STAMPS
                                                              , unsigned long long *__restrict__ stamps
 #endif
@@ -360,4 +360,6 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
     }
 #undef WGSTAMP
     wgrad_block_reduce(acc, (float *)smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
+    __syncthreads();                                   // the LDS image is free
+    rp_reduce_tail(prev, (float *)smem);               // the partial rows of the producer in front of this kernel (backward.hip)
 }

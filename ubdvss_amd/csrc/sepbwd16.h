@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
                                                         int W, int OH, int OW, int pad_lo, int DH, int DW_, int pad_up, float pre_sub,
-                                                        float pre_div
+                                                        float pre_div, const rp_job prev
 #ifdef UBD_STAMPS
                                                         , unsigned long long *__restrict__ stamps
 #endif
@@ -708,4 +708,6 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     }
     float *prow = partials + (size_t)blockIdx.x * C::PART;
     for (int t = threadIdx.x; t < C::PART; t += blockDim.x) prow[t] = red[t];
+    __syncthreads();                                   // the LDS image is free
+    rp_reduce_tail(prev, (float *)lds);                // the partial rows of the producer in front of this kernel (backward.hip)
 }
