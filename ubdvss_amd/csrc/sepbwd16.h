@@ -30,7 +30,16 @@
 template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int NW = 4;
     static constexpr int NT = NW * 64;
-    static constexpr int TH = (CIN == UBD_C) ? 8 : 16;
+    // 1/3-channel layer (L1): 8-row tiles since round 4 -- with 16 rows the block took 56 240 bytes of LDS = 44 granules of 1280 bytes and 180
+    // registers: two blocks per CU; with 8 rows 30 448 bytes / 156 registers: three (bf16 train step 1.141-1.157 -> 1.129-1.140 ms in a same-box A/B;
+    // 8 rows at two blocks per CU: 1.175-1.180; four blocks: 25 spilled registers)
+#ifndef SEPB16_TH1
+#define SEPB16_TH1 8
+#endif
+#ifndef SEPB16_L1_BLOCKS
+#define SEPB16_L1_BLOCKS 3
+#endif
+    static constexpr int TH = (CIN == UBD_C) ? 8 : SEPB16_TH1;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int XPIX = PH * PW;
@@ -64,7 +73,7 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int LDS_BYTES = OFF_CONST + 32;
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
     // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
-    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : 2);
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : (CIN != UBD_C ? SEPB16_L1_BLOCKS : 2));
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
 };
 
@@ -151,7 +160,7 @@ __device__ __forceinline__ void sepb16_stage_ar(const char *__restrict__ tensor,
 }
 
 template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
-__global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU == 3) ? 3 : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
+__global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU >= 3) ? (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU) : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
                                                         const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
