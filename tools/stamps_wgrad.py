@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ubdvss_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "_ab", "libubd_hip_diag.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "_ab", os.environ.get("DIAG_LIB", "libubd_hip_diag.so"))
 from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
 torch.cuda.set_device(0)
 lib = _lib.load()
@@ -16,7 +16,7 @@ x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32)
 y = torch.from_numpy(lab).cuda()
 for _ in range(100): tr.train_step_on_device(x, y)
 lib.ubd_debug_set_stamps_sepb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; lib.ubd_debug_set_stamps_sepb.restype = None
-names = ["wait DMA", "barrier", "decode + issue next DMA", "ragged fix", "MFMAs"]
+names = ["wait DMA", "barrier", "decode + issue next DMA", "weight-gradient MFMAs", "data-gradient phase"]
 for d in (2, 4, 8):
     st = torch.zeros((1024, 4, 8, 8), dtype=torch.int64, device="cuda")
     lib.ubd_debug_set_stamps_sepb(st.data_ptr(), -1, d)

@@ -199,9 +199,14 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
     // pixel of this lane inside a k-block (2 tile rows x 16 columns or 4 x 8): k = 8 grp + 4 j + qq, j = 0, 1
     const int krow = TW == 16 ? grp >> 1 : grp, kcol = TW == 16 ? 8 * (grp & 1) + qq : qq;
 
-    // DMA chunk -> (tile row, tile column, 16-byte part) of this lane, per piece of this wave (piece = 4 rd + wid: X pieces
-    // first, then G pieces)
-    int cinfo[C::ROUNDS];
+    // DMA chunk -> (tile row, tile column, 16-byte part) of this lane, per piece of this wave (piece = 4 rd + wid: X pieces first, then
+    // G pieces).  Kept as ONE register per piece: the chunk's byte offset relative to the tile's pixel (1, 1) -- ((sy - 1) d w + (sx - 1) d)
+    // pixels of 48 bytes + 16 part, a multiple of 16 -- in the upper 27 bits (as offset / 16) and the tile column sx (0..17) in the lower
+    // five: an item then costs one wave-uniform base and, per piece, seven vector instructions (column test, offset, select) instead of the
+    // sixteen of the (sy, sx, part) form -- in-kernel stamps had 1.5 k of an item's 10-12 k cycles in this segment without the DMA instructions and 2.3-3 k with
+    // them; the train step did not move with the shorter form (1.136 vs 1.137 ms): the SIMD issues its two waves' instruction streams back to back,
+    // and 70 vector instructions fewer per item are 1 % of them
+    int relsx[C::ROUNDS];
 #pragma unroll
     for (int rd = 0; rd < C::ROUNDS; ++rd) {
         const int piece = rd * 4 + wid;
@@ -217,7 +222,8 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
             if constexpr (DX) { sy = gp / C::GW; sx = gp % C::GW; }         // with halo: the X tile's geometry
             else { sy = gp / TW + 1; sx = gp % TW + 1; }
         }
-        cinfo[rd] = sy | (sx << 8) | (part << 16);
+        const int rel16 = ((sy - 1) * d * w + (sx - 1) * d) * 3 + part;     // offset / 16
+        relsx[rd] = (int)(((unsigned)rel16 << 5) | (unsigned)sx);
     }
 
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
@@ -249,14 +255,18 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
         const size_t imgoff = (size_t)I.img * h * w * (UBD_C * 2);
         __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)x + imgoff), 0, (int)img_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)gz + imgoff), 0, (int)img_bytes, 0x00020000);
+        // wave-uniform: byte offset of the tile's pixel (1, 1); tile columns sx_lo .. sx_hi are inside the map (gx = rx + (sx0 + sx - 1) d in [0, w)).
+        // Rows above / below the map need no test: their offsets are negative or >= img_bytes, i.e. outside the descriptor's range.
+        const int gx1 = I.rx + I.sx0 * d;
+        const int base = ((I.ry + I.sy0 * d) * w + gx1) * (UBD_C * 2);
+        const int sx_lo = gx1 - d < 0 ? 1 : 0;
+        const int sx_span = (w - 1 - gx1 + d) / d - sx_lo;                  // sx_hi - sx_lo (gx1 <= w - 1: the tile starts inside the map)
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int piece = rd * 4 + wid;
             if (piece >= C::XR + C::GR) break;                        // wave-uniform
-            const int ci = cinfo[rd];
-            const int gy = I.ry + (I.sy0 + (ci & 0xFF) - 1) * d;      // < 0 or >= h: the offset leaves the descriptor's range
-            const int gx = I.rx + (I.sx0 + ((ci >> 8) & 0xFF) - 1) * d;
-            const unsigned off = (unsigned)gx < (unsigned)w ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + (unsigned)((ci >> 16) & 0xFF) * 16u : 0x80000000u;
+            const int v = relsx[rd];
+            const unsigned off = (unsigned)((v & 31) - sx_lo) <= (unsigned)sx_span ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;
             ubd_blds16(piece < C::XR ? rx : rg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
@@ -283,7 +293,6 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * C::BUF_BYTES); }
         WGSTAMP(3);
-        WGSTAMP(4);
         const int rows_eff = min(W16_TH(TW), sh - I.sy0);
 #pragma unroll 1
         for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
                 acc[mt][1] = mfma16<T>(a, b[1], acc[mt][1]);
             }
         }
+        WGSTAMP(4);
         if constexpr (DX) {
             const int i16 = lane & 15;
             __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)gout + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
