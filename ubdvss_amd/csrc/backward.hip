@@ -1057,16 +1057,16 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const int dd = UBD_DILATIONS[k];
             const int sw = (W4 + dd - 1) / dd, tw = sw <= 8 ? 8 : 16;              // narrow sub-grids: 8-wide tiles
             const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH(tw) - 1) / W16_TH(tw)) * ((sw + tw - 1) / tw);
-            int gw = h->num_cus * (tw == 8 ? 3 : 2);                // 16 x 16 tiles: two blocks per CU (LDS); the same grid in the split mode (same order of the partial sums)
+            int gw = h->num_cus * (tw == 8 ? 3 : 2);                // 16 x 16 tiles: two blocks per CU (LDS, registers); 8-wide tiles: three; the same grid in the split mode (same order of the partial sums)
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             const rp_job prev = h->chain_reduce ? rp_take_prev(&rq) : rp_job{};   // the head's / the layer above's partial rows: totalled at the end of this kernel
             float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
             if (!partials) return -1;
-            // 16-wide tiles: weight gradient AND data gradient of the layer from the same staged tiles (bwd16.h); UBD_DILBWD=split (a
-            // diagnostic / test switch) and the 8-wide tiles of narrow sub-grids keep the separate data-gradient kernel
+            // weight gradient AND data gradient of the layer from the same staged tiles (bwd16.h); UBD_DILBWD=split (a diagnostic / test
+            // switch) keeps the separate data-gradient kernel
             const unsigned *wt = frag16t + (size_t)k * UBD_DIL16_FRAG_U32;
-            const bool fuse_dx = tw == 16 && !h->split_dilbwd;     // 8-wide tiles (dilation 16 on 128-wide maps): fused 75 us vs 38 + 33 us apart (two blocks per CU instead of three)
+            const bool fuse_dx = !h->split_dilbwd;                 // 8-wide tiles (dilation 16 on 128-wide maps) too since round 4: the fused form with M-split accumulators     // 8-wide tiles (dilation 16 on 128-wide maps): fused 75 us vs 38 + 33 us apart (two blocks per CU instead of three)
             if (tw == 8 && fuse_dx)
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
             else if (tw == 8)

@@ -153,8 +153,16 @@ __device__ __forceinline__ unsigned wg_relu_mask2(unsigned g, unsigned m)
 // right after the weight-gradient MFMAs of an item (its mask is the X tile the weight gradient reads anyway, its input the G tile
 // with a one-pixel halo): the separate data-gradient kernel read G and X once more (100 MB per layer and 64 images) and spent most
 // of its instructions on addresses.  Same arithmetic in the same order as dilconv16_kernel<T, 1> (bit-identical results).
-template <typename T, int TW, bool DX>
-__global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
+// MSPLIT: how the four waves share the 14 x 2 accumulator tiles of the weight gradient.  false (16-wide tiles): by k-blocks -- every wave
+// holds all 28 tiles (112 registers) for its k-blocks and the block adds the four sets up at the end of the launch (252 registers: two
+// blocks per CU).  true (the fused 8-wide form of the dilation-16 layer): by M tiles -- wave w owns mt = w, w + 4, w + 8, w + 12 for ALL
+// k-blocks: 8 tiles = 32 registers, no reduction at the end, every wave reads the G operand (155 registers, 39 KB of LDS: three blocks
+// per CU).  Round 4, same-box A/Bs of the bf16 train step: M-split for the 16-wide form too, two tile buffers / two blocks: +13 us; one
+// tile buffer / three blocks (163 registers, 47 KB): +4 us -- the third wave does not pay for the extra transposed reads; but it makes
+// the FUSED 8-wide form (dilation 16: it lost to the two separate kernels at 252 registers, 75 us against 38 + 33) the faster one: -11 us.
+template <typename T, int TW, bool DX, bool MSPLIT = (TW == 8)>
+#define W16_OCC(TW, DX) (((TW) == 8) ? 3 : 2)
+__global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d,
                                                              const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout, const rp_job prev
 #ifdef UBD_STAMPS
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
 #define WGSTAMP(k) do {} while (0)
 #endif
     using C = w16_cfg<TW, DX>;
-    constexpr int TILES_BYTES = 2 * C::BUF_BYTES > 28672 ? 2 * C::BUF_BYTES : 28672;   // two tile buffers; the block reduction needs 28 KiB
+    constexpr int TILES_BYTES = (!MSPLIT && 2 * C::BUF_BYTES < 28672) ? 28672 : 2 * C::BUF_BYTES;   // two tile buffers; the k-split block reduction needs 28 KiB
     constexpr int CONST_OFF = TILES_BYTES;                                    // [0,8): {1,0,0,0}   [8,32): zeros
     constexpr int WT_OFF = CONST_OFF + 64;                                    // DX: the layer's transposed fragments [7][2][64 lanes] x 16 B
     __shared__ __attribute__((aligned(16))) char smem[TILES_BYTES + 64 + (DX ? 7 * 2 * 64 * 16 : 0)];   // ONE LDS object (see fwd16.hip)
@@ -178,13 +186,15 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
     if (threadIdx.x < 16)
         ((unsigned *)(smem + CONST_OFF))[threadIdx.x] = threadIdx.x == 0 ? (unsigned)__builtin_bit_cast(unsigned short, (T)1.0f) : 0u;   // 64 bytes: {1,0,0,0} then zeros
 
-    // A operand: byte offset of segment p of M-tile mt relative to the X-tile pixel of the output position
-    int aoff[14];
+    // A operand: byte offset of segment p of M-tile mt relative to the X-tile pixel of the output position (slot sl <-> M tile mt(sl))
+    constexpr int MTW = MSPLIT ? 4 : 14;                                 // M-tile slots per wave
+    auto mt_of = [&](int sl) { return MSPLIT ? wid + 4 * sl : sl; };     // wave-uniform
+    int aoff[MTW];
 #pragma unroll
-    for (int mt = 0; mt < 14; ++mt) {
-        const int rho0 = 16 * mt + 4 * p;
+    for (int sl = 0; sl < MTW; ++sl) {
+        const int rho0 = 16 * mt_of(sl) + 4 * p;
         const int t = rho0 / UBD_C, ci = rho0 - t * UBD_C;
-        aoff[mt] = ((t / 3) * C::XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below)
+        aoff[sl] = ((t / 3) * C::XW + (t % 3)) * (UBD_C * 2) + ci * 2;   // mt == 13, p >= 2: constants instead (below); mt >= 14: unused
     }
     // DX: this lane's K-slice of chunk c (as dilconv16_kernel): k0 = 32c + 8 grp -> tap (4c + grp) / 3, channel group (4c + grp) % 3
     int doff[DX ? 7 : 1];
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
     const int chunk = (items + 7) >> 3;
     const int it_begin = xcd * chunk;
     const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
-    f32x4 acc[14][2] = {};
+    f32x4 acc[MTW][2] = {};
     int it = it_begin + (int)(blockIdx.x >> 3);
     item_t I = decode(it < it_end ? it : it_begin);
     if (it < it_end) dma_item(I, 0);
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
         WGSTAMP(3);
         const int rows_eff = min(W16_TH(TW), sh - I.sy0);
 #pragma unroll 1
-        for (int kb = wid; C::KROWS * kb < rows_eff; kb += 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
+        for (int kb = MSPLIT ? 0 : wid; C::KROWS * kb < rows_eff; kb += MSPLIT ? 1 : 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
             const int py = C::KROWS * kb + krow;
             const char *xb = buf + (py * C::XW + kcol) * (UBD_C * 2);
             const char *gb = buf + C::GOFF + ((py + (DX ? 1 : 0)) * C::GW + kcol + (DX ? 1 : 0)) * (UBD_C * 2);
@@ -312,15 +322,18 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
                 b[1] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v10, v11, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int mt = 0; mt < 14; ++mt) {
-                const char *a0 = xb + aoff[mt];
-                const char *a1 = a0 + 4 * UBD_C * 2;
-                if (mt == 13 && p >= 2) { a0 = smem + CONST_OFF + (p == 2 ? 0 : 8); a1 = a0; }
-                const s16x4 va0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
-                const s16x4 va1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
-                const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(va0, va1, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[mt][0] = mfma16<T>(a, b[0], acc[mt][0]);
-                acc[mt][1] = mfma16<T>(a, b[1], acc[mt][1]);
+            for (int sl = 0; sl < MTW; ++sl) {
+                const int mt = mt_of(sl);
+                if (mt < 14) {
+                    const char *a0 = xb + aoff[sl];
+                    const char *a1 = a0 + 4 * UBD_C * 2;
+                    if (mt == 13 && p >= 2) { a0 = smem + CONST_OFF + (p == 2 ? 0 : 8); a1 = a0; }
+                    const s16x4 va0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+                    const s16x4 va1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a1);
+                    const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(va0, va1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[sl][0] = mfma16<T>(a, b[0], acc[sl][0]);
+                    acc[sl][1] = mfma16<T>(a, b[1], acc[sl][1]);
+                }
             }
         }
         WGSTAMP(4);
@@ -369,7 +382,26 @@ __global__ __launch_bounds__(256, ((TW == 8 && !DX) ? 3 : 2)) void dil_wgrad16_k
         I = Inext;
     }
 #undef WGSTAMP
-    wgrad_block_reduce(acc, (float *)smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
-    __syncthreads();                                   // the LDS image is free
+    if constexpr (MSPLIT) {
+        // this block's row of the partial-sum matrix: every wave writes the M tiles it owns (D layout: col = lane & 15 = co within the N
+        // tile, row = 4 (lane >> 4) + r = rho within the M tile)
+        float *__restrict__ prow = partials + (size_t)blockIdx.x * (217 * UBD_C);
+#pragma unroll
+        for (int sl = 0; sl < MTW; ++sl) {
+            const int mt = mt_of(sl);
+            if (mt < 14) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + 4 * grp + r, col = 16 * nt + (lane & 15);
+                        if (row < 217 && col < UBD_C) prow[row * UBD_C + col] = acc[sl][nt][r];
+                    }
+            }
+        }
+    } else {
+        wgrad_block_reduce(acc, (float *)smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
+    }
+    __syncthreads();                                   // every wave has left the LDS
     rp_reduce_tail(prev, (float *)smem);               // the partial rows of the producer in front of this kernel (backward.hip)
 }
