@@ -844,7 +844,13 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
 #define D16S_PIECES ((D16S_PIX * 3 + 63) / 64)               // 16 pieces of 1 KiB (the last one runs past the tile)
 #define D16S_BUF (D16S_PIECES * 1024)
 template <typename T>
-__global__ __launch_bounds__(256, 3) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
+#ifndef D16S_OCC
+#define D16S_OCC 3
+#endif
+#ifndef D16S_UNROLL
+#define D16S_UNROLL 2
+#endif
+__global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                             const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
                                                             int w, int d)
 {
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(256, 3) void dilconv16s_kernel(const unsigned short
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * D16S_BUF); }
         __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)y + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
-#pragma unroll 2
+#pragma unroll D16S_UNROLL
         for (int rr = 0; rr < 4; ++rr) {              // fixed trip count: rows outside the sub-grid only lose their stores
             const int r = 4 * wid + rr;
             const char *gpix = buf + ((r + 1) * 18 + i + 1) * (UBD_C * 2);
@@ -1096,7 +1102,7 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     const int sw = (W4 + d - 1) / d, sh = (H4 + d - 1) / d;
     if (epi == 0 && sw > 8 && !h->direct_dil16) {
         const long items = (long)n * d * d * ((sh + 15) / 16) * ((sw + 15) / 16);
-        int g2 = h->num_cus * 3;
+        int g2 = h->num_cus * D16S_OCC;
         if (g2 > items) g2 = (int)items;
         g2 = (g2 + 7) / 8 * 8;                                     // the item ranges are cut per XCD: all eight need a block
         hipLaunchKernelGGL((dilconv16s_kernel<T>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
