@@ -340,13 +340,6 @@ def test_bf16_chained_partial_sum_reduction_equals_the_batched_launches(monkeypa
         grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
         assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
         t.backward_on_device(x, y)
-        nh = 25 * (1 + ncls)                                     # head kernel + bias gradients: with classes their block sums use LDS float atomics
-        assert torch.equal(t.grads[:-nh], grads[mode][:-nh])
-        if ncls == 0:
-            assert torch.equal(t.grads, grads[mode])
+        assert torch.equal(t.grads, grads[mode])                 # every gradient repeats bit for bit (with classes too: the head's block sums have a fixed order since round 4)
     assert torch.equal(loss["chained"], loss["batched"])
-    assert torch.equal(grads["chained"][:-nh], grads["batched"][:-nh])
-    if ncls == 0:
-        assert torch.equal(grads["chained"], grads["batched"])
-    else:
-        assert torch.allclose(grads["chained"][-nh:], grads["batched"][-nh:], rtol=1e-5, atol=1e-9)
+    assert torch.equal(grads["chained"], grads["batched"])

@@ -89,3 +89,24 @@ def test_train_on_batch_keras_style():
     loss = tr.train_on_batch(x, labels[..., None])
     ref = otorch.loss_and_grads(x, labels[..., None], w, True)[0]
     assert abs(loss - ref) <= 1e-4 * abs(ref)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 3, 72, 104), (1, 3, 2, 64, 96), (3, 2, 8, 128, 128)])
+def test_gradients_repeat_bit_for_bit(dtype, cin, ncls, n, hh, ww):
+    """Round 4: every block-level sum of the backward pass has a fixed order (wave-sequential LDS adds instead of LDS float atomics in the
+    fp32 / fp16 separable backward and in the multi-class head gradient; partial rows totalled in block order): the gradients of
+    repeated evaluations are BIT-identical in every activation type, with and without classes.  (The reference makes no such promise --
+    TF's reductions are not deterministic; this is what makes fused-vs-split and rank-sum comparisons exact.)"""
+    model, w, x, labels = _setup(cin, ncls, True, n, hh, ww, 31 + cin + ncls)
+    cfg = model.net_config
+    m = Model(cfg, dtype=dtype, seed=0)
+    m.set_weights(w)
+    tr = Trainer(m, Adam())
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    tr.backward_on_device(xt, yt)
+    first = tr.grads.clone()
+    assert torch.isfinite(first).all() and float(first.abs().max()) > 0
+    for _ in range(5):
+        tr.backward_on_device(xt, yt)
+        assert torch.equal(tr.grads, first)

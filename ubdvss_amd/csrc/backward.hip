@@ -315,16 +315,20 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict_
     float *red = sA;                                                              // 32 x 32 floats
     for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) red[t] = 0.f;
     __syncthreads();
+    // the four waves add their tiles one after the other (every (row, column) belongs to one lane per wave): a fixed order, so the
+    // head gradients of a multi-class model repeat bit for bit like everything else (round 4; LDS float atomics added them in
+    // whatever order the waves arrived)
+    for (int ph = 0; ph < 4; ++ph) {
+        if (wid == ph) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[mt][nt][r];
-                if (v != 0.f) atomicAdd(&red[(16 * mt + 4 * kq + r) * 32 + m + 16 * nt], v);
-            }
-    __syncthreads();
+                    for (int r = 0; r < 4; ++r) red[(16 * mt + 4 * kq + r) * 32 + m + 16 * nt] += acc[mt][nt][r];
+        }
+        __syncthreads();
+    }
     // one partial row [c (24) | ones][k_out] per block, summed by reduce_partials_kernel (a thousand blocks adding into the
     // same 25 k_out addresses would serialise for tens of microseconds)
     for (int t = threadIdx.x; t < 25 * 32; t += blockDim.x) {
@@ -749,19 +753,30 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
         for (int s = 0; s < CPL; ++s) {
             float v = ddw[t][s];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (i == 0 && ch_ok) atomicAdd(&red[t * CIN + cb + s], v);
+            ddw[t][s] = v;
         }
-    // pointwise kernel / bias gradient: D col = i (co), row = 4q + r (+16 mt) (ci or the ones row)
+    // the four waves add their sums one after the other (inside a wave every address has one writer): a fixed order -- the fp32 /
+    // fp16 train step repeats bit for bit too since round 4 (LDS float atomics added the waves in whatever order they arrived)
+    for (int ph = 0; ph < 4; ++ph) {
+        if ((int)(threadIdx.x >> 6) == ph) {
 #pragma unroll
-    for (int mt = 0; mt < MT_PW; ++mt)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+                for (int s = 0; s < CPL; ++s)
+                    if (i == 0 && ch_ok) red[t * CIN + cb + s] += ddw[t][s];
+            // pointwise kernel / bias gradient: D col = i (co), row = 4q + r (+16 mt) (ci or the ones row)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mt + 4 * q + r, col = i + 16 * nt;
-                if (col < UBD_C && row <= CIN) atomicAdd(&red[9 * CIN + row * UBD_C + col], accpw[mt][nt][r]);   // row CIN = bias
-            }
-    __syncthreads();
+            for (int mt = 0; mt < MT_PW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + 4 * q + r, col = i + 16 * nt;
+                        if (col < UBD_C && row <= CIN) red[9 * CIN + row * UBD_C + col] += accpw[mt][nt][r];   // row CIN = bias
+                    }
+        }
+        __syncthreads();
+    }
     float *prow = partials + (size_t)blockIdx.x * PART;
     for (int t = threadIdx.x; t < PART; t += blockDim.x) prow[t] = red[t];
 }
