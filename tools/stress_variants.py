@@ -2,7 +2,9 @@
   * bf16 / fp16 forward: LDS-staged dilated kernel vs direct kernel (UBD_DILCONV16=direct)
   * bf16 train step: data gradient fused into the weight-gradient kernel vs the two-kernel path (UBD_DILBWD=split)
   * fp32 inference: one-kernel stem vs three kernels (UBD_STEM=fused123 / unfused), fp32 and uint8 input
-  * 16-bit passes: L1 -> L2 in one kernel vs two kernels (UBD_STEM16=split), forward (fp32 and uint8 input) and bf16 train step
+  * 16-bit passes: the stem in one kernel (L1 -> L2 -> L3, default) vs L1 -> L2 fused + L3 (UBD_STEM16=fused12) vs three kernels (UBD_STEM16=split),
+    forward (fp32 and uint8 input) and bf16 train step
+  * bf16 train step: chained partial-sum reduction (default) vs the two batched launches (UBD_REDUCE=batched)
 (UBD_VARIANT_RANDOM_SHAPES=n adds n random shapes)
 on ragged and non-square shapes (sides are multiples of 4, maps not multiples of 16, narrow sub-grids)."""
 import os, sys
@@ -16,7 +18,7 @@ for _ in range(int(os.environ.get("UBD_VARIANT_RANDOM_SHAPES", "0"))):
     shapes.append((int(_rng.integers(1, 7)), 4 * int(_rng.integers(4, 100)), 4 * int(_rng.integers(4, 100))))
 bad = 0
 def model(env, **kw):
-    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM", "UBD_STEM16"): os.environ.pop(k, None)
+    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM", "UBD_STEM16", "UBD_REDUCE"): os.environ.pop(k, None)
     os.environ.update(env)
     return Model(NetConfig(grey=False), seed=7, **kw)
 for (n, h, w) in shapes:
@@ -34,9 +36,11 @@ for (n, h, w) in shapes:
         t = Trainer(model(env, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y); g.append(t.grads.clone())
     ok = torch.equal(g[0], g[1]) and bool(torch.isfinite(g[0]).all()); bad += not ok
     print(f"{n}x{h}x{w} bf16 train fused == split: {ok}", flush=True)
-    t = Trainer(model({"UBD_STEM16": "split"}, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y)
-    ok = torch.equal(g[0], t.grads); bad += not ok
-    print(f"{n}x{h}x{w} bf16 train, L1 -> L2 in one kernel == two kernels: {ok}", flush=True)
+    for env, name in (({"UBD_STEM16": "split"}, "one-kernel stem == three kernels"), ({"UBD_STEM16": "fused12"}, "one-kernel stem == L1 -> L2 fused + L3"),
+                      ({"UBD_REDUCE": "batched"}, "chained reduction == batched launches")):
+        t = Trainer(model(env, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y)
+        ok = torch.equal(g[0], t.grads); bad += not ok
+        print(f"{n}x{h}x{w} bf16 train, {name}: {ok}", flush=True)
     x8 = torch.from_numpy(np.random.default_rng(n * h).integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
     for name, inp in (("fp32", x), ("uint8", x8)):
         a = model({"UBD_STEM": "fused123"}).predict_on_device(inp).clone()
@@ -45,13 +49,14 @@ for (n, h, w) in shapes:
         print(f"{n}x{h}x{w} fp32 net, {name} input, stem fused123 == unfused: {ok}", flush=True)
         for dt in ("bfloat16", "float16"):
             a = model({}, dtype=dt).predict_on_device(inp).clone()
-            b = model({"UBD_STEM16": "split"}, dtype=dt).predict_on_device(inp).clone()
-            ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
-            print(f"{n}x{h}x{w} {dt} net, {name} input, L1 -> L2 in one kernel == two kernels: {ok}", flush=True)
+            for mode in ("split", "fused12"):
+                b = model({"UBD_STEM16": mode}, dtype=dt).predict_on_device(inp).clone()
+                ok = torch.equal(a, b) and bool(torch.isfinite(a).all()); bad += not ok
+                print(f"{n}x{h}x{w} {dt} net, {name} input, one-kernel stem == {mode}: {ok}", flush=True)
 # ---- repeat runs at the headline sizes: every launch of the persistent kernels must reproduce the first one bit for bit
 REPS = int(os.environ.get("UBD_VARIANT_REPEATS", "200"))
 x = torch.from_numpy(synthetic.noise_images(5, 32, 512, 512, 3)).cuda()
-for name, env, kw in (("fp32 one-kernel stem + Winograd", {"UBD_STEM": "fused123"}, {}), ("fp16 staged dilated forward", {}, {"dtype": "float16"})):
+for name, env, kw in (("fp32 one-kernel stem + Winograd", {"UBD_STEM": "fused123"}, {}), ("fp16 one-kernel stem + staged dilated forward", {}, {"dtype": "float16"})):
     m = model(env, **kw)
     first = m.predict_on_device(x).clone()
     diff = sum(0 if torch.equal(m.predict_on_device(x), first) else 1 for _ in range(REPS))
@@ -67,6 +72,6 @@ for _ in range(REPS):
     t.backward_on_device(xt, y)
     diff += 0 if torch.equal(t.grads, g0) else 1
 bad += diff
-print(f"bf16 train step (fused dilated backward): {REPS} passes at 64 x 512 x 512, {diff} differ from the first", flush=True)
+print(f"bf16 train step (one-kernel stem, fused dilated backward, chained reduction): {REPS} passes at 64 x 512 x 512, {diff} differ from the first", flush=True)
 print("MISMATCHES:", bad)
 sys.exit(1 if bad else 0)
