@@ -343,3 +343,29 @@ def test_bf16_chained_partial_sum_reduction_equals_the_batched_launches(monkeypa
         assert torch.equal(t.grads, grads[mode])                 # every gradient repeats bit for bit (with classes too: the head's block sums have a fixed order since round 4)
     assert torch.equal(loss["chained"], loss["batched"])
     assert torch.equal(grads["chained"], grads["batched"])
+
+
+@pytest.mark.parametrize("grey", [False, True])
+def test_bf16_train_uint8_input_fused_stem_equals_split(monkeypatch, grey):
+    """The train step fed uint8 pixels (preprocessing fused into L1; the register-staged input path of the one-kernel stem, which also stores a1
+    and a2): loss and gradients bit-identical to the three-kernel forward, RGB and grey."""
+    from ubdvss_amd import Trainer, Adam, PreprocessingType
+    cfg = NetConfig(grey=grey, preprocessing=PreprocessingType.MOBILENET_LIKE)
+    cin = 1 if grey else 3
+    labels = synthetic.rectangle_maps(35, 3, 72 // 4, 136 // 4)
+    x = torch.from_numpy(synthetic.textured_images(36, labels, 4, cin)).cuda()
+    assert x.dtype == torch.uint8
+    y = torch.from_numpy(labels).cuda()
+    grads, loss = {}, {}
+    for mode in ("fused", "fused12", "split"):
+        if mode != "fused":
+            monkeypatch.setenv("UBD_STEM16", mode)
+        else:
+            monkeypatch.delenv("UBD_STEM16", raising=False)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
+        assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
+    for mode in ("fused", "fused12"):
+        assert torch.equal(loss[mode], loss["split"]), mode
+        assert torch.equal(grads[mode], grads["split"]), (mode, float((grads[mode] - grads["split"]).abs().max()))
