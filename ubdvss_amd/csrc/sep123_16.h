@@ -10,9 +10,10 @@
 // tile that owns it: the backward pass reads them).  Same arithmetic as sep12_16_kernel + sepconv16_kernel<24, 2>, operation for
 // operation (depthwise of L1 on the VALU in tap order, tap-folded diagonal MFMAs for L2 / L3, rounding to T where the split pass
 // stores T): a1, a2, a3 are bit-identical to the split pass (tests/test_gpu_forward16.py; UBD_STEM16=fused12 / split keep it).
-// Price: L1 on 361 and L2 on 289 pixels per 256 owned ones.  L2's tile is walked as 19 units of 16 CONSECUTIVE tile pixels (the
-// B operand of a diagonal MFMA is a per-lane LDS address, so a unit need not be a row), L3's 64 outputs are one unit per wave.
-// LDS: 17.3 + 13.9 + 0.8 + 20.6 KB (RGB fp32 image patch) = 52.6 KB = 42 of the CU's 128 granules of 1280 bytes: three blocks per CU.
+// Price: L1 on 361 and L2 on 289 pixels per 256 owned ones.  L2's tile is walked as 19 units of 16 pixels: its 17 rows (columns 0-15), its
+// 17th column (rows 0-15) and the corner pixel (the B operand of a diagonal MFMA is a per-lane LDS address, so a unit need not be a
+// row); L3's 64 outputs are one unit per wave.
+// LDS: 17.7 + 14.6 + 0.8 + 20.6 KB (RGB fp32 image patch) = 53.6 KB = 42 of the CU's 128 granules of 1280 bytes: three blocks per CU.
 // Per tile: image patch in LDS | barrier | L1 -> a1 patch (0 outside L1's map = L2's 'same' padding) | barrier | request the next
 // tile's image patch | L2 -> L2 tile (0 outside L2's map = L3's padding) | barrier | L3 -> memory.
 #pragma once
@@ -28,17 +29,27 @@ template <int CIN> struct sep123_cfg {
     static constexpr int RC = ROWF / 4;                            // 16-byte chunks per row
     static constexpr int CHUNKS = XP * RC;                         // 1287 / 429
     static constexpr int ROUNDS = (CHUNKS + 255) / 256;            // chunks per thread: 6 / 2
-    static constexpr int A1_BYTES = AP * AP * (UBD_C * 2);         // 17328
-    static constexpr int T2_BYTES = TP * TP * (UBD_C * 2);         // 13872
+    // The two LDS images the diagonal MFMAs read are PLANAR (round 4): the three 16-byte chunks of a pixel (channels 0-7 / 8-15 / 16-23) live
+    // in three planes of 16 bytes per pixel, a multiple of 256 bytes apart.  ds_read_b128 serves a wave in four groups of 16 lanes that are NOT
+    // consecutive ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md): a group mixes eight pixels of k-group q with the other eight pixels of
+    // k-group q + 1, which read DIFFERENT chunks; with pixel-major 48-byte pixels five of a group's sixteen lanes collide for every
+    // alignment (PMC: SQ_LDS_BANK_CONFLICT = 52 % of SQ_LDS_IDX_ACTIVE, the LDS array busy 68 % of the kernel).  In the planar image a
+    // lane's bank depends on its pixel only: a group whose two k-groups read the same tap (five of a unit's eight reads) is conflict-free
+    // as long as the unit's sixteen pixels have distinct indices mod 16 -- true for a row of 16 and for a column (pitch 19: 3 i mod 16).
+    // Both images are written by the kernel itself, so the layout is free (a DMA-filled tile is not: fwd16.hip dilconv16s).
+    static constexpr int A1_PLANE = (AP * AP * 16 + 255) / 256 * 256;      // 5888
+    static constexpr int T2_PLANE = (TP * TP * 16 + 255) / 256 * 256;      // 4864
+    static constexpr int A1_BYTES = 3 * A1_PLANE;                  // 17664
+    static constexpr int T2_BYTES = 3 * T2_PLANE;                  // 14592
     static constexpr int SPARE_BYTES = 512;                        // where masked lanes write (8 bytes per lane)
     static constexpr int BIAS_BYTES = 3 * UBD_C * 4;               // the three layers' biases
     static constexpr int XP_BYTES = CHUNKS * 16;                   // 20592 / 6864
     static constexpr int UNITS1 = (AP * AP + 15) / 16;             // 23
     static constexpr int UPW1 = (UNITS1 + 3) / 4;                  // 6
-    static constexpr int UNITS2 = (TP * TP + 15) / 16;             // 19
+    static constexpr int UNITS2 = TP + 2;                          // 17 rows of 16 pixels, the 17th column as a unit, the corner pixel: 19
     static constexpr int UPW2 = (UNITS2 + 3) / 4;                  // 5
     // gfx950 hands LDS out in granules of 1280 bytes (128 per CU): three blocks per CU need <= 42 granules = 53760 bytes each
-    static constexpr int SMEM = A1_BYTES + T2_BYTES + SPARE_BYTES + BIAS_BYTES + XP_BYTES;   // 52592 / 38864
+    static constexpr int SMEM = A1_BYTES + T2_BYTES + SPARE_BYTES + BIAS_BYTES + XP_BYTES;   // 53648 / 39920
     static_assert(SMEM <= 42 * 1280, "three blocks per CU");
 };
 
@@ -60,8 +71,9 @@ __device__ __forceinline__ sep123_compact sep123_load_compact(const u32x4 *__res
     for (int nt = 0; nt < 2; ++nt) { const u32x4 v = ready[(8 + nt) * 64 + lane]; c.pa[nt] = u32x2{v[0], v[1]}; c.pb[nt] = v[2]; }
     return c;
 }
-// the byte offsets of the B operands are those of the TAPS only (row pitch `pitch` pixels): the caller adds its pixel's own
-__device__ __forceinline__ void sep123_expand(sep123_compact c, int pitch, int lane, u32x4 (&wa0)[5], u32x4 (&wa1)[3],
+// the byte offsets of the B operands are those of the TAPS (row pitch `pitch` pixels, 16 bytes per pixel) and of the chunk's PLANE: the
+// caller adds its pixel's own
+__device__ __forceinline__ void sep123_expand(sep123_compact c, int pitch, int plane, int lane, u32x4 (&wa0)[5], u32x4 (&wa1)[3],
                                               u32x4 (&pwb)[2], int (&xo0)[5], int (&xo1)[3])
 {
     // opaque copies: the expansion is loop-invariant, and hoisted out of the tile loop it would pin both 40-register sets
@@ -79,13 +91,13 @@ __device__ __forceinline__ void sep123_expand(sep123_compact c, int pitch, int l
     for (int j = 0; j < 5; ++j) {
         wa0[j] = u32x4{s0 == 0 ? c.d0[j] : 0u, s0 == 1 ? c.d0[j] : 0u, s0 == 2 ? c.d0[j] : 0u, s0 == 3 ? c.d0[j] : 0u};
         const int ts = 2 * j + (q >> 1), t = ts < 9 ? ts : 8;
-        xo0[j] = ((t / 3) * pitch + t % 3) * (UBD_C * 2) + 16 * (q & 1);
+        xo0[j] = ((t / 3) * pitch + t % 3) * 16 + (q & 1) * plane;          // planar image: 16 bytes per pixel, chunk = plane
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         wa1[j] = u32x4{s1 == 0 ? c.d1[j] : 0u, s1 == 1 ? c.d1[j] : 0u, s1 == 2 ? c.d1[j] : 0u, s1 == 3 ? c.d1[j] : 0u};
         const int ts = 4 * j + q, t = ts < 9 ? ts : 8;
-        xo1[j] = ((t / 3) * pitch + t % 3) * (UBD_C * 2) + 32;
+        xo1[j] = ((t / 3) * pitch + t % 3) * 16 + 2 * plane;
     }
     pwb[0] = u32x4{c.pa[0][0], c.pa[0][1], c.pb[0], 0u};
     pwb[1] = u32x4{c.pa[1][0], c.pa[1][1], c.pb[1], 0u};
@@ -283,8 +295,9 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
                 u32x2 o0 = {relu_pk16(pack2<T>(acc0[0], acc0[1])), relu_pk16(pack2<T>(acc0[2], acc0[3]))};
                 u32x2 o1 = {relu_pk16(pack2<T>(acc1[0], acc1[1])), relu_pk16(pack2<T>(acc1[2], acc1[3]))};
                 if (!inmap) { o0 = u32x2{0u, 0u}; o1 = u32x2{0u, 0u}; }  // outside L1's map: L2's zero padding
-                *(u32x2 *)(valid ? a1p + pp * (UBD_C * 2) + 8 * q : sparep + spare_off) = o0;
-                *(u32x2 *)((valid && q < 2) ? a1p + pp * (UBD_C * 2) + 32 + 8 * q : sparep + spare_off) = o1;
+                // channels 4q .. 4q + 3 = half (q & 1) of chunk q >> 1; channels 16 + 4q .. (q < 2) = half q of chunk 2
+                *(u32x2 *)(valid ? a1p + (q >> 1) * C::A1_PLANE + pp * 16 + 8 * (q & 1) : sparep + spare_off) = o0;
+                *(u32x2 *)((valid && q < 2) ? a1p + 2 * C::A1_PLANE + pp * 16 + 8 * q : sparep + spare_off) = o1;
             }
         }
         S3STAMP(2);
@@ -298,14 +311,15 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
 
         if constexpr (WRITE_A12) {
             // the tile's own 16 x 16 pixels of L1's activation (map rows 2 oy3 .., columns 2 ox3 ..: patch rows / columns 1 + pad ..) leave
-            // for memory: 768 contiguous bytes per row in LDS and in the map; three 16-byte pieces per thread
+            // for memory: 768 contiguous bytes per row of the map (gathered from the three planes); three 16-byte pieces per thread
             __amdgpu_buffer_rsrc_t a1rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a1out + (size_t)img * H2 * W2 * UBD_C), 0,
                                                                             (int)((unsigned)H2 * (unsigned)W2 * (UBD_C * 2u)), 0x00020000);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int c = k * 256 + (int)threadIdx.x;
                 const int row = c / 48, cc = c - row * 48;
-                const u32x4 v = *(const u32x4 *)(a1p + ((row + 1 + pad_lo) * AP + 1 + pad_lo) * (UBD_C * 2) + cc * 16);
+                const int cpx = cc / 3, cch = cc - 3 * cpx;                          // pixel of the row, chunk
+                const u32x4 v = *(const u32x4 *)(a1p + cch * C::A1_PLANE + ((row + 1 + pad_lo) * AP + 1 + pad_lo + cpx) * 16);
                 const int gy = 2 * oy3 + row, gx = 2 * ox3 + cc / 3;
                 const bool in = gy < H2 && gx < W2;
                 __builtin_amdgcn_raw_buffer_store_b128(v, a1rs, in ? (gy * W2 + 2 * ox3) * (UBD_C * 2) + cc * 16 : (int)0x80000000u, 0, 0);
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
 
         // ---- L2 on this wave's units of 16 consecutive pixels of the 17 x 17 tile
         {
-            sep123_expand(k2, AP, lane, wa0, wa1, pwb, xo0, xo1);
+            sep123_expand(k2, AP, C::A1_PLANE, lane, wa0, wa1, pwb, xo0, xo1);
             const f32x4 b2A = *(const f32x4 *)(biasp + UBD_C + 4 * q);
             const f32x4 b2B = q < 2 ? *(const f32x4 *)(biasp + UBD_C + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef S123_UNROLL2
@@ -322,18 +336,18 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
 #endif
 #pragma unroll S123_UNROLL2
             for (int j = 0; j < C::UPW2; ++j) {
-                const int u = wid + 4 * j;
-                const int p = 16 * u + i;
-                const bool valid = p < TP * TP;
-                const int pp = valid ? p : TP * TP - 1;
-                const int pr = pp / TP, pc = pp - pr * TP;
+                const int u = wid + 4 * j;                               // wave-uniform: 0..16 rows, 17 the last column, 18 the corner, 19 nothing
+                const int pr = u < TP ? u : (u == TP ? i : TP - 1);
+                const int pc = u < TP ? i : TP - 1;
+                const bool valid = u < TP || (u == TP && i < TP - 1) || (u == TP + 1 && i == 0);
+                const int pp = pr * TP + pc;
                 u32x2 o0, o1;
-                sep123_unit<T>(a1p + (pr * AP + pc) * (UBD_C * 2), wa0, wa1, pwb, xo0, xo1, b2A, b2B, o0, o1);
+                sep123_unit<T>(a1p + (pr * AP + pc) * 16, wa0, wa1, pwb, xo0, xo1, b2A, b2B, o0, o1);
                 const int gy = oy2 + pr, gx = ox2 + pc;
                 const bool inmap = (unsigned)gy < (unsigned)H2 && (unsigned)gx < (unsigned)W2;
                 if (!inmap) { o0 = u32x2{0u, 0u}; o1 = u32x2{0u, 0u}; }  // outside L2's map: L3's zero padding
-                *(u32x2 *)(valid ? t2p + pp * (UBD_C * 2) + 8 * q : sparep + spare_off) = o0;
-                *(u32x2 *)((valid && q < 2) ? t2p + pp * (UBD_C * 2) + 32 + 8 * q : sparep + spare_off) = o1;
+                *(u32x2 *)(valid ? t2p + (q >> 1) * C::T2_PLANE + pp * 16 + 8 * (q & 1) : sparep + spare_off) = o0;
+                *(u32x2 *)((valid && q < 2) ? t2p + 2 * C::T2_PLANE + pp * 16 + 8 * q : sparep + spare_off) = o1;
             }
         }
         S3STAMP(5);
@@ -349,7 +363,8 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
             for (int k = 0; k < 3; ++k) {
                 const int c = k * 256 + (int)threadIdx.x;
                 const int row = c / 48, cc = c - row * 48;
-                const u32x4 v = *(const u32x4 *)(t2p + ((row + pad_lo) * TP + pad_lo) * (UBD_C * 2) + cc * 16);
+                const int cpx = cc / 3, cch = cc - 3 * cpx;
+                const u32x4 v = *(const u32x4 *)(t2p + cch * C::T2_PLANE + ((row + pad_lo) * TP + pad_lo + cpx) * 16);
                 const int gy = 2 * oy3 + row, gx = 2 * ox3 + cc / 3;
                 const bool in = gy < H2 && gx < W2;
                 __builtin_amdgcn_raw_buffer_store_b128(v, a2rs, in ? (gy * W2 + 2 * ox3) * (UBD_C * 2) + cc * 16 : (int)0x80000000u, 0, 0);
@@ -359,12 +374,12 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
         // ---- L3: one unit per wave = tile rows 2 wid, 2 wid + 1 of the 8 x 8 outputs
 #ifndef S123_NO_L3
         {
-            sep123_expand(k3, TP, lane, wa0, wa1, pwb, xo0, xo1);
+            sep123_expand(k3, TP, C::T2_PLANE, lane, wa0, wa1, pwb, xo0, xo1);
             const f32x4 b3A = *(const f32x4 *)(biasp + 2 * UBD_C + 4 * q);
             const f32x4 b3B = q < 2 ? *(const f32x4 *)(biasp + 2 * UBD_C + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int r3 = 2 * wid + (i >> 3), c3 = i & 7;
             u32x2 o0, o1;
-            sep123_unit<T>(t2p + (2 * r3 * TP + 2 * c3) * (UBD_C * 2), wa0, wa1, pwb, xo0, xo1, b3A, b3B, o0, o1);
+            sep123_unit<T>(t2p + (2 * r3 * TP + 2 * c3) * 16, wa0, wa1, pwb, xo0, xo1, b3A, b3B, o0, o1);
             __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (size_t)img * H4 * W4 * UBD_C), 0,
                                                                            (int)((unsigned)H4 * (unsigned)W4 * (UBD_C * 2u)), 0x00020000);
             const int gy = oy3 + r3, gx = ox3 + c3;
