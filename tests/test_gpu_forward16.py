@@ -369,3 +369,26 @@ def test_bf16_train_uint8_input_fused_stem_equals_split(monkeypatch, grey):
     for mode in ("fused", "fused12"):
         assert torch.equal(loss[mode], loss["split"]), mode
         assert torch.equal(grads[mode], grads["split"]), (mode, float((grads[mode] - grads["split"]).abs().max()))
+
+
+@pytest.mark.parametrize("n,hh,ww", [(2, 256, 256), (3, 72, 104)])
+def test_bf16_train_staged_last_layer_equals_direct(monkeypatch, n, hh, ww):
+    """Round 4: the LDS-staged kernel also runs the LAST dilated layer, with the 1 x 1 head in its epilogue (inference: logits only;
+    train step: logits + the stored activation).  UBD_DILCONV16=direct keeps the direct kernel for every layer: loss and gradients of the
+    bf16 train step are bit-identical (the forward equality is test_forward16_staged_dilated_kernel_equals_direct)."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(grey=False)
+    labels = synthetic.rectangle_maps(45, n, hh // 4, ww // 4)
+    x = torch.from_numpy(synthetic.textured_images(46, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads, loss = {}, {}
+    for mode in ("staged", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("UBD_DILCONV16", "direct")
+        else:
+            monkeypatch.delenv("UBD_DILCONV16", raising=False)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
+    assert torch.equal(loss["staged"], loss["direct"])
+    assert torch.equal(grads["staged"], grads["direct"])

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
 #define D16S_PIX (18 * 18)
 #define D16S_PIECES ((D16S_PIX * 3 + 63) / 64)               // 16 pieces of 1 KiB (the last one runs past the tile)
 #define D16S_BUF (D16S_PIECES * 1024)
-template <typename T>
+template <typename T, int EPI = 0>
 #ifndef D16S_OCC
 #define D16S_OCC 3
 #endif
@@ -852,8 +852,11 @@ template <typename T>
 #endif
 __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                             const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
-                                                            int w, int d)
+                                                            int w, int d, const float *__restrict__ head, float *__restrict__ logits)
 {
+    // EPI 0: y = relu(conv + bias).  EPI 2 / 3 (last hidden layer with ONE output channel, round 4: the staged kernel takes L9 too): the
+    // 1 x 1 head (24 fp32 weights + bias at `head`, net.py:308-311) is applied in the epilogue, fp32 logits to `logits`; EPI 2 (inference)
+    // does not store the activation, EPI 3 (train step) does.  Same expressions as dilconv16_kernel<T, 2 / 3>: bit-identical logits.
     __shared__ __attribute__((aligned(16))) char smem[2 * D16S_BUF + 64];     // ONE LDS object; [2 BUF, +64): zeros
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
@@ -863,6 +866,13 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
     for (int c = 0; c < 7; ++c) { wr[c][0] = wfrag[(c * 2 + 0) * 64 + lane]; wr[c][1] = wfrag[(c * 2 + 1) * 64 + lane]; }
     const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
     const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if constexpr (EPI == 2 || EPI == 3) {
+        hA = *(const f32x4 *)(head + 4 * q);
+        if (q < 2) hB = *(const f32x4 *)(head + 16 + 4 * q);
+        hbias = head[UBD_C];
+    }
     // this lane's K-slice of chunk c: k0 = 32c + 8q -> tap (4c + q) / 3, channel group (4c + q) % 3; chunk 6, q = 3 lies beyond K
     int doff[7];
 #pragma unroll
@@ -923,12 +933,15 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
     for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         const char *buf = smem + (iter & 1) * D16S_BUF;
         // this item's tile has landed; the eight output stores of the previous item (younger than its DMA) stay in flight
-        if (iter > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // (per row: two activation stores, EPI 2 / 3 one logit store)
+        constexpr int NST = 4 * (EPI == 2 ? 1 : (EPI == 3 ? 3 : 2));
+        if (iter > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                              // ... for every wave; everyone left the other buffer
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * D16S_BUF); }
         __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)y + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rlog = __builtin_amdgcn_make_buffer_rsrc((void *)((EPI == 2 || EPI == 3) ? (char *)(logits + (size_t)I.img * h * w) : (char *)y), 0, (int)((unsigned)h * (unsigned)w * 4u), 0x00020000);
 #pragma unroll D16S_UNROLL
         for (int rr = 0; rr < 4; ++rr) {              // fixed trip count: rows outside the sub-grid only lose their stores
             const int r = 4 * wid + rr;
@@ -942,13 +955,27 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
                 acc0 = h16<T>::mfma(wr[c][0], a[c], acc0);
                 acc1 = h16<T>::mfma(wr[c][1], a[c], acc1);
             }
+            const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i) * d;
+            if constexpr (EPI == 2 || EPI == 3) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(round16<T>(fmaxf(acc0[e] + bA[e], 0.f)), hA[e], part);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(round16<T>(fmaxf(acc1[e] + bB[e], 0.f)), hB[e], part);   // hB = 0 for q >= 2
+                part += __shfl_xor(part, 16, 64);                       // sum over the four channel quarters
+                part += __shfl_xor(part, 32, 64);
+                // an unconditional buffer store (out-of-range offset for the lanes that have nothing to write): the count of stores per item is what
+                // the counted vmcnt wait at the top of the next item relies on
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part + hbias), rlog, (q == 0 && gx < w && gy < h) ? (gy * w + gx) * 4 : (int)0x80000000u, 0, 0);
+            }
+            if constexpr (EPI != 2) {
             acc0 += bA; acc1 += bB;                   // bias added last (the order the oracle uses), ReLU on the packed values
             const u32x2 o0 = {relu_pk16(pack2<T>(acc0[0], acc0[1])), relu_pk16(pack2<T>(acc0[2], acc0[3]))};
             const u32x2 o1 = {relu_pk16(pack2<T>(acc1[0], acc1[1])), relu_pk16(pack2<T>(acc1[2], acc1[3]))};
-            const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + i) * d;
             const unsigned off = (gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + 8u * q : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b64(o0, rout, (int)off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(q < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4q + r exist for q < 2
+            }
         }
         I = Inext;
     }
@@ -1100,13 +1127,20 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     const unsigned mg_tx = magic_u32(tiles_x), mg_h = magic_u32((unsigned)H4);
     // forward layers whose dilation sub-grids are wider than 8 pixels: the LDS-staged kernel (UBD_DILCONV16=direct keeps the direct one)
     const int sw = (W4 + d - 1) / d, sh = (H4 + d - 1) / d;
-    if (epi == 0 && sw > 8 && !h->direct_dil16) {
+    if ((epi == 0 || epi == 2 || epi == 3) && sw > 8 && !h->direct_dil16) {
         const long items = (long)n * d * d * ((sh + 15) / 16) * ((sw + 15) / 16);
         int g2 = h->num_cus * D16S_OCC;
         if (g2 > items) g2 = (int)items;
         g2 = (g2 + 7) / 8 * 8;                                     // the item ranges are cut per XCD: all eight need a block
-        hipLaunchKernelGGL((dilconv16s_kernel<T>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                           (const u32x4 *)frag, bias, n, H4, W4, d);
+        if (epi == 0)
+            hipLaunchKernelGGL((dilconv16s_kernel<T, 0>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)nullptr, (float *)nullptr);
+        else if (epi == 2)      // out = fp32 logits, mask = fp32 head: the activation is not stored
+            hipLaunchKernelGGL((dilconv16s_kernel<T, 2>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)nullptr,
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, (float *)out);
+        else                    // out = activation, logits3 = fp32 logits
+            hipLaunchKernelGGL((dilconv16s_kernel<T, 3>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, logits3);
     } else if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
