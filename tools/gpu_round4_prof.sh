@@ -19,3 +19,6 @@ UBD_PMC_DTYPE=float16 bash tools/gpu_pmc_traffic.sh > /dev/null 2>&1; cp gpurun_
 bash tools/gpu_pmc.sh dilconv_wino > /dev/null 2>&1; cp gpurun_out/pmc_dilconv_wino.txt gpurun_out/r04_pmc_dilconv_wino.txt
 bash tools/gpu_pmc.sh stem123_kernel > /dev/null 2>&1; cp gpurun_out/pmc_stem123_kernel.txt gpurun_out/r04_pmc_stem123_fp32.txt
 head -14 gpurun_out/r04_pmc_traffic_train_bf16.txt
+UBD_PMC_DTYPE=float16 bash tools/gpu_pmc.sh dilconv16s > /dev/null 2>&1; cp gpurun_out/pmc_dilconv16s.txt gpurun_out/r04_pmc_dilconv16s_fp16.txt
+UBD_PMC_DTYPE=float16 bash tools/gpu_pmc.sh sep123_16 > /dev/null 2>&1; cp gpurun_out/pmc_sep123_16.txt gpurun_out/r04_pmc_sep123_16_fp16.txt
+grep -E "BANK_CONFLICT|IDX_ACTIVE" gpurun_out/r04_pmc_sep123_16_fp16.txt
