@@ -346,6 +346,32 @@ def test_bf16_chained_partial_sum_reduction_equals_the_batched_launches(monkeypa
 
 
 @pytest.mark.parametrize("grey", [False, True])
+@pytest.mark.parametrize("n,hh,ww", [(2, 256, 256), (3, 72, 104), (1, 40, 36), (2, 132, 68)])
+def test_bf16_l1_backward_input_patch_by_lds_dma_equals_register_staging(monkeypatch, grey, n, hh, ww):
+    """bf16 train step on preprocessed fp32 images: the backward kernel of L1 fetches its fp32 input patch by LDS-DMA (16-byte chunks, rows
+    from the aligned boundary below the patch, zeros outside the image from the buffer descriptor; sepbwd16.h IN_MODE 2) instead of
+    4-byte loads held in registers over phase 2 (UBD_SEPB16_X=regs).  Same values, same order of sums: bit-identical gradients."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(grey=grey)
+    cin = 1 if grey else 3
+    labels = synthetic.rectangle_maps(45, n, hh // 4, ww // 4)
+    x = torch.from_numpy(synthetic.textured_images(46, labels, 4, cin).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads, loss = {}, {}
+    for mode in ("dma", "regs"):
+        if mode == "regs":
+            monkeypatch.setenv("UBD_SEPB16_X", "regs")
+        else:
+            monkeypatch.delenv("UBD_SEPB16_X", raising=False)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
+        assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
+    assert torch.equal(loss["dma"], loss["regs"])
+    assert torch.equal(grads["dma"], grads["regs"]), float((grads["dma"] - grads["regs"]).abs().max())
+
+
+@pytest.mark.parametrize("grey", [False, True])
 def test_bf16_train_uint8_input_fused_stem_equals_split(monkeypatch, grey):
     """The train step fed uint8 pixels (preprocessing fused into L1; the register-staged input path of the one-kernel stem, which also stores a1
     and a2): loss and gradients bit-identical to the three-kernel forward, RGB and grey."""

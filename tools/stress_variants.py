@@ -5,6 +5,7 @@
   * 16-bit passes: the stem in one kernel (L1 -> L2 -> L3, default) vs L1 -> L2 fused + L3 (UBD_STEM16=fused12) vs three kernels (UBD_STEM16=split),
     forward (fp32 and uint8 input) and bf16 train step
   * bf16 train step: chained partial-sum reduction (default) vs the two batched launches (UBD_REDUCE=batched)
+  * bf16 train step: L1 backward with its fp32 input patch by LDS-DMA (default) vs staged through registers (UBD_SEPB16_X=regs)
 (UBD_VARIANT_RANDOM_SHAPES=n adds n random shapes)
 on ragged and non-square shapes (sides are multiples of 4, maps not multiples of 16, narrow sub-grids)."""
 import os, sys
@@ -18,7 +19,7 @@ for _ in range(int(os.environ.get("UBD_VARIANT_RANDOM_SHAPES", "0"))):
     shapes.append((int(_rng.integers(1, 7)), 4 * int(_rng.integers(4, 100)), 4 * int(_rng.integers(4, 100))))
 bad = 0
 def model(env, **kw):
-    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM", "UBD_STEM16", "UBD_REDUCE"): os.environ.pop(k, None)
+    for k in ("UBD_DILCONV16", "UBD_DILBWD", "UBD_STEM", "UBD_STEM16", "UBD_REDUCE", "UBD_SEPB16_X"): os.environ.pop(k, None)
     os.environ.update(env)
     return Model(NetConfig(grey=False), seed=7, **kw)
 for (n, h, w) in shapes:
@@ -37,7 +38,8 @@ for (n, h, w) in shapes:
     ok = torch.equal(g[0], g[1]) and bool(torch.isfinite(g[0]).all()); bad += not ok
     print(f"{n}x{h}x{w} bf16 train fused == split: {ok}", flush=True)
     for env, name in (({"UBD_STEM16": "split"}, "one-kernel stem == three kernels"), ({"UBD_STEM16": "fused12"}, "one-kernel stem == L1 -> L2 fused + L3"),
-                      ({"UBD_REDUCE": "batched"}, "chained reduction == batched launches")):
+                      ({"UBD_REDUCE": "batched"}, "chained reduction == batched launches"),
+                      ({"UBD_SEPB16_X": "regs"}, "L1 backward input by LDS-DMA == through registers")):
         t = Trainer(model(env, dtype="bfloat16"), Adam()); t.backward_on_device(xt, y)
         ok = torch.equal(g[0], t.grads); bad += not ok
         print(f"{n}x{h}x{w} bf16 train, {name}: {ok}", flush=True)

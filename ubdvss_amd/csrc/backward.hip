@@ -957,12 +957,23 @@ static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const un
                           float sub, float div, hipStream_t st)
 {
     using C = sepb16_cfg<CIN, STRIDE, GSRC>;
+    // 1/3-channel fp32 input that is already preprocessed, rows a whole number of 16-byte chunks: the patch is fetched by LDS-DMA
+    // (UBD_SEPB16_X=regs keeps the register path, which also serves every other input)
+    bool xdma = false;
+    if constexpr (CIN != UBD_C)
+        xdma = !in_u8 && sub == 0.f && div == 1.f && (W * CIN) % 4 == 0 && ((uintptr_t)x & 15) == 0 && (unsigned)pad_lo <= 1u && !h->sepb_x_regs;
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
-    int grid = h->num_cus * C::BLOCKS_PER_CU;
+    int grid = h->num_cus * (xdma ? sepb16_cfg<CIN, STRIDE, GSRC, 1>::BLOCKS_PER_CU : C::BLOCKS_PER_CU);
     if (grid > tiles) grid = (int)tiles;
     const rp_job prev = h->chain_reduce ? rp_take_prev(rq) : rp_job{};
     float *partials = rp_add(rq, grid, C::PART, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
     if (!partials) return -1;
+    if constexpr (CIN != UBD_C) {
+        if (xdma) {
+            hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 2, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
+            return 0;
+        }
+    }
     if (in_u8)
         hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
     else

@@ -27,7 +27,7 @@
 
 // NW = waves per block: the 1/3-channel layer needs few registers, so 6 waves share one tile's LDS (3 waves per SIMD at two
 // blocks per CU); the 24-channel layers hold 54 + 16 accumulators per lane and run 4 waves per block.
-template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
+template <int CIN, int STRIDE, int GSRC, int XDMA = 0> struct sepb16_cfg {
     static constexpr int NW = 4;
     static constexpr int NT = NW * 64;
     // 1/3-channel layer (L1): 8-row tiles since round 4 -- with 16 rows the block took 56 240 bytes of LDS = 44 granules of 1280 bytes and 180
@@ -60,8 +60,14 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int OFF_D = XBUF * XI * 1024;                                  // byte offsets inside the DMA area
     static constexpr int OFF_M = OFF_D + DI * 1024;
     static constexpr int DMA_BYTES = OFF_M + MI * 1024;
-    static constexpr int XREGS = (CIN == UBD_C) ? 1 : (XPIX * CIN + NT - 1) / NT;                           // staged input elements per thread
-    static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XPIX * CIN + 3) / 4 * 16;   // fp32 patch of 1/3-channel inputs
+    static constexpr int XREGS = (CIN == UBD_C || XDMA) ? 1 : (XPIX * CIN + NT - 1) / NT;                  // staged input elements per thread
+    // XDMA (1/3-channel fp32 input that needs no preprocessing, image rows a whole number of 16-byte chunks): the patch rows are
+    // fetched by LDS-DMA from the 16-byte boundary at or below their first float (skew 0..3 floats: pad_lo channels back from a
+    // 16-byte-aligned tile origin), double-buffered; XROWC chunks per row
+    static constexpr int XROWC = (PW * CIN + (CIN == 3 ? 1 : 3) + 3) / 4;
+    static constexpr int XROW = XDMA ? XROWC * 4 : PW * CIN;                        // row pitch of the fp32 patch (floats)
+    static constexpr int XD_CHUNKS = PH * XROWC, XDI = (XD_CHUNKS + 63) / 64, XDK = (XDI + NW - 1) / NW;
+    static constexpr int XF32_BYTES = (CIN == UBD_C) ? 0 : (XDMA ? 2 * XDI * 1024 : (XPIX * CIN + 3) / 4 * 16);   // fp32 patch of 1/3-channel inputs
     static constexpr int OFF_DMA = XF32_BYTES;
     static constexpr int OFF_G = OFF_DMA + DMA_BYTES;                  // G tile in T (GSRC 0: the D tile itself)
     static constexpr int OFF_SDW = OFF_G + (GSRC == 0 ? 0 : GPIX * UBD_C * 2);   // per-wave depthwise-output images
@@ -73,7 +79,10 @@ template <int CIN, int STRIDE, int GSRC> struct sepb16_cfg {
     static constexpr int LDS_BYTES = OFF_CONST + 32;
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
     // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
-    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : (CIN != UBD_C ? SEPB16_L1_BLOCKS : 2));
+#ifndef SEPB16_XD_BLOCKS
+#define SEPB16_XD_BLOCKS 3
+#endif
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : (CIN != UBD_C ? (XDMA ? SEPB16_XD_BLOCKS : SEPB16_L1_BLOCKS) : 2));
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
 };
 
@@ -159,8 +168,9 @@ __device__ __forceinline__ void sepb16_stage_ar(const char *__restrict__ tensor,
     }
 }
 
-template <int CIN, int STRIDE, int IN_U8, int GSRC, typename T>
-__global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU >= 3) ? (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU) : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
+// IN_MODE (1/3-channel layers): 0 fp32 input through registers (preprocessed here), 1 uint8 input through registers, 2 fp32 input by LDS-DMA
+template <int CIN, int STRIDE, int IN_MODE, int GSRC, typename T>
+__global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::BLOCKS_PER_CU >= 3) ? (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::BLOCKS_PER_CU) : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
                                                         const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
@@ -177,7 +187,10 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #else
 #define SBSTAMP(k) do {} while (0)
 #endif
-    using C = sepb16_cfg<CIN, STRIDE, GSRC>;
+    constexpr bool XDMA = (IN_MODE == 2);
+    constexpr int IN_U8 = (IN_MODE == 1);
+    static_assert(!XDMA || CIN != UBD_C, "the 24-channel patch is a 16-bit tensor");
+    using C = sepb16_cfg<CIN, STRIDE, GSRC, XDMA>;
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         }
     }
     const unsigned lds_dma = ubd_lds_addr(dma);
+    const unsigned lds_x = ubd_lds_addr(lds);
     __amdgpu_buffer_rsrc_t ddw_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)dDW, 0, dDW ? (int)((unsigned)n * OH * OW * (UBD_C * 2)) : 0, 0x00020000);   // <= 2^31 bytes (ubd.h size limits)
     unsigned *utp = (unsigned *)(lds + C::OFF_UT);
 
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // address is image base (scalar registers) + a 32-bit element offset -- the size_t index arithmetic of round 1 cost five
     // quarter-rate v_mad_u64_u32 per element on border tiles
     int xpk[C::XREGS];
-    if constexpr (CIN != UBD_C) {
+    if constexpr (CIN != UBD_C && !XDMA) {
 #pragma unroll
         for (int k = 0; k < C::XREGS; ++k) {
             int e = k * C::NT + (int)threadIdx.x;
@@ -373,6 +387,29 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     // 1/3-channel input: raw bits (fp32 pattern or zero-extended byte; 0x100 / pre_sub bits = "outside", exactly 0 after the
     // preprocessing) held in registers across phase 2
     unsigned xreg[C::XREGS];
+    const int xskew = (-(CIN * pad_lo)) & 3;                            // XDMA: floats between the 16-byte boundary and the patch's first float
+    auto stage_xd = [&](const geom &g, int buf) {
+        if constexpr (XDMA) {
+            using MR = sepb16_magic<C::XROWC, C::XDI * 64>;
+            const int WC = W * CIN;
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)g.img * H * WC * 4), 0,
+                                                                            (int)((unsigned)H * WC * 4), 0x00020000);   // wave-uniform; rows above / below the image fall out of its range
+            const int a0f = g.ix0 * CIN - xskew;                          // a multiple of 4 (tile origins are multiples of 32 pixels)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int k = 0; k < C::XDK; ++k) {
+                const int instr = k * C::NW + wid;
+                if (instr >= C::XDI) break;                               // wave-uniform
+                const unsigned c = (unsigned)(instr * 64 + ln);
+                const unsigned pr = __umul24(c, MR::m) >> MR::sh, pc = c - (unsigned)C::XROWC * pr;
+                const int gy = g.iy0 + (int)pr, f0 = a0f + 4 * (int)pc;
+                // chunks left / right of the image row (never partial: the row is a whole number of chunks) and the slack of the last piece: zeros
+                const unsigned off = (c < (unsigned)C::XD_CHUNKS && (unsigned)f0 < (unsigned)WC) ? (unsigned)((gy * WC + f0) * 4) : 0x80000000u;
+                ubd_blds16(rsrc, off, lds_x + buf * (C::XDI * 1024) + instr * 1024);
+            }
+        }
+    };
     auto load_x = [&](const geom &g) {
         const int WC = W * CIN;
         const unsigned char *img8 = (const unsigned char *)xin + (size_t)g.img * H * WC * (IN_U8 ? 1 : 4);   // wave-uniform
@@ -405,7 +442,8 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
     if (tile < total) {
         const geom g0 = tile_geom(tile);
         if constexpr (D_AHEAD) stage_dm(g0);
-        if constexpr (CIN != UBD_C) load_x(g0);
+        if constexpr (XDMA) stage_xd(g0, 0);
+        else if constexpr (CIN != UBD_C) load_x(g0);
         if constexpr (X_AHEAD) stage_x(g0, 0);
     }
     for (; tile < total; tile += gridDim.x) {
@@ -414,12 +452,14 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         const bool xborder = g.xborder;
         const char *xraw = dma + xb * (C::XI * 1024);                  // 24-channel patch (bf16)
         SBSTAMP(0);
-        __syncthreads();                                               // previous tile's phase 2 is done: X patch / xf32 are free
+        // previous tile's phase 2 is done: X patch / xf32 are free.  XDMA: nothing is written before the barrier behind the wait
+        // below, and the next tile's patch goes into the other buffer, last read two barriers ago
+        if constexpr (!XDMA) __syncthreads();
         SBSTAMP(1);
         if constexpr (!D_AHEAD) stage_dm(g);
         if constexpr (CIN == UBD_C) {
             if constexpr (!X_AHEAD) stage_x(g, 0);
-        } else {
+        } else if constexpr (!XDMA) {
             const bool plain = !IN_U8 && pre_sub == 0.f && pre_div == 1.f;      // already preprocessed fp32 input: a copy (no 12-instruction division)
             if (xborder) {                                             // block-uniform: outside the image = exactly 0 after the preprocessing
 #pragma unroll
@@ -506,13 +546,15 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
         if (tile + (int)gridDim.x < total) {                           // block-uniform: next tile's D / mask (and 1/3-channel input)
             const geom gn = tile_geom(tile + gridDim.x);
             if constexpr (D_AHEAD) stage_dm(gn);
-            if constexpr (CIN != UBD_C) load_x(gn);
+            if constexpr (XDMA) stage_xd(gn, xb ^ 1);
+            else if constexpr (CIN != UBD_C) load_x(gn);
             if constexpr (X_AHEAD) stage_x(gn, xb ^ 1);
         }
         SBSTAMP(6);
 
         // ---- phase 2: two row tiles (one k-block of 32 pixels) per step
         const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;   // roles in the transposed reads (bwd16.h)
+        const float *xt = XDMA ? (const float *)(lds + xb * (C::XDI * 1024)) + xskew : xf32;   // fp32 patch of this tile (1/3 channels)
 #pragma unroll 1
         for (int rp = 0; rp < C::TH / (2 * C::NW); ++rp) {
             const int r0 = wid + C::NW * (2 * rp), r1 = r0 + C::NW;
@@ -571,7 +613,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int t = ky * 3 + kx;
-                        const float v = xf32[((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * CIN + cb];
+                        const float v = xt[(r * STRIDE + ky) * C::XROW + (i * STRIDE + kx) * CIN + cb];
                         dwv = fmaf(v, dwk1[t], dwv);                    // dwk1 is zero for lanes without a channel
                         ddw[t][0] = fmaf(v, ddwv, ddw[t][0]);
                     }
@@ -664,7 +706,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC>::BLOCKS_PER_CU 
 #ifdef UBD_STAMPS
         ++stamp_it;
 #endif
-        if constexpr (X_AHEAD) xb ^= 1;
+        if constexpr (X_AHEAD || XDMA) xb ^= 1;
     }
 #undef SBSTAMP
     // ---- flush: wave-sequential reduction of the per-lane sums into this block's row of the partial-sum matrix
