@@ -27,6 +27,9 @@
 
 // NW = waves per block: the 1/3-channel layer needs few registers, so 6 waves share one tile's LDS (3 waves per SIMD at two
 // blocks per CU); the 24-channel layers hold 54 + 16 accumulators per lane and run 4 waves per block.
+#ifndef SEPB16_G2_MFMA
+#define SEPB16_G2_MFMA 1      // L2's G tile on the matrix pipe (0: the v_dot2c form)
+#endif
 template <int CIN, int STRIDE, int GSRC, int XDMA = 0> struct sepb16_cfg {
     static constexpr int NW = 4;
     static constexpr int NT = NW * 64;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
     // Lane (i, q) owns channels chs(s) = {4q .. 4q+3, 16+2q, 17+2q} of pixel column i (24-channel layers) or channel q
     // (1/3 channels).  Depthwise taps live in LDS tables ([tap][24], read as b128 + b64 broadcast per k-group): keeping
     // 2 x 54 of them in VGPRs limits the kernel to two waves per SIMD.
-    if constexpr (GSRC != 0)
+    if constexpr (GSRC != 0 && !((GSRC == 2) && (SEPB16_G2_MFMA != 0)))
         for (int t = threadIdx.x; t < 12 * UBD_C; t += C::NT) {
             const int ch = t % UBD_C, kk = t / UBD_C, kx = kk & 3, ky = kk >> 2;
             // 16-bit tap in the half of the dword that matches the channel's position in its pair: ONE v_dot2c then
@@ -264,6 +267,42 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
             ga1[j] = u32x4{w[0], w[1], w[2], w[3]};
             const int ky = t / 3, kx = t - 3 * ky;
             gb1[j] = ((2 - ky) * C::DCOLS + (i + 2 - kx)) * 48 + 32;
+        }
+    }
+    // GSRC 2 (L2: stride-2 transposed depthwise conv of L3's dDW): the same construction (round 4; it was 24 v_dot2c + 16 LDS reads per
+    // row).  A G pixel receives only the taps whose row / column parity matches its own: the rows of a wave (wid + 4 kr, oy0 even) all
+    // have ONE parity, so a wave folds either the six taps ky in {0, 2} or the three taps ky = 1 into its MFMAs -- three + two (two + one)
+    // per row of 16 pixels --, and a lane whose column parity does not match a tap's kx supplies the 16-byte ZERO operand as its B
+    // column for that tap.  The diagonal A operands hold one non-zero 16-bit value per lane: kept compact (one register per MFMA) and
+    // expanded with four selects where they are used -- the kernel has no 20 registers to spare at three blocks per CU.
+    constexpr bool UREG2 = (GSRC == 2) && (SEPB16_G2_MFMA != 0);
+    unsigned g2d0[UREG2 ? 3 : 1], g2d1[UREG2 ? 2 : 1];            // the non-zero value of this lane's A fragment, already in its half of the dword
+    int g2b0[UREG2 ? 3 : 1], g2b1[UREG2 ? 2 : 1];                 // B operand: byte offset inside the D tile for the wave's first row, < 0: the zero operand
+    const int g2par = (wid + pad_up) & 1;                         // wave-uniform: 0 -> taps ky in {0, 2}, 1 -> ky = 1
+    if constexpr (UREG2) {
+        const int ntap = g2par ? 3 : 6;
+        auto wup2 = [&](int ky, int kx, int ch) { return (unsigned)__builtin_bit_cast(unsigned short, (T)dw_up[(ky * 3 + kx) * UBD_C + ch]); };
+        auto tap_of = [&](int ts, int &ky, int &kx) { ky = g2par ? 1 : (ts < 3 ? 0 : 2); kx = ts % 3; };
+        auto boff = [&](int ky, int kx, int chunk_bytes) {
+            if (((i + pad_up - kx) & 1) != 0) return -1;             // this pixel column does not receive the tap
+            const int dr = ((wid + pad_up - ky) >> 1) + 1, dc = ((i + pad_up - kx) >> 1) + 1;
+            return (dr * C::DCOLS + dc) * 48 + chunk_bytes;
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ts = 2 * j + (q >> 1), e = i - 8 * (q & 1);      // k = 8q + e <-> channel 8 (q & 1) + e == row i
+            int ky, kx;
+            tap_of(ts < ntap ? ts : 0, ky, kx);
+            g2d0[j] = (ts < ntap && e >= 0 && e < 8) ? wup2(ky, kx, i) << (16 * (e & 1)) : 0u;
+            g2b0[j] = ts < ntap ? boff(ky, kx, 16 * (q & 1)) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ts = 4 * j + q, rr = i & 3, e = 2 * (i >> 2) + rr;   // row i = 4 qq + rr <-> channel 16 + 2 qq + rr (rr < 2)
+            int ky, kx;
+            tap_of(ts < ntap ? ts : 0, ky, kx);
+            g2d1[j] = (ts < ntap && rr < 2) ? wup2(ky, kx, 16 + e) << (16 * (e & 1)) : 0u;
+            g2b1[j] = ts < ntap ? boff(ky, kx, 32) : -1;
         }
     }
     // 24-channel layers, phase 2 on the matrix pipe (M2).  The depthwise recompute uses the same tap-folded diagonal
@@ -508,6 +547,30 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
                 for (int j = 0; j < 5; ++j) c0 = mfma16<T>(ga0[j], b0[j], c0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) c1 = mfma16<T>(ga1[j], b1[j], c1);
+                acc[0] = c0[0]; acc[1] = c0[1]; acc[2] = c0[2]; acc[3] = c0[3]; acc[4] = c1[0]; acc[5] = c1[1];
+            } else if constexpr (UREG2) {
+                const char *rowb = draw + kr * (2 * C::DCOLS * 48);        // row wid + 4 kr: two D rows further down
+                const char *zero16 = lds + C::OFF_CONST + 16;
+                const int e0 = i - 8 * (q & 1), s0 = (e0 >= 0 && e0 < 8) ? (e0 >> 1) : -1;
+                const int s1 = (i & 3) < 2 ? (i >> 2) : -1;
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                u32x4 b0[3], b1[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) b0[j] = *(const u32x4 *)(g2b0[j] >= 0 ? rowb + g2b0[j] : zero16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b1[j] = *(const u32x4 *)(g2b1[j] >= 0 ? rowb + g2b1[j] : zero16);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j == 2 && g2par) break;                         // wave-uniform: three taps fill two MFMAs (channels 0..15)
+                    const u32x4 wa = {s0 == 0 ? g2d0[j] : 0u, s0 == 1 ? g2d0[j] : 0u, s0 == 2 ? g2d0[j] : 0u, s0 == 3 ? g2d0[j] : 0u};
+                    c0 = mfma16<T>(wa, b0[j], c0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && g2par) break;                         // ... and one (channels 16..23)
+                    const u32x4 wa = {s1 == 0 ? g2d1[j] : 0u, s1 == 1 ? g2d1[j] : 0u, s1 == 2 ? g2d1[j] : 0u, s1 == 3 ? g2d1[j] : 0u};
+                    c1 = mfma16<T>(wa, b1[j], c1);
+                }
                 acc[0] = c0[0]; acc[1] = c0[1]; acc[2] = c0[2]; acc[3] = c0[3]; acc[4] = c1[0]; acc[5] = c1[1];
             } else {
 #pragma unroll
