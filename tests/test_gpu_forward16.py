@@ -226,7 +226,9 @@ def test_bf16_train_full_size_batch_is_deterministic():
 def test_bf16_dilated_backward_fused_equals_split(monkeypatch, n, hh, ww):
     """The bf16 dilated backward computes a layer's data gradient inside its weight-gradient kernel (same staged tiles, same
     MFMA order as the stand-alone data-gradient kernel): the gradients must be BIT-IDENTICAL to the two-kernel path
-    (UBD_DILBWD=split, read when the handle is created) -- on maps with several 16 x 16 sub-grid tiles per phase and on ragged ones."""
+    (UBD_DILBWD=split, read when the handle is created) -- on maps with several 16 x 16 sub-grid tiles per phase and on ragged ones.
+    (The fused side runs with UBD_DILBWD=pair8: sub-grids of exactly 8 columns -- dilation 8 on the 64-wide maps here -- otherwise go in pairs
+    into 16-wide tiles, which adds the same weight-gradient products in another order: test_bf16_dilated_backward_paired_subgrids_... below.)"""
     from ubdvss_amd import Trainer, Adam
     cfg = NetConfig(grey=False)
     labels = synthetic.rectangle_maps(5, n, hh // 4, ww // 4)
@@ -234,16 +236,56 @@ def test_bf16_dilated_backward_fused_equals_split(monkeypatch, n, hh, ww):
     y = torch.from_numpy(labels).cuda()
     grads = {}
     for mode in ("fused", "split"):
-        if mode == "split":
-            monkeypatch.setenv("UBD_DILBWD", "split")
-        else:
-            monkeypatch.delenv("UBD_DILBWD", raising=False)
+        monkeypatch.setenv("UBD_DILBWD", "split" if mode == "split" else "pair8")
         m = Model(cfg, dtype="bfloat16", seed=9)
         t = Trainer(m, Adam())
         t.backward_on_device(x, y)
         grads[mode] = t.grads.clone()
         assert torch.isfinite(grads[mode]).all()
+    monkeypatch.delenv("UBD_DILBWD", raising=False)
     assert torch.equal(grads["fused"], grads["split"])
+
+
+@pytest.mark.parametrize("n,hh,ww,layers", [(2, 512, 512, ("l8",)), (1, 64, 512, ("l8",)), (3, 260, 512, ("l8",)), (1, 36, 512, ("l8",)), (2, 256, 256, ("l7",)),
+                                               (2, 128, 128, ("l6",))])
+def test_bf16_dilated_backward_paired_subgrids_equal_the_8_wide_tiles(monkeypatch, n, hh, ww, layers):
+    """Dilation 16 on 128-wide maps (dilation 8 on 64-wide, 4 on 32-wide ones): sub-grids of exactly 8 columns.  The fused backward kernel takes TWO of them (phases rx, rx + 1) side by
+    side in one 16-wide tile with a zero column between them (bwd16.h PAIR) instead of one per 8-wide item (UBD_DILBWD=pair8).  The data
+    gradient is the same arithmetic per pixel: every tensor that flows on is bit-identical, so the gradients of all OTHER layers are too up
+    to their own sums; the layer's own weight gradient adds the same products in a different order (other items, other blocks): 1e-5.
+    Also against the two-kernel path (UBD_DILBWD=split).  Full, single-row (64 x 512: one sub-grid row), ragged (260: 5 or 4 rows per
+    sub-grid) and short (36 x 512) maps."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(grey=False)
+    labels = synthetic.rectangle_maps(15, n, hh // 4, ww // 4)
+    x = torch.from_numpy(synthetic.textured_images(16, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads = {}
+    for mode in ("pair", "pair8", "split"):
+        if mode == "pair":
+            monkeypatch.delenv("UBD_DILBWD", raising=False)
+        else:
+            monkeypatch.setenv("UBD_DILBWD", mode)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode] = t.grads.clone()
+        assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
+        if mode == "pair":
+            t.backward_on_device(x, y)
+            assert torch.equal(t.grads, grads[mode])                    # repeats bit for bit
+    monkeypatch.delenv("UBD_DILBWD", raising=False)
+    assert torch.equal(grads["pair8"], grads["split"])
+    a, b = grads["pair"].double(), grads["pair8"].double()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1e-5 * scale, float((a - b).abs().max()) / scale
+    # every layer but the dilation-16 one (and L3 .. L1 below it, which only see the bit-identical data gradient): identical
+    off = 0
+    for nm, shape in onet.weight_shapes(3, 0):
+        sz = int(np.prod(shape))
+        if not nm.startswith(layers):
+            assert torch.equal(grads["pair"][off:off + sz], grads["pair8"][off:off + sz]), nm
+        off += sz
+    assert off == grads["pair"].numel()
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

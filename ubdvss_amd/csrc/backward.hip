@@ -1082,8 +1082,12 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const void *X = acts[k];
             const int dd = UBD_DILATIONS[k];
             const int sw = (W4 + dd - 1) / dd, tw = sw <= 8 ? 8 : 16;              // narrow sub-grids: 8-wide tiles
-            const long items = (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH(tw) - 1) / W16_TH(tw)) * ((sw + tw - 1) / tw);
-            int gw = h->num_cus * (tw == 8 ? 3 : 2);                // 16 x 16 tiles: two blocks per CU (LDS, registers); 8-wide tiles: three; the same grid in the split mode (same order of the partial sums)
+            // sub-grids exactly 8 columns wide and at most 8 rows high (dilation 16 on 128 x 128 maps): two of them side by side in one 16-wide tile
+            // (bwd16.h PAIR; UBD_DILBWD=pair8 keeps the 8-wide form)
+            const bool pair = !h->split_dilbwd && !h->no_pair_dilbwd && tw == 8 && sw == 8 && (dd & 1) == 0 && W4 % dd == 0 && (H4 + dd - 1) / dd <= 8;
+            const long items = pair ? (long)n * dd * (dd / 2)
+                                    : (long)n * dd * dd * (((H4 + dd - 1) / dd + W16_TH(tw) - 1) / W16_TH(tw)) * ((sw + tw - 1) / tw);
+            int gw = h->num_cus * ((tw == 8 && !pair) ? 3 : 2);     // 16 x 16 tiles: two blocks per CU (LDS, registers); 8-wide tiles: three; the same grid in the split mode (same order of the partial sums)
             if (gw > items) gw = (int)items;
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             const rp_job prev = h->chain_reduce ? rp_take_prev(&rq) : rp_job{};   // the head's / the layer above's partial rows: totalled at the end of this kernel
@@ -1093,7 +1097,9 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             // switch) keeps the separate data-gradient kernel
             const unsigned *wt = frag16t + (size_t)k * UBD_DIL16_FRAG_U32;
             const bool fuse_dx = !h->split_dilbwd;                 // 8-wide tiles (dilation 16 on 128-wide maps) too since round 4: the fused form with M-split accumulators     // 8-wide tiles (dilation 16 on 128-wide maps): fused 75 us vs 38 + 33 us apart (two blocks per CU instead of three)
-            if (tw == 8 && fuse_dx)
+            if (pair)
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true, false, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
+            else if (tw == 8 && fuse_dx)
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
             else if (tw == 8)
                 hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev WG_STAMP_ARG);

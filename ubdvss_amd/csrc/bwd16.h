@@ -116,13 +116,20 @@ __global__ __launch_bounds__(256) void head_bwd1_16_kernel(const float *__restri
                                               // bookkeeping cost as much as one k-block of MFMAs); 8 x 8 sub-grids (dilation 16 on 128-wide maps) keep 8 rows
 // TW = 16 (default) or 8 (sub-grids at most 8 columns wide, i.e. dilation 16 on 128-wide maps: half of a 16-wide tile
 // would be padding).  k-block = 32 sub-pixels = 2 rows x 16 or 4 rows x 8.
-template <int TW, bool DX = false> struct w16_cfg {
-    static constexpr int XW = TW + 2;
-    static constexpr int XPIX = (W16_TH(TW) + 2) * XW;           // 324 / 100
+// PAIR (round 4; 16-wide tiles of the fused form only): sub-grids that are exactly 8 columns wide (dilation 16 on 128-wide maps) leave half
+// of a 16-wide tile empty, and the 8-wide form pays the per-item costs (barriers, DMA bookkeeping, decode) for 64 pixels.  A PAIR item
+// holds the sub-grids of phases (ry, rx) and (ry, rx + 1) side by side: tile columns 0-7 / 8-15, 8 rows; the staged images get ONE zero
+// column between the two (patch columns 0 | 1-8 | 9 | 10-17 | 18): the right neighbour of the first sub-grid's last column and the left
+// neighbour of the second one's first column are both outside their sub-grids -- 'same' padding.
+template <int TW, bool DX = false, bool PAIR = false> struct w16_cfg {
+    static_assert(!PAIR || (TW == 16 && DX), "paired sub-grids: the fused 16-wide form");
+    static constexpr int TH = PAIR ? 8 : W16_TH(TW);
+    static constexpr int XW = PAIR ? 19 : TW + 2;
+    static constexpr int XPIX = (TH + 2) * XW;                   // 324 / 100 / 190
     // DX (the data gradient of the same layer is computed from the same tiles, see dil_wgrad16_kernel): the G tile carries its
     // one-pixel halo too and has the X tile's geometry
     static constexpr int GW = DX ? XW : TW;                      // G tile row pitch in pixels
-    static constexpr int GPIX = DX ? XPIX : W16_TH(TW) * TW;     // 324 / 256 / 64
+    static constexpr int GPIX = DX ? XPIX : TH * TW;             // 324 / 256 / 64 / 190
     // DMA pieces (one wave-instruction = 64 chunks of 16 bytes): the X tile is padded to whole pieces so that a piece is
     // either X or G -- its tensor's descriptor then sits in scalar registers and the lanes add a 32-bit offset
     static constexpr int XR = (XPIX * 3 + 63) / 64, GR = (GPIX * 3 + 63) / 64;   // 16 + 12 (16 with halo) / 5 + 3 pieces
@@ -160,7 +167,7 @@ __device__ __forceinline__ unsigned wg_relu_mask2(unsigned g, unsigned m)
 // per CU).  Round 4, same-box A/Bs of the bf16 train step: M-split for the 16-wide form too, two tile buffers / two blocks: +13 us; one
 // tile buffer / three blocks (163 registers, 47 KB): +4 us -- the third wave does not pay for the extra transposed reads; but it makes
 // the FUSED 8-wide form (dilation 16: it lost to the two separate kernels at 252 registers, 75 us against 38 + 33) the faster one: -11 us.
-template <typename T, int TW, bool DX, bool MSPLIT = (TW == 8)>
+template <typename T, int TW, bool DX, bool MSPLIT = (TW == 8), bool PAIR = false>
 #define W16_OCC(TW, DX) (((TW) == 8) ? 3 : 2)
 __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d,
@@ -175,7 +182,8 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
 #else
 #define WGSTAMP(k) do {} while (0)
 #endif
-    using C = w16_cfg<TW, DX>;
+    using C = w16_cfg<TW, DX, PAIR>;
+    static_assert(!PAIR || !MSPLIT, "paired sub-grids: accumulators split by k-blocks");
     constexpr int TILES_BYTES = (!MSPLIT && 2 * C::BUF_BYTES < 28672) ? 28672 : 2 * C::BUF_BYTES;   // two tile buffers; the k-split block reduction needs 28 KiB
     constexpr int CONST_OFF = TILES_BYTES;                                    // [0,8): {1,0,0,0}   [8,32): zeros
     constexpr int WT_OFF = CONST_OFF + 64;                                    // DX: the layer's transposed fragments [7][2][64 lanes] x 16 B
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
     }
     // pixel of this lane inside a k-block (2 tile rows x 16 columns or 4 x 8): k = 8 grp + 4 j + qq, j = 0, 1
     const int krow = TW == 16 ? grp >> 1 : grp, kcol = TW == 16 ? 8 * (grp & 1) + qq : qq;
+    const int kcolp = kcol + (PAIR ? (kcol >> 3) : 0);             // column inside the staged images (PAIR: past the zero column)
 
     // DMA chunk -> (tile row, tile column, 16-byte part) of this lane, per piece of this wave (piece = 4 rd + wid: X pieces first, then
     // G pieces).  Kept as ONE register per piece: the chunk's byte offset relative to the tile's pixel (1, 1) -- ((sy - 1) d w + (sx - 1) d)
@@ -232,27 +241,36 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
             if constexpr (DX) { sy = gp / C::GW; sx = gp % C::GW; }         // with halo: the X tile's geometry
             else { sy = gp / TW + 1; sx = gp % TW + 1; }
         }
+        if constexpr (PAIR) {
+            // columns 1-8: sub-grid rx, 10-17: sub-grid rx + 1 (one pixel to the right in the map); 0, 9, 18: zeros.  The low bits hold "this chunk exists"
+            const bool real = sx != 0 && sx != 9 && sx != 18;
+            const int colrel = sx < 9 ? (sx - 1) * d : 1 + (sx - 10) * d;
+            const int rel16 = ((sy - 1) * d * w + colrel) * 3 + part;
+            relsx[rd] = (int)(((unsigned)rel16 << 5) | (real ? 1u : 0u));
+        } else {
         const int rel16 = ((sy - 1) * d * w + (sx - 1) * d) * 3 + part;     // offset / 16
         relsx[rd] = (int)(((unsigned)rel16 << 5) | (unsigned)sx);
+        }
     }
 
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
-    const int tiles_y = (sh + W16_TH(TW) - 1) / W16_TH(TW), tiles_x = (sw + TW - 1) / TW;
-    const int items = n * d * d * tiles_y * tiles_x;
+    const int tiles_y = PAIR ? 1 : (sh + C::TH - 1) / C::TH, tiles_x = PAIR ? 1 : (sw + TW - 1) / TW;
+    const int dxp = PAIR ? d >> 1 : d;                                   // column phases per item row (PAIR: two per item; d is even)
+    const int items = n * d * dxp * tiles_y * tiles_x;
     struct item_t { int img, ry, rx, sy0, sx0; };
     // item index -> (image, phase, tile) with magic-number divisions (wave-uniform: s_mul_hi; exact while it * divisor < 2^32)
     auto magic = [](unsigned dv) { return dv == 1u ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
-    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d);
+    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d), m_dx = magic((unsigned)dxp);
     auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {
         item_t r;
         unsigned a = (unsigned)it, b;
         b = divm(a, (unsigned)tiles_x, m_tx); const int tx = (int)(a - b * (unsigned)tiles_x); a = b;
         b = divm(a, (unsigned)tiles_y, m_ty); const int ty = (int)(a - b * (unsigned)tiles_y); a = b;
-        b = divm(a, (unsigned)d, m_d); r.rx = (int)(a - b * (unsigned)d); a = b;
+        b = divm(a, (unsigned)dxp, m_dx); r.rx = (int)(a - b * (unsigned)dxp) * (PAIR ? 2 : 1); a = b;
         b = divm(a, (unsigned)d, m_d); r.ry = (int)(a - b * (unsigned)d);
         r.img = (int)b;
-        r.sy0 = ty * W16_TH(TW); r.sx0 = tx * TW;
+        r.sy0 = ty * C::TH; r.sx0 = tx * TW;
         return r;
     };
     const unsigned lds_smem = ubd_lds_addr(smem);
@@ -276,7 +294,9 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
             const int piece = rd * 4 + wid;
             if (piece >= C::XR + C::GR) break;                        // wave-uniform
             const int v = relsx[rd];
-            const unsigned off = (unsigned)((v & 31) - sx_lo) <= (unsigned)sx_span ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;
+            unsigned off;
+            if constexpr (PAIR) off = (v & 1) ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;      // both sub-grids are exactly 8 columns wide (host)
+            else off = (unsigned)((v & 31) - sx_lo) <= (unsigned)sx_span ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;
             ubd_blds16(piece < C::XR ? rx : rg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
@@ -303,12 +323,12 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * C::BUF_BYTES); }
         WGSTAMP(3);
-        const int rows_eff = min(W16_TH(TW), sh - I.sy0);
+        const int rows_eff = min(C::TH, sh - I.sy0);
 #pragma unroll 1
         for (int kb = MSPLIT ? 0 : wid; C::KROWS * kb < rows_eff; kb += MSPLIT ? 1 : 4) {   // wave-uniform: k-blocks whose tile rows hold real sub-pixels
             const int py = C::KROWS * kb + krow;
-            const char *xb = buf + (py * C::XW + kcol) * (UBD_C * 2);
-            const char *gb = buf + C::GOFF + ((py + (DX ? 1 : 0)) * C::GW + kcol + (DX ? 1 : 0)) * (UBD_C * 2);
+            const char *xb = buf + (py * C::XW + kcolp) * (UBD_C * 2);
+            const char *gb = buf + C::GOFF + ((py + (DX ? 1 : 0)) * C::GW + kcolp + (DX ? 1 : 0)) * (UBD_C * 2);
             // B operand: segments of the two N tiles (co 0..15, 16..23 + zero padding)
             u32x4 b[2];
             {
@@ -350,12 +370,13 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
                 // one MFMA column tile = 16 pixels = one tile row of a 16-wide tile, two rows of an 8-wide one
                 constexpr int RSTEP = 16 / TW;
                 const int prow = TW == 16 ? 0 : i16 >> 3, pcol = TW == 16 ? i16 : i16 & 7;
+                const int pcolp = pcol + (PAIR ? (pcol >> 3) : 0);   // column inside the staged images
 #pragma unroll 1
                 for (int rr = 0; rr < C::KROWS; rr += RSTEP) {
                     const int r0 = C::KROWS * kb + rr;
                     if (r0 >= rows_eff) break;                                // wave-uniform
                     const int r = r0 + prow;
-                    const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + pcol + 1) * (UBD_C * 2);
+                    const char *gpix = buf + C::GOFF + ((r + 1) * C::GW + pcolp + 1) * (UBD_C * 2);
                     u32x4 a[7];
 #pragma unroll
                     for (int c = 0; c < 7; ++c) a[c] = *(const u32x4 *)(doff[c] > -(1 << 19) ? gpix + doff[c] : zero16);
@@ -366,12 +387,12 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
                         acc1 = mfma16<T>(wr1[c], a[c], acc1);
                     }
                     // ReLU mask = the saved activation X of this pixel (centre of the X tile), same channels as the result rows
-                    const char *xpix = buf + ((r + 1) * C::XW + pcol + 1) * (UBD_C * 2);
+                    const char *xpix = buf + ((r + 1) * C::XW + pcolp + 1) * (UBD_C * 2);
                     const u32x2 m0 = *(const u32x2 *)(xpix + 8 * grp);
                     const u32x2 m1 = *(const u32x2 *)(xpix + (grp < 2 ? 32 + 8 * grp : 0));
                     const u32x2 o0 = {wg_relu_mask2(wg_pack2<T>(acc0[0], acc0[1]), m0[0]), wg_relu_mask2(wg_pack2<T>(acc0[2], acc0[3]), m0[1])};
                     const u32x2 o1 = {wg_relu_mask2(wg_pack2<T>(acc1[0], acc1[1]), m1[0]), wg_relu_mask2(wg_pack2<T>(acc1[2], acc1[3]), m1[1])};
-                    const int gy = I.ry + (I.sy0 + r) * d, gx = I.rx + (I.sx0 + pcol) * d;
+                    const int gy = I.ry + (I.sy0 + r) * d, gx = PAIR ? I.rx + (pcol >> 3) + (pcol & 7) * d : I.rx + (I.sx0 + pcol) * d;
                     const unsigned off = (gx < w && gy < h) ? (unsigned)((gy * w + gx) * (UBD_C * 2)) + 8u * grp : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b64(o0, rout, (int)off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(grp < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4 grp + r exist for grp < 2
