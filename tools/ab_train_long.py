@@ -1,0 +1,29 @@
+"""Steady-state A/B of the bf16 train step: every build under tools/_ab/ named on the command line runs BLOCKS x 200 steps in its own process (interleaved, two rounds)."""
+import os, sys, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import numpy as np, torch
+    sys.path.insert(0, ROOT)
+    from ubdvss_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "_ab", sys.argv[2])
+    from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
+    torch.cuda.set_device(0)
+    m = Model(NetConfig(grey=False), dtype="bfloat16", seed=1)
+    tr = Trainer(m, Adam())
+    lab = synthetic.rectangle_maps(30, 64, 128, 128)
+    x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(lab).cuda()
+    for _ in range(50): tr.train_step_on_device(x, y)
+    out = []
+    for blk in range(int(os.environ.get("BLOCKS", "12"))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200): tr.train_step_on_device(x, y)
+        e1.record(); torch.cuda.synchronize()
+        out.append(round(e0.elapsed_time(e1) / 200, 4))
+    print(json.dumps(out))
+else:
+    for rep in range(2):
+        for lib in sys.argv[1:]:
+            r = subprocess.run([sys.executable, __file__, "child", lib], capture_output=True, text=True)
+            print(lib, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
     const int items = n * d * dxp * tiles_y * tiles_x;
     struct item_t { int img, ry, rx, sy0, sx0; };
     // item index -> (image, phase, tile) with magic-number divisions (wave-uniform: s_mul_hi; exact while it * divisor < 2^32)
-    auto magic = [](unsigned dv) { return dv == 1u ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv) in 32 bits (the 64-bit form was three ~150-instruction division loops in the prologue)
     const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d), m_dx = magic((unsigned)dxp);
     auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {

@@ -692,11 +692,16 @@ __global__ __launch_bounds__(256, XB == 1 ? 4 : 3) void sep12_16_kernel(const vo
 
 #include "sep123_16.h"
 #ifdef UBD_STAMPS
+static unsigned long long *g_d16s_stamps = nullptr;
+static int g_d16s_stamps_d = 0;
+extern "C" void ubd_debug_set_stamps_d16s(void *p, int d) { g_d16s_stamps = (unsigned long long *)p; g_d16s_stamps_d = d; }
+#define D16S_STAMP_ARG , (d == g_d16s_stamps_d ? g_d16s_stamps : nullptr)
 static unsigned long long *g_s123_stamps = nullptr;
 extern "C" void ubd_debug_set_stamps_s123(void *p) { g_s123_stamps = (unsigned long long *)p; }
 #define S123_16_STAMP_ARG , g_s123_stamps
 #else
 #define S123_16_STAMP_ARG
+#define D16S_STAMP_ARG
 #endif
 
 // ------------------------------------------------------------------------------------ dilated layers
@@ -852,8 +857,21 @@ template <typename T, int EPI = 0>
 #endif
 __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                             const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
-                                                            int w, int d, const float *__restrict__ head, float *__restrict__ logits)
+                                                            int w, int d, const float *__restrict__ head, float *__restrict__ logits
+#ifdef UBD_STAMPS
+                                                            , unsigned long long *__restrict__ stamps
+#endif
+                                                            )
 {
+#ifdef UBD_STAMPS   // diagnostic build only: s_memtime of lane 0 of every wave at the phase boundaries of its first 8 items (tools/stamps_d16s.py)
+#define D16STAMP(k) do { if (stamps && iter < 8 && (threadIdx.x & 63) == 0 && blockIdx.x < 768) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + iter) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // block time line: [5] entry, [6] in front of the item loop, [7] behind it (s_memtime), [5..7] of item slot 1: the same three points on the 100-MHz clock all CUs share
+#define D16BLK(k) do { if (stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 768) { const size_t b_ = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 * 8; stamps[b_ + (k)] = __builtin_amdgcn_s_memtime(); stamps[b_ + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define D16STAMP(k) do {} while (0)
+#define D16BLK(k) do {} while (0)
+#endif
+    D16BLK(5);
     // EPI 0: y = relu(conv + bias).  EPI 2 / 3 (last hidden layer with ONE output channel, round 4: the staged kernel takes L9 too): the
     // 1 x 1 head (24 fp32 weights + bias at `head`, net.py:308-311) is applied in the epilogue, fp32 logits to `logits`; EPI 2 (inference)
     // does not store the activation, EPI 3 (train step) does.  Same expressions as dilconv16_kernel<T, 2 / 3>: bit-identical logits.
@@ -893,7 +911,7 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
     const int tiles_y = (sh + 15) >> 4, tiles_x = (sw + 15) >> 4;
     const int items = n * d * d * tiles_y * tiles_x;
     struct item_t { int img, ry, rx, sy0, sx0; };
-    auto magic = [](unsigned dv) { return dv == 1u ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv) in 32 bits (the 64-bit form was three ~150-instruction division loops in the prologue)
     const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d);
     auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {
@@ -930,16 +948,21 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
     item_t I = decode(it < it_end ? it : it_begin);
     if (it < it_end) dma_item(I, 0);
     const char *zero16 = smem + 2 * D16S_BUF;
+    D16BLK(6);
     for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         const char *buf = smem + (iter & 1) * D16S_BUF;
         // this item's tile has landed; the eight output stores of the previous item (younger than its DMA) stay in flight
         // (per row: two activation stores, EPI 2 / 3 one logit store)
         constexpr int NST = 4 * (EPI == 2 ? 1 : (EPI == 3 ? 3 : 2));
+        D16STAMP(0);
         if (iter > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        D16STAMP(1);
         __syncthreads();                              // ... for every wave; everyone left the other buffer
+        D16STAMP(2);
         item_t Inext = I;
         if (it + nblk_x < it_end) { Inext = decode(it + nblk_x); dma_item(Inext, ((iter + 1) & 1) * D16S_BUF); }
+        D16STAMP(3);
         __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)y + (size_t)I.img * h * w * (UBD_C * 2)), 0, (int)img_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rlog = __builtin_amdgcn_make_buffer_rsrc((void *)((EPI == 2 || EPI == 3) ? (char *)(logits + (size_t)I.img * h * w) : (char *)y), 0, (int)((unsigned)h * (unsigned)w * 4u), 0x00020000);
 #pragma unroll D16S_UNROLL
@@ -977,8 +1000,12 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
             __builtin_amdgcn_raw_buffer_store_b64(o1, rout, (int)(q < 2 ? off + 32u : 0x80000000u), 0, 0);   // channels 16 + 4q + r exist for q < 2
             }
         }
+        D16STAMP(4);
         I = Inext;
     }
+    D16BLK(7);
+#undef D16STAMP
+#undef D16BLK
 }
 
 // ------------------------------------------------------------------------------------ head
@@ -1134,13 +1161,13 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
         g2 = (g2 + 7) / 8 * 8;                                     // the item ranges are cut per XCD: all eight need a block
         if (epi == 0)
             hipLaunchKernelGGL((dilconv16s_kernel<T, 0>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)nullptr, (float *)nullptr);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)nullptr, (float *)nullptr D16S_STAMP_ARG);
         else if (epi == 2)      // out = fp32 logits, mask = fp32 head: the activation is not stored
             hipLaunchKernelGGL((dilconv16s_kernel<T, 2>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)nullptr,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, (float *)out);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, (float *)out D16S_STAMP_ARG);
         else                    // out = activation, logits3 = fp32 logits
             hipLaunchKernelGGL((dilconv16s_kernel<T, 3>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, logits3);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, logits3 D16S_STAMP_ARG);
     } else if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
