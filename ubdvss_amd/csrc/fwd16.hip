@@ -845,6 +845,18 @@ __global__ __launch_bounds__(256) void dilconv16_kernel(const unsigned short *__
 // ds_read_b128 (A fragments at the tap offsets, constant per lane) + 14 MFMAs + the epilogue.  The direct kernel above spends
 // 159 instructions per 16 pixels (PMC: waves wait for an issue slot half of their time), 28 of them on per-load column checks
 // and most of the scalar ones on per-tile bookkeeping; here the bookkeeping is per 256 pixels.  EPI 0 (bias + ReLU) only.
+// geometry of a launch, worked out once on the host: five 32-bit divisions (~40 scalar instructions each) less in every block's prologue
+struct d16s_geom { int tiles_x, tiles_y, items; unsigned m_tx, m_ty, m_d; };
+static d16s_geom d16s_geometry(int n, int h, int w, int d)
+{
+    d16s_geom g;
+    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
+    g.tiles_y = (sh + 15) >> 4; g.tiles_x = (sw + 15) >> 4;
+    g.items = n * d * d * g.tiles_y * g.tiles_x;
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv): floor(a / dv) = umulhi(a, m) while a * dv < 2^32
+    g.m_tx = magic((unsigned)g.tiles_x); g.m_ty = magic((unsigned)g.tiles_y); g.m_d = magic((unsigned)d);
+    return g;
+}
 #define D16S_PIX (18 * 18)
 #define D16S_PIECES ((D16S_PIX * 3 + 63) / 64)               // 16 pieces of 1 KiB (the last one runs past the tile)
 #define D16S_BUF (D16S_PIECES * 1024)
@@ -857,7 +869,7 @@ template <typename T, int EPI = 0>
 #endif
 __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigned short *__restrict__ x, unsigned short *__restrict__ y,
                                                             const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, int n, int h,
-                                                            int w, int d, const float *__restrict__ head, float *__restrict__ logits
+                                                            int w, int d, const float *__restrict__ head, float *__restrict__ logits, const d16s_geom geo
 #ifdef UBD_STAMPS
                                                             , unsigned long long *__restrict__ stamps
 #endif
@@ -907,12 +919,9 @@ __global__ __launch_bounds__(256, D16S_OCC) void dilconv16s_kernel(const unsigne
         const int pix = c / 3, sy = pix / 18;
         cinfo[rd] = sy | ((pix - sy * 18) << 8) | ((c - pix * 3) << 16);
     }
-    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
-    const int tiles_y = (sh + 15) >> 4, tiles_x = (sw + 15) >> 4;
-    const int items = n * d * d * tiles_y * tiles_x;
+    const int tiles_y = geo.tiles_y, tiles_x = geo.tiles_x, items = geo.items;     // from the host (d16s_geometry; in the kernel they were 64-bit division loops first, then five 32-bit divisions)
     struct item_t { int img, ry, rx, sy0, sx0; };
-    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv) in 32 bits (the 64-bit form was three ~150-instruction division loops in the prologue)
-    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d);
+    const unsigned m_tx = geo.m_tx, m_ty = geo.m_ty, m_d = geo.m_d;
     auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {
         item_t r;
@@ -1157,17 +1166,18 @@ static void launch_dil16(const ubd_handle *h, int epi, const unsigned *frag, con
     if ((epi == 0 || epi == 2 || epi == 3) && sw > 8 && !h->direct_dil16) {
         const long items = (long)n * d * d * ((sh + 15) / 16) * ((sw + 15) / 16);
         int g2 = h->num_cus * D16S_OCC;
+        const d16s_geom geo = d16s_geometry(n, H4, W4, d);
         if (g2 > items) g2 = (int)items;
         g2 = (g2 + 7) / 8 * 8;                                     // the item ranges are cut per XCD: all eight need a block
         if (epi == 0)
             hipLaunchKernelGGL((dilconv16s_kernel<T, 0>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)nullptr, (float *)nullptr D16S_STAMP_ARG);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)nullptr, (float *)nullptr, geo D16S_STAMP_ARG);
         else if (epi == 2)      // out = fp32 logits, mask = fp32 head: the activation is not stored
             hipLaunchKernelGGL((dilconv16s_kernel<T, 2>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)nullptr,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, (float *)out D16S_STAMP_ARG);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, (float *)out, geo D16S_STAMP_ARG);
         else                    // out = activation, logits3 = fp32 logits
             hipLaunchKernelGGL((dilconv16s_kernel<T, 3>), dim3(g2), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
-                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, logits3 D16S_STAMP_ARG);
+                               (const u32x4 *)frag, bias, n, H4, W4, d, (const float *)mask, logits3, geo D16S_STAMP_ARG);
     } else if (epi == 0)
         hipLaunchKernelGGL((dilconv16_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)out,
                            (const u32x4 *)frag, bias, (const unsigned short *)nullptr, n, H4, W4, d, mg_tx, mg_h, (float *)nullptr);
