@@ -140,29 +140,6 @@ __device__ __forceinline__ bool loss_publish_and_total(loss_part *__restrict__ p
     return true;
 }
 
-// One count into an LDS histogram for every lane with `on` set.  The first-level bins are coarse (sign, exponent, two mantissa bits) and the
-// values are not spread: every positive pixel counts as exactly 0, and the negatives of a batch sit within a factor of two of each other, so
-// most lanes of a wave hit the same one or two words -- which the LDS adds one lane after the other.  Two rounds of "the first lane's bin,
-// counted once for all lanes that share it" (a ballot and ONE atomic) take those out; what is left goes lane by lane.
-#ifndef LOSS_HIST_PEEL
-#define LOSS_HIST_PEEL 2
-#endif
-__device__ __forceinline__ void loss_hist_add(unsigned *s_hist, unsigned bin, bool on)
-{
-    unsigned long long todo = __ballot(on);
-#pragma unroll
-    for (int round = 0; round < LOSS_HIST_PEEL; ++round) {
-        if (todo == 0) break;                                    // wave-uniform
-        const int src = __builtin_ctzll(todo);
-        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, src);
-        const unsigned long long same = __ballot(on && bin == b);
-        if ((int)(threadIdx.x & 63) == src) atomicAdd(&s_hist[b], (unsigned)__popcll(same));
-        todo &= ~same;
-        on = on && bin != b;
-    }
-    if (on) atomicAdd(&s_hist[bin], 1u);
-}
-
 // ---- pass 1: per-pixel BCE, batch sums, first-level histogram ------------------------------
 // 1024 threads per block: with one block per CU (LOSS_MAX_BLOCKS) that is four waves per SIMD to hide the load -> exp/log ->
 // LDS-atomic chain of a pixel, at the same number of block-level global atomics
@@ -193,7 +170,7 @@ __global__ __launch_bounds__(LOSS_STATS_BLOCK) void loss_stats_kernel(const floa
         sp += (double)(ce * z);
         sn += (double)cn;
         np += (z > 0.f);
-        loss_hist_add(s_hist, __float_as_uint(cn) >> 21, true);
+        atomicAdd(&s_hist[__float_as_uint(cn) >> 21], 1u);
     };
     long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; p + 3 * stride < npix; p += 4 * stride) {
