@@ -208,16 +208,22 @@ __device__ __forceinline__ loss_sel loss_select_block(loss_hdr *hdr, const unsig
     const int nbins = level == 2 ? 1024 : 2048;
     const int per = nbins / 256;
     // thread t sums bins [nbins - (t+1)*per, nbins - t*per)  (descending order); inclusive prefix over the 256 segment
-    // sums (Hillis-Steele in LDS); the one thread whose segment holds the k_rem-th largest element finishes the scan
+    // sums; the one thread whose segment holds the k_rem-th largest element finishes the scan
     unsigned mine = 0;
     for (int j = 0; j < per; ++j) mine += hist[nbins - 1 - (threadIdx.x * per + j)];
-    s_part[threadIdx.x] = mine;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const unsigned v = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0u;
+    // inclusive prefix over the 256 threads: shuffles inside a wave, the four wave totals through LDS -- ONE barrier (the Hillis-Steele form in LDS
+    // took sixteen: ~2 us at the head of each of the three kernels that start with this scan)
+    unsigned incl_w = mine;
+    {
+        const int ln = threadIdx.x & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl_w, o, 64);
+            if (ln >= o) incl_w += v;
+        }
+        if (ln == 63) s_part[threadIdx.x >> 6] = incl_w;
         __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+        for (int w2 = 0; w2 < (int)(threadIdx.x >> 6); ++w2) incl_w += s_part[w2];
     }
     unsigned k_rem, k, prev_prefix = 0;
     if (level == 0) {
@@ -231,7 +237,7 @@ __device__ __forceinline__ loss_sel loss_select_block(loss_hdr *hdr, const unsig
         k_rem = hdr->k_rem_l[level - 1];
         prev_prefix = hdr->prefix_l[level - 1];
     }
-    const unsigned incl = s_part[threadIdx.x], excl = incl - mine;
+    const unsigned incl = incl_w, excl = incl - mine;
     // k_rem <= total count holds by construction (k <= number of masked negatives incl. zeros); the last segment takes
     // any remainder like the serial scan did
     const bool winner = (excl < k_rem && k_rem <= incl) || (threadIdx.x == 255 && incl < k_rem);
