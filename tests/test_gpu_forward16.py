@@ -246,6 +246,31 @@ def test_bf16_dilated_backward_fused_equals_split(monkeypatch, n, hh, ww):
     assert torch.equal(grads["fused"], grads["split"])
 
 
+@pytest.mark.parametrize("n,hh,ww,ncls", [(2, 256, 256, 8), (3, 72, 104, 3), (1, 40, 36, 1), (2, 64, 96, 31)])
+def test_bf16_head_backward_with_classes_in_one_pass_equals_the_two_kernels(monkeypatch, n, hh, ww, ncls):
+    """bf16 train step with classes: the head's data gradient G9 is written by the head's weight-gradient kernel from the tile it stages anyway
+    (backward.hip head_wgrad_kernel<TX, true>) instead of by a second pass over A9 (UBD_HEADBWD=split).  Same expression, same order: loss and
+    every gradient bit-identical, up to the 31 classes the ABI allows, on ragged maps too."""
+    from ubdvss_amd import Trainer, Adam
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)], grey=False)
+    labels = synthetic.rectangle_maps(55, n, hh // 4, ww // 4, n_classes=ncls)
+    x = torch.from_numpy(synthetic.textured_images(56, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+    y = torch.from_numpy(labels).cuda()
+    grads, loss = {}, {}
+    for mode in ("one", "split"):
+        if mode == "split":
+            monkeypatch.setenv("UBD_HEADBWD", "split")
+        else:
+            monkeypatch.delenv("UBD_HEADBWD", raising=False)
+        t = Trainer(Model(cfg, dtype="bfloat16", seed=9), Adam())
+        t.backward_on_device(x, y)
+        grads[mode], loss[mode] = t.grads.clone(), t.loss.clone()
+        assert torch.isfinite(grads[mode]).all() and float(grads[mode].abs().max()) > 0
+    monkeypatch.delenv("UBD_HEADBWD", raising=False)
+    assert torch.equal(loss["one"], loss["split"])
+    assert torch.equal(grads["one"], grads["split"]), float((grads["one"] - grads["split"]).abs().max())
+
+
 @pytest.mark.parametrize("n,hh,ww,layers", [(2, 512, 512, ("l8",)), (1, 64, 512, ("l8",)), (3, 260, 512, ("l8",)), (1, 36, 512, ("l8",)), (2, 256, 256, ("l7",)),
                                                (2, 128, 128, ("l6",))])
 def test_bf16_dilated_backward_paired_subgrids_equal_the_8_wide_tiles(monkeypatch, n, hh, ww, layers):

@@ -58,6 +58,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         h->pp_global = getenv("UBD_PP_GLOBAL") != nullptr; h->pp_split = getenv("UBD_PP_SPLIT") != nullptr;
         h->pp_poison = getenv("UBD_PP_POISON") != nullptr; h->pp_serial_tail = getenv("UBD_PP_SERIAL_TAIL") != nullptr;
         h->pp_threads_512 = getenv("UBD_PP_THREADS_512") != nullptr;
+        { const char *b = getenv("UBD_HEADBWD"); h->split_headbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_SEPB16_X"); h->sepb_x_regs = (b && strcmp(b, "regs") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_REDUCE"); h->chain_reduce = (b && strcmp(b, "batched") == 0) ? 0 : 1; }
         { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }

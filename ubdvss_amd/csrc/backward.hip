@@ -228,10 +228,18 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float *__restrict__ 
 // Wave w multiplies pixels 16 w .. 16 w + 15 of every tile.
 #define HW_TILE 64
 #define HW_STRIDE 48
-template <typename TX>
+// DXOUT (bf16 train step with classes, round 4): the head's DATA gradient G9 = (dlogits . hk^T) * (A9 > 0), rounded to TX, leaves from the same staged
+// tile -- head_dx16_kernel read the 48 bytes per pixel of A9 a second time (22.5 + 23.7 us at 64 images and 8 classes).  Same expression in the
+// same order as head_dx16_kernel (fmaf chain over the output channels k = 0, 1, ..): bit-identical G9.
+template <typename TX, bool DXOUT = false>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict__ a9, const float *__restrict__ dlogits,
-                                                         float *__restrict__ partials, long npix, int k_out)
+                                                         float *__restrict__ partials, long npix, int k_out,
+                                                         const float *__restrict__ hk = nullptr, unsigned short *__restrict__ gout = nullptr)
 {
+    static_assert(!DXOUT || sizeof(TX) == 2, "the 16-bit gradient tensor");
+    __shared__ __attribute__((aligned(16))) float s_kT[DXOUT ? (UBD_MAX_CLASSES + 1) * UBD_C : 4];   // head kernel transposed: [k][c]
+    if constexpr (DXOUT)
+        for (int t = threadIdx.x; t < UBD_C * k_out; t += 256) { const int c = t / k_out, k = t - c * k_out; s_kT[k * UBD_C + c] = hk[t]; }   // visible after the first barrier of the tile loop
     __shared__ __attribute__((aligned(16))) float sA[HW_TILE * HW_STRIDE];      // [px][c (24) | 1 | zeros]
     __shared__ __attribute__((aligned(16))) float sB[HW_TILE * (UBD_MAX_CLASSES + 1) + 32];   // flat copy of the tile's dlogits: [px][k_out]; columns k >= k_out
                                                                                             // of the B operand read the next pixel's values and are dropped at the end
@@ -296,6 +304,30 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const void *__restrict_
             for (int px = threadIdx.x; px < HW_TILE; px += 256) sA[px * HW_STRIDE + UBD_C] = (p0 + px < npix) ? 1.f : 0.f;
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if constexpr (DXOUT) {
+            // one 16-byte chunk (8 channels of a pixel) per thread: 192 of the 256 threads; the pixel's d logits come from sB (broadcast reads),
+            // the weights of the eight channels as two ds_read_b128 per output channel, the ReLU mask from the staged activation (fp32 copy: > 0)
+            if (threadIdx.x < HW_TILE * 3) {
+                const int px = (int)threadIdx.x / 3, c8 = (int)threadIdx.x - 3 * px;
+                float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < k_out; ++k) {
+                    const float dl = sB[px * k_out + k];
+                    const f32x4 w0 = *(const f32x4 *)&s_kT[k * UBD_C + c8 * 8], w1 = *(const f32x4 *)&s_kT[k * UBD_C + c8 * 8 + 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { g8[e] = fmaf(dl, w0[e], g8[e]); g8[4 + e] = fmaf(dl, w1[e], g8[4 + e]); }
+                }
+                const f32x4 a0 = *(const f32x4 *)&sA[px * HW_STRIDE + c8 * 8], a1 = *(const f32x4 *)&sA[px * HW_STRIDE + c8 * 8 + 4];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float alo = e < 2 ? a0[2 * e] : a1[2 * e - 4], ahi = e < 2 ? a0[2 * e + 1] : a1[2 * e - 3];
+                    const unsigned lo = alo > 0.f ? (unsigned)__builtin_bit_cast(unsigned short, (TX)g8[2 * e]) : 0u;
+                    const unsigned hi = ahi > 0.f ? (unsigned)__builtin_bit_cast(unsigned short, (TX)g8[2 * e + 1]) : 0u;
+                    o[e] = lo | (hi << 16);
+                }
+                if (p0 + px < npix) ((u32x4 *)gout)[(p0 + px) * 3 + c8] = o;
+            }
+        }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int px = 16 * wid + 4 * s4 + kq;
@@ -999,7 +1031,21 @@ static int launch_head_wgrad(const ubd_handle *h, const void *a9, const float *d
     const int cols = (UBD_C + 1) * h->k_out;
     float *partials = rp_add(rq, g2, cols, grads + h->off_head_k, UBD_C * h->k_out, grads + h->off_head_b, h->k_out, nullptr, st);
     if (!partials) return -1;
-    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out);
+    hipLaunchKernelGGL((head_wgrad_kernel<TX>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out, (const float *)nullptr, (unsigned short *)nullptr);
+    return 0;
+}
+// bf16 train step with classes: weight gradient AND data gradient of the head in one pass over A9 (head_wgrad_kernel<TX, true>)
+template <typename TX>
+static int launch_head_bwd16(const ubd_handle *h, const void *a9, const float *dlogits, const float *hk, unsigned short *g, float *grads, rp_queue *rq,
+                             long npix, hipStream_t st)
+{
+    long g2l = (npix + HW_TILE - 1) / HW_TILE;
+    if (g2l > h->num_cus * 4) g2l = h->num_cus * 4;
+    const int g2 = (int)g2l;
+    const int cols = (UBD_C + 1) * h->k_out;
+    float *partials = rp_add(rq, g2, cols, grads + h->off_head_k, UBD_C * h->k_out, grads + h->off_head_b, h->k_out, nullptr, st);
+    if (!partials) return -1;
+    hipLaunchKernelGGL((head_wgrad_kernel<TX, true>), dim3(g2), dim3(256), 0, st, a9, dlogits, partials, npix, h->k_out, hk, g);
     return 0;
 }
 
@@ -1074,9 +1120,11 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             float *partials = rp_add(&rq, g1, UBD_C + 1, grads + h->off_head_k, UBD_C, grads + h->off_head_b, 1, nullptr, st);
             if (!partials) return -1;
             hipLaunchKernelGGL((head_bwd1_16_kernel<TX>), dim3(g1), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], partials, npix);
-        } else {
+        } else if (h->split_headbwd) {                        // UBD_HEADBWD=split: the two kernels (diagnostics / tests)
             hipLaunchKernelGGL((head_dx16_kernel<TX>), dim3(grid), dim3(256), 0, st, dlogits, (const unsigned short *)acts[6], params + h->off_head_k, g16[0], npix, h->k_out);
             if (launch_head_wgrad<TX>(h, acts[6], dlogits, grads, &rq, npix, st)) return -1;
+        } else {
+            if (launch_head_bwd16<TX>(h, acts[6], dlogits, params + h->off_head_k, g16[0], grads, &rq, npix, st)) return -1;
         }
         for (int k = UBD_NUM_DIL - 1; k >= 0; --k) {
             const void *X = acts[k];

@@ -22,6 +22,7 @@ struct ubd_handle {
     int num_cus;
     int pp_lds_attr_set;      // pp_front_lds_kernel's dynamic-LDS limit has been raised on this handle's device
     int fuse_force;           // UBD_STEM named a fused variant explicitly: use it at any launch size
+    int split_headbwd;        // UBD_HEADBWD=split: bf16 train step with classes: head data gradient and head weight gradient as two kernels (diagnostics / tests)
     int no_pair_dilbwd;       // UBD_DILBWD=pair8: narrow sub-grids (dilation 16 on 128-wide maps) keep the 8-wide tiles instead of pairs in 16-wide ones (diagnostics / tests)
     int split_dilbwd;         // UBD_DILBWD=split: bf16 dilated backward as two kernels per layer (diagnostics / tests)
     int split_stem16;         // UBD_STEM16=split: 16-bit pass with separate L1 and L2 kernels (diagnostics / tests)
