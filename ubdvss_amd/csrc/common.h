@@ -104,6 +104,29 @@ __device__ __forceinline__ void ubd_glds16(const void *gsrc, const void *lds_gen
 // and were spending 75 of the 93 scalar instructions per 16-pixel row tile on them (PMC).  Division by the
 // launch constant d is n * m >> 32 with m = floor((2^32 - 1) / d) + 1, exact while n * d < 2^32 (checked once; tile
 // counts are < 2^24 and tiles_x, tiles_y < 2^8 for every supported shape) -- otherwise the real division is used.
+// floor(n / D) for 0 <= n < NMAX as (n * m) >> sh with n * m < 2^24 (one v_mul_u32_u24 + one shift); checked at compile time
+template <int D, int NMAX> struct ubd_magic24 {
+    static constexpr int find_sh()
+    {
+        for (int sh = 8; sh < 24; ++sh) {
+            const long m = (1L << sh) / D + 1;
+            if (m * NMAX >= (1L << 24)) continue;
+            bool ok = true;
+            for (long n = 0; n < NMAX && ok; ++n) ok = ((n * m) >> sh) == n / D;
+            if (ok) return sh;
+        }
+        return -1;
+    }
+    static constexpr int sh = find_sh();
+    static_assert(sh > 0, "no 24-bit magic number for this divisor / range");
+    static constexpr unsigned m = (1u << sh) / D + 1;
+};
+
+// v_mul_lo_u32 / v_mul_hi_u32 / v_mad_u64_u32 issue at a QUARTER of the rate of the 24-bit multiplies (16 cycles per wave instead of 4): index arithmetic
+// whose operands provably fit 24 bits says so (hipcc cannot know the ranges and takes the 32-bit forms -- four of them per 16-pixel unit in the L1 loop of
+// the 16-bit stem, ~15 % of that loop's issue cycles; round 4)
+__device__ __forceinline__ int ubd_mul24(int a, int b) { return __mul24(a, b); }
+template <int D, int NMAX> __device__ __forceinline__ int ubd_div24(int n) { return (int)(__umul24((unsigned)n, ubd_magic24<D, NMAX>::m) >> ubd_magic24<D, NMAX>::sh); }
 struct ubd_tile_decoder {
     unsigned tiles_x, tiles_y, mx, my, total;
     bool fast;

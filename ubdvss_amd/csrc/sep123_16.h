@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
             const int pr = c / C::RC, gf = if0 + 4 * (c - pr * C::RC);
             // rows above / below the image fall out of the descriptor's range by themselves (a negative offset wraps); chunks left / right
             // of it get an out-of-range offset: zeros in LDS.  Only the lanes that have a chunk write (16 bytes at dst + 16 * lane).
-            const unsigned off = (unsigned)gf < (unsigned)WC ? (unsigned)(((iy0 + pr) * WC + gf) * 4) : 0x80000000u;
+            const unsigned off = (unsigned)gf < (unsigned)WC ? (unsigned)((ubd_mul24(iy0 + pr, WC) + gf) * 4) : 0x80000000u;
             if (k < C::ROUNDS - 1 || c < C::CHUNKS) ubd_blds16(rsrc, off, dst + (unsigned)(k * 4096));
         }
     };
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
             c = c < C::CHUNKS ? c : C::CHUNKS - 1;
             const int pr = c / C::RC, pf = 4 * (c - pr * C::RC);
             const int gy = min(max(iy0 + pr, 0), H - 1), gf = min(max(if0 + pf, 0), WC - 4);
-            const unsigned off = (unsigned)(gy * WC + gf);
+            const unsigned off = (unsigned)(ubd_mul24(gy, WC) + gf);
             if constexpr (IN_MODE == 1) st[k][0] = *(const unsigned *)(img8 + off);
             else {
                 const u32x4 v = *(const u32x4 *)(img8 + (size_t)off * 4);
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
                 const int p = 16 * u + i;
                 const bool valid = p < AP * AP;
                 const int pp = valid ? p : AP * AP - 1;
-                const int pr = pp / AP, pc = pp - pr * AP;
-                const float *xb = xp + 2 * pr * C::ROWF + (2 * pc + dx0) * CIN + cb;
+                const int pr = ubd_div24<AP, AP * AP>(pp), pc = pp - ubd_mul24(pr, AP);          // 24-bit multiplies (common.h)
+                const float *xb = xp + ubd_mul24(pr, 2 * C::ROWF) + ubd_mul24(2 * pc + dx0, CIN) + cb;
                 float dwv = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
@@ -319,10 +319,11 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
                 const int c = k * 256 + (int)threadIdx.x;
                 const int row = c / 48, cc = c - row * 48;
                 const int cpx = cc / 3, cch = cc - 3 * cpx;                          // pixel of the row, chunk
-                const u32x4 v = *(const u32x4 *)(a1p + cch * C::A1_PLANE + ((row + 1 + pad_lo) * AP + 1 + pad_lo + cpx) * 16);
+                const u32x4 v = *(const u32x4 *)(a1p + cch * C::A1_PLANE + (ubd_mul24(row + 1 + pad_lo, AP) + 1 + pad_lo + cpx) * 16);
                 const int gy = 2 * oy3 + row, gx = 2 * ox3 + cc / 3;
                 const bool in = gy < H2 && gx < W2;
-                __builtin_amdgcn_raw_buffer_store_b128(v, a1rs, in ? (gy * W2 + 2 * ox3) * (UBD_C * 2) + cc * 16 : (int)0x80000000u, 0, 0);
+                const int gpx = ubd_mul24(gy, W2) + 2 * ox3;                         // pixel index inside the image: x 48 as shifts (it may exceed 24 bits)
+                __builtin_amdgcn_raw_buffer_store_b128(v, a1rs, in ? (gpx << 5) + (gpx << 4) + cc * 16 : (int)0x80000000u, 0, 0);
             }
         }
 
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
                 const int pr = u < TP ? u : (u == TP ? i : TP - 1);
                 const int pc = u < TP ? i : TP - 1;
                 const bool valid = u < TP || (u == TP && i < TP - 1) || (u == TP + 1 && i == 0);
-                const int pp = pr * TP + pc;
+                const int pp = ubd_mul24(pr, TP) + pc;
                 u32x2 o0, o1;
-                sep123_unit<T>(a1p + (pr * AP + pc) * 16, wa0, wa1, pwb, xo0, xo1, b2A, b2B, o0, o1);
+                sep123_unit<T>(a1p + (ubd_mul24(pr, AP) + pc) * 16, wa0, wa1, pwb, xo0, xo1, b2A, b2B, o0, o1);
                 const int gy = oy2 + pr, gx = ox2 + pc;
                 const bool inmap = (unsigned)gy < (unsigned)H2 && (unsigned)gx < (unsigned)W2;
                 if (!inmap) { o0 = u32x2{0u, 0u}; o1 = u32x2{0u, 0u}; }  // outside L2's map: L3's zero padding
@@ -364,10 +365,11 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
                 const int c = k * 256 + (int)threadIdx.x;
                 const int row = c / 48, cc = c - row * 48;
                 const int cpx = cc / 3, cch = cc - 3 * cpx;
-                const u32x4 v = *(const u32x4 *)(t2p + cch * C::T2_PLANE + ((row + pad_lo) * TP + pad_lo + cpx) * 16);
+                const u32x4 v = *(const u32x4 *)(t2p + cch * C::T2_PLANE + (ubd_mul24(row + pad_lo, TP) + pad_lo + cpx) * 16);
                 const int gy = 2 * oy3 + row, gx = 2 * ox3 + cc / 3;
                 const bool in = gy < H2 && gx < W2;
-                __builtin_amdgcn_raw_buffer_store_b128(v, a2rs, in ? (gy * W2 + 2 * ox3) * (UBD_C * 2) + cc * 16 : (int)0x80000000u, 0, 0);
+                const int gpx = ubd_mul24(gy, W2) + 2 * ox3;
+                __builtin_amdgcn_raw_buffer_store_b128(v, a2rs, in ? (gpx << 5) + (gpx << 4) + cc * 16 : (int)0x80000000u, 0, 0);
             }
         }
 
@@ -379,12 +381,13 @@ __global__ __launch_bounds__(256, S123_OCC) void sep123_16_kernel(
             const f32x4 b3B = q < 2 ? *(const f32x4 *)(biasp + 2 * UBD_C + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int r3 = 2 * wid + (i >> 3), c3 = i & 7;
             u32x2 o0, o1;
-            sep123_unit<T>(t2p + (2 * r3 * TP + 2 * c3) * 16, wa0, wa1, pwb, xo0, xo1, b3A, b3B, o0, o1);
+            sep123_unit<T>(t2p + (ubd_mul24(2 * r3, TP) + 2 * c3) * 16, wa0, wa1, pwb, xo0, xo1, b3A, b3B, o0, o1);
             __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (size_t)img * H4 * W4 * UBD_C), 0,
                                                                            (int)((unsigned)H4 * (unsigned)W4 * (UBD_C * 2u)), 0x00020000);
             const int gy = oy3 + r3, gx = ox3 + c3;
             const bool in = gy < H4 && gx < W4;
-            const unsigned off = in ? (unsigned)((gy * W4 + gx) * (UBD_C * 2)) + 8u * (unsigned)q : 0x80000000u;
+            const int gpx3 = ubd_mul24(gy, W4) + gx;
+            const unsigned off = in ? (unsigned)((gpx3 << 5) + (gpx3 << 4)) + 8u * (unsigned)q : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b64(o0, yrs, (int)off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(o1, yrs, (int)(q < 2 ? off + 32u : 0x80000000u), 0, 0);
         }

@@ -124,23 +124,7 @@ __device__ __forceinline__ unsigned relu_mask2(unsigned g, unsigned m)
     return r;
 }
 
-// floor(n / D) for 0 <= n < NMAX as (n * m) >> sh with n * m < 2^24 (one v_mul_u32_u24 + one shift); checked at compile time
-template <int D, int NMAX> struct sepb16_magic {
-    static constexpr int find_sh()
-    {
-        for (int sh = 8; sh < 24; ++sh) {
-            const long m = (1L << sh) / D + 1;
-            if (m * NMAX >= (1L << 24)) continue;
-            bool ok = true;
-            for (long n = 0; n < NMAX && ok; ++n) ok = ((n * m) >> sh) == n / D;
-            if (ok) return sh;
-        }
-        return -1;
-    }
-    static constexpr int sh = find_sh();
-    static_assert(sh > 0, "no 24-bit magic number for this divisor / range");
-    static constexpr unsigned m = (1u << sh) / D + 1;
-};
+template <int D, int NMAX> using sepb16_magic = ubd_magic24<D, NMAX>;      // (common.h)
 
 // Staging of a tile by LDS-DMA: chunk -> (pixel, part) -> (row, column) with two magic-number divisions, then ONE buffer-addressed
 // DMA per 1 KiB piece through a descriptor that covers exactly the image (ubd_blds16, common.h): rows above / below the image fall
