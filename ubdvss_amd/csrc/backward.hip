@@ -1146,15 +1146,15 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             const unsigned *wt = frag16t + (size_t)k * UBD_DIL16_FRAG_U32;
             const bool fuse_dx = !h->split_dilbwd;                 // 8-wide tiles (dilation 16 on 128-wide maps) too since round 4: the fused form with M-split accumulators     // 8-wide tiles (dilation 16 on 128-wide maps): fused 75 us vs 38 + 33 us apart (two blocks per CU instead of three)
             if (pair)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true, false, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true, false, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev, w16_geometry<16, true>(n, H4, W4, dd) WG_STAMP_ARG);
             else if (tw == 8 && fuse_dx)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev, w16_geometry<8, false>(n, H4, W4, dd) WG_STAMP_ARG);
             else if (tw == 8)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 8, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev, w16_geometry<8, false>(n, H4, W4, dd) WG_STAMP_ARG);
             else if (fuse_dx)
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, true>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)wt, g16[cur ^ 1], prev, w16_geometry<16, false>(n, H4, W4, dd) WG_STAMP_ARG);
             else
-                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev WG_STAMP_ARG);
+                hipLaunchKernelGGL((dil_wgrad16_kernel<TX, 16, false>), dim3(gw), dim3(256), 0, st, (const unsigned short *)X, g16[cur], partials, n, H4, W4, dd, (const u32x4 *)nullptr, (unsigned short *)nullptr, prev, w16_geometry<16, false>(n, H4, W4, dd) WG_STAMP_ARG);
             if (!fuse_dx) ubd_launch_dilconv16(h, 1, wt, nullptr, X, dd, g16[cur], g16[cur ^ 1], n, H4, W4, st);
             cur ^= 1;
         }

@@ -139,6 +139,21 @@ template <int TW, bool DX = false, bool PAIR = false> struct w16_cfg {
     static constexpr int KROWS = 32 / TW;                    // tile rows per k-block
 };
 #define W16_BUF_BYTES_MAX (w16_cfg<16>::BUF_BYTES)
+// geometry of a launch, worked out once on the host (as d16s_geom, fwd16.hip): six 32-bit divisions less in every block's prologue
+struct w16_geom { int sh, tiles_x, tiles_y, dxp, items; unsigned m_tx, m_ty, m_d, m_dx; };
+template <int TW, bool PAIR> static w16_geom w16_geometry(int n, int h, int w, int d)
+{
+    constexpr int TH = PAIR ? 8 : W16_TH(TW);
+    w16_geom g;
+    const int sw = (w + d - 1) / d;
+    g.sh = (h + d - 1) / d;
+    g.tiles_y = PAIR ? 1 : (g.sh + TH - 1) / TH; g.tiles_x = PAIR ? 1 : (sw + TW - 1) / TW;
+    g.dxp = PAIR ? d >> 1 : d;                                            // column phases per item row (PAIR: two per item; d is even)
+    g.items = n * d * g.dxp * g.tiles_y * g.tiles_x;
+    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv): floor(a / dv) = umulhi(a, m) while a * dv < 2^32
+    g.m_tx = magic((unsigned)g.tiles_x); g.m_ty = magic((unsigned)g.tiles_y); g.m_d = magic((unsigned)d); g.m_dx = magic((unsigned)g.dxp);
+    return g;
+}
 
 // 16 x 16 two-bit helpers of the fused data gradient (the separable-layer header has its own)
 template <typename T> __device__ __forceinline__ unsigned wg_pack2(float lo, float hi)
@@ -171,7 +186,7 @@ template <typename T, int TW, bool DX, bool MSPLIT = (TW == 8), bool PAIR = fals
 #define W16_OCC(TW, DX) (((TW) == 8) ? 3 : 2)
 __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ gz,
                                                              float *__restrict__ partials, int n, int h, int w, int d,
-                                                             const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout, const rp_job prev
+                                                             const u32x4 *__restrict__ wfrag_t, unsigned short *__restrict__ gout, const rp_job prev, const w16_geom geo
 #ifdef UBD_STAMPS
                                                              , unsigned long long *__restrict__ stamps
 #endif
@@ -253,14 +268,10 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
         }
     }
 
-    const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;
-    const int tiles_y = PAIR ? 1 : (sh + C::TH - 1) / C::TH, tiles_x = PAIR ? 1 : (sw + TW - 1) / TW;
-    const int dxp = PAIR ? d >> 1 : d;                                   // column phases per item row (PAIR: two per item; d is even)
-    const int items = n * d * dxp * tiles_y * tiles_x;
+    const int sh = geo.sh, tiles_y = geo.tiles_y, tiles_x = geo.tiles_x, dxp = geo.dxp, items = geo.items;      // from the host (w16_geometry)
     struct item_t { int img, ry, rx, sy0, sx0; };
     // item index -> (image, phase, tile) with magic-number divisions (wave-uniform: s_mul_hi; exact while it * divisor < 2^32)
-    auto magic = [](unsigned dv) { return dv == 1u ? 0u : 0xFFFFFFFFu / dv + 1u; };       // ceil(2^32 / dv) in 32 bits (the 64-bit form was three ~150-instruction division loops in the prologue)
-    const unsigned m_tx = magic((unsigned)tiles_x), m_ty = magic((unsigned)tiles_y), m_d = magic((unsigned)d), m_dx = magic((unsigned)dxp);
+    const unsigned m_tx = geo.m_tx, m_ty = geo.m_ty, m_d = geo.m_d, m_dx = geo.m_dx;
     auto divm = [](unsigned a, unsigned dv, unsigned m) { return dv == 1u ? a : __umulhi(a, m); };
     auto decode = [&](int it) {
         item_t r;
