@@ -19,6 +19,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         m5 = Model(NetConfig(grey=False), dtype="float16", seed=1)
         x5 = torch.from_numpy(synthetic.noise_images(7, 8, 1024, 1024, 3)).cuda()
         step, per = (lambda: m5.predict_on_device(x5)), 1000
+    if os.environ.get("MODE") == "fwd32":                        # the headline's net: 32 x 512 x 512 fp32 forward
+        mf = Model(NetConfig(grey=False), seed=1)
+        xf = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
+        step, per = (lambda: mf.predict_on_device(xf)), 500
     for _ in range(50): step()
     out = []
     for blk in range(int(os.environ.get("BLOCKS", "12"))):
