@@ -45,7 +45,8 @@ template <int CIN> struct s123_cfg {
     static constexpr int UNITS = (NPIX + 15) / 16;                 // 24
     static constexpr int UPW = (UNITS + NW - 1) / NW;              // units per wave
     static constexpr int W1_FLOATS = 64 * 12 + 64 + 4;              // L1 per-lane weights (9 depthwise taps, 2 pointwise, pad) + biases of L1 / L3 (2 x 32) + the ring of strip ids
-    static constexpr int STEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS;
+    static constexpr int LUT_FLOATS = 256;                          // uint8 input: the 256 preprocessed values (one lookup per element instead of a subtract + an exact division)
+    static constexpr int STEM_FLOATS = A1_FLOATS + B::L2_FLOATS + XP_FLOATS + B::W3PW_FLOATS + B::W3DW_FLOATS + B::CARRY_FLOATS + W1_FLOATS + LUT_FLOATS;
     static constexpr int PP_FLOATS = (PP_LDS_MAX_BYTES + 3) / 4;   // the postprocess job some blocks run first (pp_lds.h) uses the same LDS
     static constexpr int SMEM_FLOATS = STEM_FLOATS > PP_FLOATS ? STEM_FLOATS : PP_FLOATS;
     static_assert(XCH <= 64 && (A1_FLOATS % 4) == 0 && (B::L2_FLOATS % 4) == 0, "patch rows are single 16-byte-aligned DMA pieces");
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     const int strips = n * tiles_y;
     const int D = tiles_x >= 3 ? 1 : 4 - tiles_x;                                   // strips claimed ahead of the current one
     int *ring = (int *)(bt + 64);                                                   // logical strip id of the block's strip ordinal j at [j & 3]
+    float *lut = bt + 64 + 4;                                                       // uint8 input: ((float)b - pre_sub) / pre_div for b = 0 .. 255, filled with the weight tables
     struct tpos { int tx, ty, img, ord, ls; };                                      // ord: ordinal of the strip in this block's sequence
     auto strip_pos = [&](int ord, int tx) {
         tpos p;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             const int e = k * C::NT + (int)threadIdx.x;
             if (e < X::XE) {
                 float *dst = xp + pr * X::XS + CIN + pcf;                            // the LDS image keeps one unused pixel column on the left (dma_x)
-                if constexpr (IN_U8) *dst = xreg[k] > 255u ? 0.f : ((float)xreg[k] - pre_sub) / pre_div;
+                if constexpr (IN_U8) *dst = xreg[k] > 255u ? 0.f : lut[xreg[k] & 255u];
                 else *dst = plain ? __builtin_bit_cast(float, xreg[k]) : (__builtin_bit_cast(float, xreg[k]) - pre_sub) / pre_div;
             }
             pr += C::NT / RWF; pcf += C::NT % RWF;
@@ -385,9 +387,13 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         const float v5 = (t & 31) < UBD_C ? (t < 32 ? bias1 : bias3)[t & 31] : 0.f;
         w1t[t] = v0; w1t[e1] = v1; w3pw[t] = v2; w3pw[e3] = v3; w3dw[ed] = v4;
         if (t < 64) bt[t] = v5;
+        if constexpr (IN_U8) { if (t < 256) lut[t] = ((float)t - pre_sub) / pre_div; }     // the expression the conversion applied per element: same bits
     }
     if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else convert_x(cur);
+    else {
+        if constexpr (IN_U8) __syncthreads();                                        // the lookup table is complete
+        convert_x(cur);
+    }
     __syncthreads();
     S123_BLOCK_STAMP(29);
     phase0b(cur);
