@@ -444,6 +444,9 @@ extern "C" void ubd_debug_set_stamps(void *p) { g_ubd_stamps = (unsigned long lo
 #include "pp_lds.h"
 #include "stem23.h"
 #include "stem123.h"
+#ifdef UBD_EXPERIMENTAL_STEM123W   // tools/build_diag.sh only: the sixteen-wave re-cut of the one-kernel stem (measured slower, profiles/r05_experiment_notes.txt)
+#include "stem123w.h"
+#endif
 
 // ------------------------------------------------------------------------------------
 // Dense dilated 3x3 conv 24 -> 24 (+bias+ReLU), fp32 MFMA, weights resident in VGPRs.
@@ -738,7 +741,7 @@ static bool fused_stem_applies(const ubd_handle *h, int n, int H)
     const int H4 = H / 4;
     const long stem_strips = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
     const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
-    return stem_big && h->fuse_stem == 2 && h->cfg.fml_compatible != 0;
+    return stem_big && h->fuse_stem >= 2 && h->cfg.fml_compatible != 0;
 }
 bool ubd_forward_uses_fused_stem(const ubd_handle *h, int n, int H, int W) { (void)W; return h->cfg.dtype == UBD_F32 && fused_stem_applies(h, n, H); }
 
@@ -794,7 +797,12 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #else
 #define S123_STAMP_ARG
 #endif
+#ifdef UBD_EXPERIMENTAL_STEM123W
+#define UBD_LAUNCH_S123(CINV, U8V, PLV) do { if (h->fuse_stem == 3) hipLaunchKernelGGL((stem123w_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s123w_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG); \
+        else hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG); } while (0)
+#else
 #define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG)
+#endif
         const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30);   // fp32 fed as it is: LDS-DMA path (offsets of one image in 30 bits)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
@@ -876,7 +884,11 @@ extern "C" int ubd_forward_postprocess(ubd_handle *h, const float *params, const
     if (h->cfg.dtype == UBD_F32 && n > 0 && height > 0 && (height % 4) == 0 && ubd_forward_uses_fused_stem(h, n, height, width)) {
         pp_lds_args job;
         const int fits = ubd_pp_fill_job(h, pp_logits, pp_n, pp_map_h, pp_map_w, logit_threshold, scale, min_area, binary_map, quads, classes,
-                                         counts, cap, pp_workspace, pp_workspace_bytes, s23_cfg::NT, &job);
+                                         counts, cap, pp_workspace, pp_workspace_bytes,
+#ifdef UBD_EXPERIMENTAL_STEM123W
+                                         h->fuse_stem == 3 ? s123w_cfg::NT :
+#endif
+                                         s23_cfg::NT, &job);
         if (fits < 0) return 1;
         if (fits == 1) {
             ubd_fwd_layout L;
