@@ -69,6 +69,13 @@ def csrc_sha16():
     return hsh.hexdigest()[:16]
 
 
+def library_build_id():
+    """Fingerprint of the kernel sources the LOADED libubd_hip.so was compiled from (ubd_build_id, written by build.sh): what the
+    committed profiles are compared with -- the files on disk may have been edited since the build."""
+    from ubdvss_amd import _lib
+    return _lib.load().ubd_build_id().decode()
+
+
 def committed_profile(kernel_prefix):
     """(traffic MB per launch, average launch us, file names, whether the profile was taken on the sources of this build) from
     the NEWEST committed profile set under profiles/ -- values measured in another run and labelled as such on the line."""
@@ -102,7 +109,7 @@ def committed_profile(kernel_prefix):
                 meta["round"] = rnd
             except (OSError, ValueError):
                 meta = {}
-    fresh = bool(meta) and meta.get("csrc_sha16") == csrc_sha16() and all(v.startswith(f"profiles/{meta['round']}_") for v in files.values())
+    fresh = bool(meta) and meta.get("csrc_sha16") == library_build_id() and all(v.startswith(f"profiles/{meta['round']}_") for v in files.values())
     return traffic, avg_us, files, fresh
 
 
@@ -573,13 +580,25 @@ def main():
             tstep()
         tel = timed_wall(tstep, args.steps)
         tel_single = timed_wall(lambda: trainer.train_step_on_device(txs[0], tys[0]), args.steps)
+        params_agree = None
+        if dist is not None:
+            # data-parallel replicas apply the SAME summed gradient to the same weights: after the timed steps every rank must hold
+            # bit-identical parameters -- a lost or half-summed all-reduce segment (an ordering bug between the communication
+            # stream and the step's stream) makes the replicas drift apart.  min == max of a checksum over the ranks; checked, not timed.
+            cs = tmodel.params.double().sum().reshape(1)
+            absum = tmodel.params.double().abs().sum().reshape(1)
+            lo, hi, lo2, hi2 = cs.clone(), cs.clone(), absum.clone(), absum.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo2, op=dist.ReduceOp.MIN); dist.all_reduce(hi2, op=dist.ReduceOp.MAX)
+            params_agree = bool(float(lo) == float(hi) and float(lo2) == float(hi2))
+            assert params_agree, f"bench.py: rank {rank}: the replicas' parameters differ after {tno[0]} data-parallel train steps ({float(lo)} .. {float(hi)})"
         bpe = 4.0 if dtype == "float32" else 2.0
         e_fwd = SIDE * SIDE * (C_IN + 45 + (1 + n_cls) / 16.0)                    # E_fwd elements per image
         train_bytes_per_image = (3 * e_fwd - SIDE * SIDE * C_IN) * bpe             # E_train = 3 E_fwd - H W C_in
         res = {"metric": "images/sec (512x512) train step", "value": round(world * tb * args.steps / tel, 1),
                "unit": "images/s", "ms_per_step": round(tel / args.steps * 1e3, 4), "batch_per_gpu": tb, "global_batch": tb * world,
                "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtype], "n_classes": n_cls,
-               "parallelism": comm_kind,
+               "parallelism": comm_kind, "replica_parameters_identical_after_the_steps": params_agree,
                "loss_last": round(float(trainer.loss[0]), 5),
                "hbm_frac_algorithmic": round(tb * train_bytes_per_image / (tel / args.steps) / 1e9 / PEAK_HBM, 4),
                "input_ring_MB": round(sum(t.numel() * t.element_size() for t in txs) / 1e6, 1),

@@ -80,3 +80,19 @@ def test_batch_global_loss_mode_one_rank_equals_local(n_cls):
     torch.cuda.synchronize()
     assert torch.equal(tr.loss, ref.loss)
     assert torch.allclose(tr.grads, ref.grads, rtol=1e-4, atol=1e-7) and torch.allclose(m.params, ref.model.params, rtol=1e-5, atol=1e-7)
+
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: a real two-rank RCCL exchange (the GPU box of the test run has one)")
+def test_two_rank_real_rccl_fused_step_is_bit_equal_to_the_unfused_all_reduce():
+    """the fused data-parallel step puts the dilated + head segment's all-reduce on the communication stream under the stem
+    backward; chained reduction moved the point where that segment becomes final.  On real RCCL with two ranks (one process per GPU,
+    tools/dist_rccl_check.py): gradients of the fused + chained, fused + batched and unfused (one torch all-reduce) steps are BIT-equal
+    on every one of 200 steps, and the ranks' parameters agree afterwards.  Skipped on a one-GPU box (there the N-rank paths run as
+    threads over the stream-ordered in-process stand-in: tests/test_gpu_comm_loopback.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", os.path.join(root, "tools", "dist_rccl_check.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "DIST_RCCL_CHECK OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -26,6 +26,7 @@ _vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _f = ctypes.c_float
 SIGNATURES = {
     "ubd_abi_version": (_i, []),
+    "ubd_build_id": (ctypes.c_char_p, []),
     "ubd_last_error": (ctypes.c_char_p, []),
     "ubd_create": (_i, [ctypes.POINTER(UbdConfig), ctypes.POINTER(_vp)]),
     "ubd_destroy": (None, [_vp]),
@@ -78,3 +79,30 @@ def load():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed (code {rc}): {load().ubd_last_error().decode()}")
+
+
+class StreamWorkspaces:
+    """Device scratch per (device, stream) for the static entry points (losses.get_loss, SegmapManager.postprocess): calls on one
+    stream are ordered and may share a scratch, two streams never do.  Bounded: the least recently used entry goes when more than
+    ``max_entries`` streams have been seen (a process that makes many short-lived streams would otherwise keep one full-size
+    scratch per stream handle for ever; a dropped tensor returns to torch's caching allocator, which reuses it in stream order)."""
+
+    def __init__(self, max_entries=8):
+        import collections
+        self._d = collections.OrderedDict()
+        self._max = int(max_entries)
+
+    def get(self, device, raw_stream, nbytes):
+        import torch
+        key = (str(device), int(raw_stream))
+        ws = self._d.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self._d[key] = ws
+        self._d.move_to_end(key)
+        while len(self._d) > self._max:
+            self._d.popitem(last=False)
+        return ws
+
+    def __len__(self):
+        return len(self._d)

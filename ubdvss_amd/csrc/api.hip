@@ -15,6 +15,10 @@ void ubd_set_error(const char *fmt, ...)
 
 extern "C" const char *ubd_last_error(void) { return g_err; }
 extern "C" int ubd_abi_version(void) { return UBD_ABI_VERSION; }
+#ifndef UBD_BUILD_ID
+#define UBD_BUILD_ID "unknown"
+#endif
+extern "C" const char *ubd_build_id(void) { return UBD_BUILD_ID; }   // sha256 over the kernel sources at build time (build.sh); bench.py compares it with the committed profiles' fingerprint
 
 extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
 {

@@ -993,7 +993,8 @@ static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const un
     // (UBD_SEPB16_X=regs keeps the register path, which also serves every other input)
     bool xdma = false;
     if constexpr (CIN != UBD_C)
-        xdma = !in_u8 && sub == 0.f && div == 1.f && (W * CIN) % 4 == 0 && ((uintptr_t)x & 15) == 0 && (unsigned)pad_lo <= 1u && !h->sepb_x_regs;
+        xdma = !in_u8 && sub == 0.f && div == 1.f && (W * CIN) % 4 == 0 && ((uintptr_t)x & 15) == 0 && (unsigned)pad_lo <= 1u && !h->sepb_x_regs &&
+               (size_t)H * W * CIN * 4 < (1ull << 31);      // the kernel's 'outside the image' offset 0x80000000 must lie beyond one image's bytes (the register path serves larger images)
     const long tiles = (long)n * ((OH + C::TH - 1) / C::TH) * ((OW + 15) / 16);
     int grid = h->num_cus * (xdma ? sepb16_cfg<CIN, STRIDE, GSRC, 1>::BLOCKS_PER_CU : C::BLOCKS_PER_CU);
     if (grid > tiles) grid = (int)tiles;

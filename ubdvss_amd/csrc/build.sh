@@ -5,6 +5,15 @@ cd "$(dirname "$0")"
 OUT=../libubd_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 mkdir -p _obj
+# fingerprint of the kernel sources, compiled into the library (ubd_build_id): the same digest bench.csrc_sha16() takes of the files
+BUILD_ID=$(python3 - <<'PY'
+import glob, hashlib, os
+h = hashlib.sha256()
+for f in sorted(glob.glob("*.hip") + glob.glob("*.h")):
+    h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+print(h.hexdigest()[:16])
+PY
+)
 pids=()
 for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   [ -f $f.hip ] || continue
@@ -17,6 +26,10 @@ for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
   stale=0
   for dep in $f.hip *.h ../../include/ubd.h; do [ "$dep" -nt _obj/$f.o ] && stale=1; done
+  if [ "$f" = "api" ]; then   # carries the fingerprint of ALL kernel sources
+    extra="$extra -DUBD_BUILD_ID=\"$BUILD_ID\""
+    [ "$(cat _obj/api.build_id 2>/dev/null)" != "$BUILD_ID" ] && stale=1
+  fi
   if [ ! -f _obj/$f.o ] || [ $stale = 1 ]; then
     ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o _obj/$f.o ${UBD_SAVE_TEMPS:+-save-temps=obj} ) &
     pids+=($!)
@@ -25,5 +38,6 @@ done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
 for f in api forward fwd16 wino postprocess loss backward train comm raster; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
+echo "$BUILD_ID" > _obj/api.build_id
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs -ldl
 echo "built $OUT"

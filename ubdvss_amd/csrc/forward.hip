@@ -803,7 +803,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #else
 #define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG)
 #endif
-        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30);   // fp32 fed as it is: LDS-DMA path (offsets of one image in 30 bits)
+        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30) && ((uintptr_t)images & 15) == 0;   // fp32 fed as it is: 16-byte LDS-DMA path (offsets of one image in 30 bits, 16-byte aligned base)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
 #undef UBD_LAUNCH_S123

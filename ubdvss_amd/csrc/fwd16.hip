@@ -1114,7 +1114,7 @@ static void launch_sep12(const ubd_handle *h, const void *x, unsigned short *a1,
                        bias2, n, H, W, H2, W2, pad_lo, sub, div); else hipLaunchKernelGGL((sep12_16_kernel<CIN, IN_MODE, PLAIN, WR, T, 2>), dim3(grid), dim3(256), 0, st, x, a1, a2, frag1, bias1, frag2,    \
                        bias2, n, H, W, H2, W2, pad_lo, sub, div); } while (0)
     // fp32 pixels fed as they are, offsets inside one image below 2^31: LDS-DMA
-    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31);
+    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31) && ((uintptr_t)x & 15) == 0;   // 16-byte DMA pieces: an offset view of a tensor takes the register-staged variant
     if constexpr (IN_MODE == 0) {
         if (plain) {
             if (write_a1) UBD_SEP12_LAUNCH(true, true); else UBD_SEP12_LAUNCH(true, false);
@@ -1139,7 +1139,7 @@ static void launch_sep123(const ubd_handle *h, const void *x, unsigned short *a1
     hipLaunchKernelGGL((sep123_16_kernel<CIN, IN_MODE, PLAIN, WR, T>), dim3(grid), dim3(256), 0, st, x, a1, a2, a3, frag1, bias1, (const u32x4 *)ready23, \
                        bias2, bias3, n, H, W, H2, W2, H4, W4, pad_lo, sub, div S123_16_STAMP_ARG)
     // fp32 pixels fed as they are, offsets inside one image below 2^31: LDS-DMA
-    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31);
+    const bool plain = IN_MODE == 0 && sub == 0.f && div == 1.f && (size_t)H * W * CIN * 4 < (1ull << 31) && ((uintptr_t)x & 15) == 0;   // 16-byte DMA pieces: an offset view of a tensor takes the register-staged variant
     if constexpr (IN_MODE == 0) {
         if (plain) {
             if (write_a12) UBD_SEP123_LAUNCH(true, true); else UBD_SEP123_LAUNCH(true, false);

@@ -20,7 +20,7 @@ L_DETECTION_WEIGHT = 1.
 L_CLASSIFICATION_WEIGHT = 1.
 
 _handles = {}
-_workspaces = {}          # (device, stream) -> uint8 scratch reused between calls on that stream (grown on demand)
+_workspaces = _lib.StreamWorkspaces()   # (device, stream) -> uint8 scratch reused between calls on that stream (grown on demand, LRU-bounded)
 
 
 def _handle(n_classes, device):
@@ -58,11 +58,7 @@ def loss_and_grad(y_true, y_pred, want_grad=True):
     nbytes = int(lib.ubd_loss_workspace_bytes(hd, n, h, w))
     # one scratch per (device, stream): calls on one stream are ordered, two streams never share header / histograms
     raw_stream = torch.cuda.current_stream(device).cuda_stream
-    wkey = (str(device), int(raw_stream))
-    ws = _workspaces.get(wkey)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _workspaces[wkey] = ws
+    ws = _workspaces.get(device, raw_stream, nbytes)
     stream = ctypes.c_void_p(raw_stream)
     _lib.check(lib.ubd_loss(hd, yp.data_ptr(), yt.data_ptr(), n, h, w, loss.data_ptr(),
                             grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(), stream), "ubd_loss")

@@ -379,11 +379,14 @@ class Model:
 
     # ---------------------------------------------------------------- postprocess
     def alloc_postprocess_outputs(self, n, mh, mw, cap, want_map=True):
+        """Result buffers of ``ubd_postprocess``.  Nothing is cleared: the library writes ``counts[i]`` for every image and the first
+        ``min(counts[i], cap)`` entries of an image's lists; entries behind a list's end are unspecified (no fill kernels on this
+        path -- rounds 1-4 zero-filled 1 MB per call through two torch kernels)."""
         dev = self.device
         bmap = torch.empty((n, mh, mw), dtype=torch.int32, device=dev) if want_map else None
-        quads = torch.zeros((n, cap, 8), dtype=torch.int32, device=dev)
-        classes = torch.zeros((n, cap), dtype=torch.int32, device=dev) if self.n_classes > 0 else None
-        counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        quads = torch.empty((n, cap, 8), dtype=torch.int32, device=dev)
+        classes = torch.empty((n, cap), dtype=torch.int32, device=dev) if self.n_classes > 0 else None
+        counts = torch.empty((n,), dtype=torch.int32, device=dev)
         return bmap, quads, classes, counts
 
     def postprocess_on_device(self, logits, logit_threshold, scale, min_area, cap=256, want_map=True, outputs=None):

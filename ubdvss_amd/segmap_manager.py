@@ -14,18 +14,13 @@ from . import _lib
 from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 _handles = {}
-_workspaces = {}          # (device, stream) -> uint8 tensor: the static entry points reuse their scratch between calls
+_workspaces = _lib.StreamWorkspaces()   # (device, stream) -> uint8 tensor: the static entry points reuse their scratch between calls (LRU-bounded)
 
 
 def _workspace(device, nbytes):
     """Device scratch of at least nbytes, kept per (device, current stream): calls on one stream are ordered, two streams
     never share a scratch (grown when a bigger request comes; never shrunk)."""
-    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
+    return _workspaces.get(device, torch.cuda.current_stream(device).cuda_stream, nbytes)
 
 
 def _reset_handles():
@@ -69,9 +64,9 @@ class SegmapManager:
         lgt = torch.from_numpy(lg).to(device)
         hd = _handle(n_cls, device)
         cap = max_objects
-        quads = torch.zeros((1, cap, 8), dtype=torch.int32, device=device)
-        classes = torch.zeros((1, cap), dtype=torch.int32, device=device)
-        counts = torch.zeros((1,), dtype=torch.int32, device=device)
+        quads = torch.empty((1, cap, 8), dtype=torch.int32, device=device)      # the library writes the count and the list's first entries
+        classes = torch.empty((1, cap), dtype=torch.int32, device=device)
+        counts = torch.empty((1,), dtype=torch.int32, device=device)
         ws = _workspace(device, lib.ubd_postprocess_workspace_bytes(hd, 1, h, w, cap))
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         _lib.check(lib.ubd_postprocess(hd, lgt.data_ptr(), 1, h, w, 0.5, int(scale), float(min_area_threshold),
