@@ -50,7 +50,7 @@ typedef struct ubd_handle ubd_handle;
 
 /* --- lifecycle ----------------------------------------------------------- */
 int ubd_abi_version(void);
-const char *ubd_build_id(void);                         /* 16 hex digits: fingerprint of the kernel sources (csrc/*.hip, *.h) THIS library was compiled from */
+const char *ubd_build_id(void);                         /* 16 hex digits: fingerprint of the kernel sources (every .hip and .h file of csrc) THIS library was compiled from */
 const char *ubd_last_error(void);                       /* thread-local message of the last failure */
 int ubd_create(const ubd_config *cfg, ubd_handle **out); /* replaces NetManager.build_model (net.py:273-314) */
 void ubd_destroy(ubd_handle *h);

@@ -11,8 +11,11 @@ stand-in for the six RCCL entry points comm.hip resolves (UBD_RCCL_LIB).  What i
   * round 4: the same three paths with EIGHT ranks (configs[3]'s world size) on tiny shapes -- fused all-reduce = the rank-order
     sum of eight shard gradients, the batch-global top-k with its k-th value repeated in several shards, broadcast from a
     non-zero root.
-The stand-in synchronises the host and the stream around every collective: these tests check the collective ARITHMETIC and the
-matching of calls across ranks, not cross-stream event ordering or overlap (tests/loopback/loopback_nccl.cpp).
+Round 5: the stand-in is STREAM-ORDERED (no host synchronisation of any stream: a rank's contribution is read by a device copy on
+the stream it passed, the rank-order sum runs on the group's stream behind the ranks' events, the result is copied out on each
+rank's stream behind the sum's event -- NCCL's visibility contract), so these tests now also check the cross-stream ORDERING of
+the fused step: test_fused_step_ordering_* goes red on a build of the library with one event wait dropped
+(tools/prove_comm_ordering.sh, profiles/r05_comm_ordering_power.log).
 """
 import ctypes
 import os
@@ -323,3 +326,44 @@ def test_eight_ranks_broadcast_from_a_non_zero_root(loopback):
     assert not torch.equal(outs[0][0], outs[5][0])
     for r in range(world):
         assert torch.equal(outs[r][1], outs[5][0])
+
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_fused_step_ordering_matches_the_explicit_all_reduce_step_by_step(loopback, monkeypatch, world):
+    """Cross-stream ordering of the fused data-parallel step (comm.hip / backward.hip): the dilated + head segment is all-reduced on
+    the handle's communication stream under the stem backward (event `ready`: compute -> communication stream; event `done`:
+    communication stream -> the caller's stream before Adam).  Reference without any cross-stream edge: the same step with an
+    unfused communicator and ONE explicit ubd_allreduce_grads on the caller's stream.  bf16 gradients are bit-reproducible, the
+    stand-in sums in rank order: gradients and parameters must be BIT-equal on every one of 12 steps, with the sum deliberately
+    300 us late (LOOPBACK_DELAY_US; only the big segment: the small one that follows it on the caller's stream is on time, and the
+    stand-in does not order two collectives with each other) so that a consumer that does not wait reads stale bytes for certain."""
+    monkeypatch.setenv("LOOPBACK_DELAY_US", "300")
+    monkeypatch.setenv("LOOPBACK_DELAY_MIN_COUNT", "10000")          # the dilated + head segment (31 273 floats) is late, the stem segment (1 755) is not
+    cfg = NetConfig(grey=False)
+    steps = 12
+    batches = [_batch(4 * world, 96, 300 + 7 * k) for k in range(3)]
+
+    def run(fused):
+        uid = _uid()
+
+        def body(r):
+            m = Model(cfg, dtype="bfloat16", seed=5)
+            _attach(m, uid, r, world, _lib.UBD_COMM_FUSED if fused else 0)
+            tr = Trainer(m, Adam(lr=1e-3))
+            tr.broadcast_weights(src=0)
+            hist = []
+            for s in range(steps):
+                x, y = batches[s % 3]
+                tr.backward_on_device(x[4 * r:4 * r + 4], y[4 * r:4 * r + 4])
+                tr.apply_gradients()                             # explicit mode: ubd_allreduce_grads on the caller's stream, then Adam
+                hist.append((tr.grads.clone(), m.params.clone()))    # clones are enqueued on the rank's stream: ordered behind the step
+            torch.cuda.current_stream().synchronize()
+            return hist
+        return _ranks(world, body)
+    fused, explicit = run(True), run(False)
+    for r in range(world):
+        for s in range(steps):
+            assert torch.equal(fused[r][s][0], explicit[r][s][0]), f"rank {r} step {s}: summed gradients differ (max {float((fused[r][s][0] - explicit[r][s][0]).abs().max()):.3e})"
+            assert torch.equal(fused[r][s][1], explicit[r][s][1]), f"rank {r} step {s}: parameters differ"
+            assert torch.equal(fused[r][s][1], fused[0][s][1]), f"rank {r} step {s}: replicas drifted apart"

@@ -162,7 +162,9 @@ int ubd_comm_begin_tail(ubd_handle *h, float *grads, hipStream_t st)
     ubd_comm *c = h->comm;
     const size_t first = h->off_dil_k[0];
     UBD_CHECK_HIP(hipEventRecord(c->ready, st));
+#if !(defined(UBD_SABOTAGE_COMM) && UBD_SABOTAGE_COMM == 1)   // diagnostic build of tools/prove_comm_ordering.sh: this wait dropped, the ordering test must go red
     UBD_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+#endif
     UBD_CHECK_NCCL(c, c->AllReduce(grads + first, grads + first, h->n_params - first, ncclFloat32, ncclSum, c->comm, c->stream));
     UBD_CHECK_HIP(hipEventRecord(c->done, c->stream));
     return 0;
@@ -173,6 +175,8 @@ int ubd_comm_finish(ubd_handle *h, float *grads, hipStream_t st)
 {
     ubd_comm *c = h->comm;
     UBD_CHECK_NCCL(c, c->AllReduce(grads, grads, h->off_dil_k[0], ncclFloat32, ncclSum, c->comm, st));
+#if !(defined(UBD_SABOTAGE_COMM) && UBD_SABOTAGE_COMM == 2)
     UBD_CHECK_HIP(hipStreamWaitEvent(st, c->done, 0));
+#endif
     return 0;
 }
