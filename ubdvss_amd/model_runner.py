@@ -13,18 +13,20 @@ from .data_markup import ObjectMarkup, ClassifiedObjectMarkup
 
 
 class ModelRunner:
-    def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256, pipelined=False):
+    def __init__(self, net_config, pixel_threshold=0.5, max_objects_per_image=256, pipelined=False, slots=2):
         """model_runner.py:31-38: pixel_probability > pixel_threshold is positive.
         pipelined=True: the postprocess of batch k is enqueued together with the forward pass of batch k+1 -- inside the
         first blocks of that pass's stem kernel (ubd_forward_postprocess), on the same stream, without events.  The result
         tensors a call returns are therefore COMPLETE only after the next call (or ``flush()``) has been enqueued and the
         stream has been waited for; ``synchronize()`` does both.  Logits / results are double-buffered: they stay valid until
-        the second call after the one that returned them."""
+        the second call after the one that returned them (``slots`` = 3: until the third -- ``predict_stream`` copies a batch's
+        results to the host while the next two batches are in flight)."""
         self._net_config = net_config
         eps = 1e-9
         self._logit_threshold = - np.log(1 / np.clip(pixel_threshold, eps, 1 - eps) - 1)
         self._cap = max_objects_per_image
         self._pipelined = pipelined
+        self._nslots = max(2, int(slots))
         self._slots = {}
         self._step = 0
         self._pending = None            # (model, slot): logits whose postprocess has not been enqueued yet
@@ -63,7 +65,7 @@ class ModelRunner:
             return logits, bmap, quads, classes, counts
         # ---- pipeline on ONE stream: this call = forward(batch k+1) + postprocess(batch k) in the same launches
         n, hh, ww, _ = images.shape
-        key = (self._step & 1, n, hh, ww, id(model))
+        key = (self._step % self._nslots, n, hh, ww, id(model))
         self._step += 1
         slot = self._slots.get(key)
         if slot is None:
@@ -90,26 +92,187 @@ class ModelRunner:
         xt = torch.from_numpy(np.ascontiguousarray(x)).to(model.device)
         logits, bmap, quads, classes, counts = self.predict_on_device(model, xt)
         self.flush()                                    # pipelined runner: this batch's postprocess now, the copies below wait for it
-        counts_h = counts.cpu().numpy()
+        return self._assemble(counts.cpu().numpy(), quads.cpu().numpy(), classes.cpu().numpy() if classes is not None else None,
+                              logits.cpu().numpy(), bmap.cpu().numpy(), rescale, meta_infos)
+
+    def _assemble(self, counts_h, quads_h, classes_h, logits_h, bmap_h, rescale, meta_infos, copy=False):
+        """Host arrays -> the reference's return triple (model_runner.py:121-138).  copy: the arrays are reused staging buffers."""
         if (counts_h > self._cap).any():
             raise RuntimeError(f"more than max_objects_per_image={self._cap} objects in an image "
                                f"(max found {int(counts_h.max())}); raise the capacity")
-        quads_h = quads.cpu().numpy()
-        classes_h = classes.cpu().numpy() if classes is not None else None
-        logits_h = logits.cpu().numpy()
-        detection_logits = bmap.cpu().numpy().astype(np.int64)[..., None]
-        classification_logits = logits_h[..., 1:]
+        detection_logits = bmap_h.astype(np.int64)[..., None]
+        classification_logits = np.array(logits_h[..., 1:]) if copy else logits_h[..., 1:]
         with_cls = self._net_config.is_classification_supported()
         found_objects = []
-        for i in range(x.shape[0]):
-            objs = []
-            for j in range(int(counts_h[i])):
-                bbox = quads_h[i, j].astype(int)
-                objs.append(ClassifiedObjectMarkup(bbox, classes_h[i, j]) if with_cls else ObjectMarkup(bbox))
-            found_objects.append(objs)
+        for i in range(len(counts_h)):
+            n = int(counts_h[i])
+            boxes = quads_h[i, :n].astype(int)              # one conversion per image (a fresh array: the rows are views of it)
+            if with_cls:
+                found_objects.append([ClassifiedObjectMarkup(boxes[j], classes_h[i, j]) for j in range(n)])
+            else:
+                found_objects.append([ObjectMarkup(boxes[j]) for j in range(n)])
         if rescale:
             found_objects = self.rescale(found_objects, meta_infos)
         return detection_logits, classification_logits, found_objects
+
+    def predict_stream(self, model, batches, rescale=False, meta_infos=None, copy_threads=4):
+        """The loop of the reference's ``ModelRunner.run`` (model_runner.py:60-67: ``predict`` batch after batch) as ONE pipeline:
+        generator over ``predict``'s return triple, one per batch of ``batches`` (an iterable of numpy (N,H,W,C) arrays, uint8 or
+        float32), in order.  Batch k + 1 is staged and transferred while batch k computes:
+          staging thread: the batch is copied into one of three PINNED staging buffers by ``copy_threads`` pool threads (numpy
+            releases the GIL) -- the transfer of pageable memory would otherwise be staged by the runtime, synchronously;
+          copy-in stream: pinned -> device (three device input buffers), enqueued as soon as the batch is staged and BEFORE the
+            consumer blocks on an older batch's results; an event hands the buffer to the compute stream;
+          compute stream: the pipelined runner -- forward pass of batch k with the postprocess of batch k - 1 inside its stem kernel;
+          copy-out stream: (logits, map, quads, classes, counts) of batch k - 1 -> pinned host memory behind an event;
+          consumer (this generator): the object lists of batch k - 2 are built while all of that is in flight.
+        ``meta_infos``: one list per batch when ``rescale``.  Results are identical to calling ``predict`` per batch
+        (tests/test_gpu_end_to_end.py::test_predict_stream_equals_predict)."""
+        import concurrent.futures as cf
+        import queue
+        import threading
+        import time
+        dev = model.device
+        runner = ModelRunner(self._net_config, max_objects_per_image=self._cap, pipelined=True, slots=3)
+        runner._logit_threshold = self._logit_threshold
+        s_main = torch.cuda.current_stream(dev)
+        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        pool = cf.ThreadPoolExecutor(max_workers=max(1, int(copy_threads)))
+        NPIN, NDEV, NRES = 3, 3, 3
+        pinned, dev_in, host_res = [None] * NPIN, [None] * NDEV, [None] * NRES
+        fwd_done, d2h_done = [None] * NDEV, [None] * NRES
+        inflight = []                                   # [batch index, device results, d2h event or None, meta]
+        metas = iter(meta_infos) if meta_infos is not None else None
+        free_slots, staged = queue.Queue(), queue.Queue(maxsize=NPIN - 1)
+        for slot in range(NPIN):
+            free_slots.put((slot, None))
+        stop = threading.Event()
+
+        def stager():
+            """host side of the copy-in, its own thread: batch -> pinned staging buffer, ahead of the stream work"""
+            try:
+                for k, x in enumerate(batches):
+                    if stop.is_set():
+                        return
+                    x = np.asarray(x)
+                    if x.dtype != np.uint8:
+                        x = x.astype(np.float32, copy=False)
+                    x = np.ascontiguousarray(x)
+                    tdt = torch.uint8 if x.dtype == np.uint8 else torch.float32
+                    slot, ev = free_slots.get()
+                    if ev is not None:
+                        ev.synchronize()                # the transfer that last read this staging buffer is over
+                    if pinned[slot] is None or tuple(pinned[slot].shape) != x.shape or pinned[slot].dtype != tdt:
+                        pinned[slot] = torch.empty(x.shape, dtype=tdt, pin_memory=True)
+                    dst = pinned[slot].numpy()
+                    n = x.shape[0]
+                    parts = max(1, min(int(copy_threads), n))
+                    bounds = [n * i // parts for i in range(parts + 1)]
+                    futs = [pool.submit(np.copyto, dst[bounds[i]:bounds[i + 1]], x[bounds[i]:bounds[i + 1]]) for i in range(parts)]
+                    for f in futs:
+                        f.result()
+                    staged.put((k, slot, next(metas) if metas is not None else None))
+                staged.put(None)
+            except BaseException as e:                  # noqa: BLE001 -- re-raised by the consumer
+                staged.put(e)
+
+        def copy_in(item):
+            """pinned -> device on the copy-in stream; returns (k, device buffer index, event, meta)"""
+            k, slot, meta = item
+            d, src = k % NDEV, pinned[slot]
+            if dev_in[d] is None or dev_in[d].shape != src.shape or dev_in[d].dtype != src.dtype:
+                dev_in[d] = torch.empty(src.shape, dtype=src.dtype, device=dev)
+            with torch.cuda.stream(s_in):
+                if fwd_done[d] is not None:
+                    s_in.wait_event(fwd_done[d])        # the forward pass that last read this device buffer is over
+                dev_in[d].copy_(src, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(s_in)
+            free_slots.put((slot, ev))                  # the stager waits for the event before it writes the buffer again
+            return k, d, ev, meta
+
+        def fetch(entry):
+            """device results of batch entry[0] -> its pinned host set on the copy-out stream, behind everything enqueued on the compute stream so far"""
+            r, res = entry[0] % NRES, entry[1]
+            if host_res[r] is None or any((h is None) != (t is None) or (t is not None and (h.shape != t.shape or h.dtype != t.dtype)) for h, t in zip(host_res[r], res)):
+                host_res[r] = [None if t is None else torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in res]
+            ev_c = torch.cuda.Event(); ev_c.record(s_main)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_c)
+                for h, t in zip(host_res[r], res):
+                    if t is not None:
+                        h.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(s_out)
+            d2h_done[r] = ev
+            entry[2] = ev
+
+        def deliver(entry):
+            entry[2].synchronize()
+            logits_h, bmap_h, quads_h, classes_h, counts_h = [None if h is None else h.numpy() for h in host_res[entry[0] % NRES]]
+            return self._assemble(counts_h, quads_h, classes_h, logits_h, bmap_h, rescale, entry[3], copy=True)
+
+        stats = {"wait_staged_s": 0.0, "enqueue_s": 0.0, "deliver_s": 0.0, "batches": 0}
+        self.last_stream_stats = stats                  # where the consumer thread's time went (tools/bench_host_stream.py prints it)
+        th = threading.Thread(target=stager, daemon=True)
+        th.start()
+        try:
+            ahead = None                                # batch k + 1, already on its way to the device
+            done = False
+            while True:
+                t0 = time.perf_counter()
+                if ahead is None:
+                    if done:
+                        break
+                    item = staged.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    ahead = copy_in(item)
+                k, d, ev, meta = ahead
+                ahead = None
+                t1 = time.perf_counter()
+                stats["wait_staged_s"] += t1 - t0
+                s_main.wait_event(ev)
+                if d2h_done[k % NRES] is not None:
+                    s_main.wait_event(d2h_done[k % NRES])           # the runner's result slot k % 3 is about to be overwritten: batch k - 3 has left it (long ago)
+                res = runner.predict_on_device(model, dev_in[d])   # forward of batch k + postprocess of batch k - 1, one stream
+                fe = torch.cuda.Event(); fe.record(s_main)
+                fwd_done[d] = fe
+                if inflight:                                        # batch k - 1 is complete behind this call: copy its results out
+                    fetch(inflight[-1])
+                inflight.append([k, res, None, meta])
+                if not done:                                        # batch k + 1: start its transfer NOW, before blocking on older results
+                    try:
+                        item = staged.get_nowait()
+                        if item is None:
+                            done = True
+                        elif isinstance(item, BaseException):
+                            raise item
+                        else:
+                            ahead = copy_in(item)
+                    except queue.Empty:
+                        pass
+                t2 = time.perf_counter()
+                stats["enqueue_s"] += t2 - t1
+                stats["batches"] += 1
+                while len(inflight) > 2:                            # build batch k - 2's lists while k - 1 copies out and k computes
+                    out = deliver(inflight.pop(0))
+                    stats["deliver_s"] += time.perf_counter() - t2
+                    yield out
+            if inflight:
+                runner.flush()                                      # the last batch's postprocess, a launch of its own
+                fetch(inflight[-1])
+            while inflight:
+                yield deliver(inflight.pop(0))
+        finally:
+            stop.set()
+            while th.is_alive():                                    # a consumer that stopped early: unblock the stager
+                try:
+                    staged.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
+            pool.shutdown(wait=True)
 
     @staticmethod
     def rescale(found_objects, meta_infos):
