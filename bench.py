@@ -201,6 +201,9 @@ def cpu_child(kind, seconds, n_threads):
         # tenants) and repeats on pinned cores scatter, so the fastest and slowest repeat are reported beside it
         res = {"value": round(BATCH / float(np.median(times)), 2), "unit": "images/s", "kind": "port", **pin,
                "fastest": round(BATCH / min(times), 2), "slowest": round(BATCH / max(times), 2), "repeats": len(times),
+               "spread_images_per_s": {"min": round(BATCH / max(times), 2), "p10": round(BATCH / float(np.percentile(times, 90)), 2),
+                                       "median": round(BATCH / float(np.median(times)), 2), "p90": round(BATCH / float(np.percentile(times, 10)), 2),
+                                       "max": round(BATCH / min(times), 2)},
                "sample": f"{len(times)} repeats of ONE batch of {BATCH} textured 512x512x3 images (the GPU step's tensor), torch-CPU fp32 "
                          f"forward (oneDNN) + C restatement of the OpenCV postprocess; value = median repeat, {el:.1f} s in all"}
     elif kind == "train":
@@ -220,6 +223,9 @@ def cpu_child(kind, seconds, n_threads):
         times, el = _timed_repeats(step, seconds)
         res = {"value": round(nb / float(np.median(times)), 2), "unit": "images/s", "kind": "port", **pin,
                "fastest": round(nb / min(times), 2), "slowest": round(nb / max(times), 2), "repeats": len(times),
+               "spread_images_per_s": {"min": round(nb / max(times), 2), "p10": round(nb / float(np.percentile(times, 90)), 2),
+                                       "median": round(nb / float(np.median(times)), 2), "p90": round(nb / float(np.percentile(times, 10)), 2),
+                                       "max": round(nb / min(times), 2)},
                "sample": f"{len(times)} steps of batch {nb} (512x512x3), torch-CPU fp32 forward + loss + autograd backward + Adam; "
                          f"value = median step, {el:.1f} s in all"}
     else:                                                         # "latency": predict.py:73-78 on the CPU stand-in
@@ -544,6 +550,21 @@ def main():
         rect_step()
     rect_ms = timed_wall(rect_step, args.steps) / args.steps * 1e3
     rect_counts = rect_out[0][3].cpu().numpy()
+    # ... and with MANY objects per map: a jittered 8 x 8 grid of small rotated rectangles, ~50 separate objects per image
+    many_maps = [synthetic.crowded_maps(900 + rank + k, BATCH, SIDE // 4, SIDE // 4) for k in range(2)]
+    many_logits = [torch.from_numpy(synthetic.logits_from_maps(many_maps[k], 0, seed=15 + k)).to(dev) for k in range(2)]
+
+    def many_step():
+        step_no[0] += 1
+        k = step_no[0] & 1
+        job = {"logits": many_logits[k], "logit_threshold": runner.logit_threshold, "scale": 4, "min_area": cfg.get_min_pixels_for_detection(),
+               "cap": 1024, "outputs": rect_out[k]}
+        model.predict_on_device(xs[step_no[0] % RING], out=rect_dst, postprocess=job)
+
+    for _ in range(50):
+        many_step()
+    many_ms = timed_wall(many_step, args.steps) / args.steps * 1e3
+    many_counts = rect_out[0][3].cpu().numpy()
 
     # ---- extra: train step (fwd + loss + bwd + gradient all-reduce + Adam), batch/GPU = --train-batch:
     #      configs[2] / configs[3] name bf16 activations (fp32 master weights, fp32 accumulation); the fp32
@@ -681,20 +702,43 @@ def main():
     # ---- extra: the PCIe-inclusive rate -- ModelRunner.predict with HOST numpy input (the reference's calling convention,
     #      model_runner.py:105-138): H2D of the batch, forward, device postprocess, D2H of maps / logits / lists, python lists
     #      of ObjectMarkup.  Never `value` (the bench contract times HBM-resident input); reported so that it is measured.
+
     def time_host_path():
-        res = {"protocol": "ModelRunner.predict(model, numpy batch of 32 x 512 x 512 x 3) -> (maps, class logits, object lists), wall clock, "
-                           "median of 8 after 2 warm-up calls; pageable host memory"}
+        """The reference's real seam, PCIe included (model_runner.py:60-67: ModelRunner.predict batch after batch, numpy in, python object
+        lists out): per-batch ``predict`` (synchronous pageable copies) and ``predict_stream`` (pinned staging ring, copy-in / compute /
+        copy-out streams, the postprocess of batch k inside the stem kernel of batch k + 1).  Never the headline value."""
+        res = {"protocol": "numpy batches of 32 x 512 x 512 x 3 (4 distinct arrays in turn, 1-8 objects per image) -> (maps, class logits, object lists); wall clock; "
+                           "predict: median of 8 calls after 2 warm-up calls; predict_stream: 48 batches in one pipeline after four untimed 24-batch runs (steady state of a streaming job)",
+               "pcie_note": "uint8: 25.2 MB per batch = 0.49 ms at the ~51 GB/s this link sustains (63 GB/s spec) -> <= 65 k img/s; "
+                            "float32: 100.7 MB = 1.97 ms -> <= 16.2 k img/s: the float32 stream runs AT the link rate"}
         hr = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
-        x_u8 = synthetic.textured_images(4 + rank, labels, 4, C_IN)
-        for name, arr in (("uint8", x_u8), ("float32", x_u8.astype(np.float32) / 127.5 - 1.0)):
+        x_u8 = [synthetic.textured_images(4 + rank + 7 * k, labels, 4, C_IN) for k in range(4)]
+        from ubdvss_amd import PreprocessingType
+        # uint8 pixels take the reference's preprocessing (net.py:217-218) fused into the first layer -- raw 0..255 values through
+        # random weights give noise maps with hundreds of specks per image, and the leg would time the building of their python objects
+        model_u8 = Model(NetConfig(grey=False, preprocessing=PreprocessingType.MOBILENET_LIKE), seed=1)
+        model_u8.set_weights(model.get_weights())
+        for name, arrs, mdl in (("uint8", x_u8, model_u8), ("float32", [a.astype(np.float32) / 127.5 - 1.0 for a in x_u8], model)):
             for _ in range(2):
-                hr.predict(model, arr)
+                hr.predict(mdl, arrs[0])
             ts = []
-            for _ in range(8):
-                t0 = time.perf_counter(); hr.predict(model, arr); ts.append(time.perf_counter() - t0)
+            for k in range(8):
+                t0 = time.perf_counter(); last = hr.predict(mdl, arrs[k % 4]); ts.append(time.perf_counter() - t0)
             med = float(np.median(ts))
-            res[name] = {"ms_per_batch": round(med * 1e3, 3), "images_per_s": round(BATCH / med, 1), "h2d_MB": round(arr.nbytes / 1e6, 1)}
+            for _ in range(4):                           # a streaming job's steady state: the first ~100 batches of a process run up to 3 x slower (staging buffers, clocks)
+                list(hr.predict_stream(mdl, [arrs[k % 4] for k in range(24)]))
+            nb = 48
+            t0 = time.perf_counter()
+            n_out = sum(1 for _ in hr.predict_stream(mdl, (arrs[k % 4] for k in range(nb))))
+            per = (time.perf_counter() - t0) / nb
+            assert n_out == nb
+            res[name] = {"ms_per_batch": round(med * 1e3, 3), "images_per_s": round(BATCH / med, 1), "h2d_MB": round(arrs[0].nbytes / 1e6, 1),
+                         "stream_ms_per_batch": round(per * 1e3, 3), "stream_images_per_s": round(BATCH / per, 1),
+                         "stream_host_to_device_GBps": round(arrs[0].nbytes / per / 1e9, 1), "objects_per_image_mean": round(float(np.mean([len(o) for o in last[2]])), 2),
+                         "stream_consumer_thread_ms_per_batch": {k[:-2]: round(v / nb * 1e3, 3) for k, v in hr.last_stream_stats.items() if k.endswith("_s")}}
         return res
+
+
 
     host_path = time_host_path() if (world == 1 and rank == 0) else None
 
@@ -767,7 +811,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "clock_settle_steps": max(0, SETTLE_STEPS - args.warmup), "input_ring_MB": input_ring_mb,
             "ms_per_step_single_tensor": round(single_ms, 4),
-            "ms_per_step_rect_maps": round(rect_ms, 4),
+            "ms_per_step_rect_maps": round(rect_ms, 4), "ms_per_step_many_object_maps": round(many_ms, 4),
             "config": {"workload": "configs[1]: batch=32 512x512x3 fp32 forward + CCL postprocess per GPU "
                                    "(stripe-textured rectangle images, random-init weights)",
                        "batch_per_gpu": BATCH, "image": [SIDE, SIDE, C_IN], "parallelism": f"replicas x{world}, no collective"},
@@ -776,6 +820,7 @@ def main():
                       "postprocess_ms_on_rectangle_maps": round(post_rect_ms, 4),
                       "objects_found_mean": float(counts.mean()), "objects_found_max": int(counts.max()),
                       "rect_maps_objects_found_mean": float(rect_counts.mean()), "rect_maps_objects_found_max": int(rect_counts.max()),
+                      "many_object_maps_objects_found_mean": float(many_counts.mean()), "many_object_maps_objects_found_max": int(many_counts.max()),
                       "clock_settle_launches": SETTLE_STEPS},
         }
     if dist is not None and not args.no_train:

@@ -428,3 +428,14 @@ def test_pipelined_runner_16bit_model_falls_back_to_back_to_back_calls():
     got = [piped.predict_on_device(model, b) for b in batches]
     piped.synchronize()
     assert _same_results(got[2], ref[2]) and _same_results(got[1], ref[1])
+
+
+def test_crowded_maps_vs_oracle():
+    """About fifty separate objects per 128 x 128 map (synthetic.crowded_maps: the bench's many-object leg): counts and quads
+    bit-exact against the oracle on every map, in every code path."""
+    maps = synthetic.crowded_maps(77, 6, 128, 128)
+    lg = synthetic.logits_from_maps(maps, 0, seed=78, noise=0.0)
+    model = _model(0)
+    _compare(model, lg, 0, cap=256)
+    _, out, counts = _run(model, lg, cap=256)
+    assert 40 <= int(counts.min()) and int(counts.max()) <= 64

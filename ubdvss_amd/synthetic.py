@@ -36,16 +36,40 @@ def random_quads(rng, map_h, map_w, n_min=1, n_max=8, side_min=6, side_max=60):
     return quads
 
 
-def rectangle_maps(seed, n, map_h, map_w, n_classes=0):
-    """(n, map_h, map_w) int32 label maps: 0 background, 1..max(n_classes,1) objects."""
+def rectangle_maps(seed, n, map_h, map_w, n_classes=0, n_min=1, n_max=8, side_min=6, side_max=60):
+    """(n, map_h, map_w) int32 label maps: 0 background, 1..max(n_classes,1) objects (n_min..n_max rotated rectangles per map,
+    sides side_min..side_max pixels at 128 x 128; overlapping rectangles merge into one object)."""
     rng = np.random.default_rng(seed)
     out = np.zeros((n, map_h, map_w), np.int32)
     for i in range(n):
         im = Image.new(mode='L', size=(map_w, map_h), color=0)
         draw = ImageDraw.Draw(im)
-        for q in random_quads(rng, map_h, map_w):
+        for q in random_quads(rng, map_h, map_w, n_min, n_max, side_min, side_max):
             fill = int(rng.integers(1, n_classes + 1)) if n_classes > 0 else 1
             draw.polygon([(int(round(x)), int(round(y))) for x, y in q], fill=fill)
+        out[i] = np.asarray(im, dtype=np.int32)
+    return out
+
+
+def crowded_maps(seed, n, map_h, map_w, cells=8, fill=0.8):
+    """(n, map_h, map_w) int32 {0,1} maps with MANY separate objects: one small rotated rectangle (sides 25-55 % of a cell) in ``fill`` of the
+    cells of a ``cells`` x ``cells`` grid, jittered inside its cell so that neighbours do not touch -- about 50 objects per map at 8 x 8."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n, map_h, map_w), np.int32)
+    ch, cw = map_h / cells, map_w / cells
+    for i in range(n):
+        im = Image.new(mode='L', size=(map_w, map_h), color=0)
+        draw = ImageDraw.Draw(im)
+        for gy in range(cells):
+            for gx in range(cells):
+                if rng.uniform() > fill:
+                    continue
+                a, b = rng.uniform(0.25, 0.55) * cw, rng.uniform(0.25, 0.55) * ch
+                ang = rng.uniform(0, np.pi)
+                cx, cy = (gx + rng.uniform(0.42, 0.58)) * cw, (gy + rng.uniform(0.42, 0.58)) * ch
+                ca, sa = np.cos(ang), np.sin(ang)
+                pts = [(cx + dx * ca - dy * sa, cy + dx * sa + dy * ca) for dx, dy in ((-a / 2, -b / 2), (a / 2, -b / 2), (a / 2, b / 2), (-a / 2, b / 2))]
+                draw.polygon([(int(round(x)), int(round(y))) for x, y in pts], fill=1)
         out[i] = np.asarray(im, dtype=np.int32)
     return out
 
