@@ -59,6 +59,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         // the small shapes the CPU oracle can check (tests/test_gpu_persistent.py; ubd_num_cus reports what was taken)
         { const char *c = getenv("UBD_TEST_NUM_CUS"); if (c && atoi(c) > 0) h->num_cus = atoi(c); }
         { const char *b = getenv("UBD_DILBWD"); h->split_dilbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; h->no_pair_dilbwd = (b && strcmp(b, "pair8") == 0) ? 1 : 0; }
+        { const char *b = getenv("UBD_SEPBWD"); h->split_sepbwd32 = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_STEM16"); h->split_stem16 = (b && strcmp(b, "split") == 0) ? 1 : ((b && strcmp(b, "fused12") == 0) ? 2 : 0); }   // 0: L1 -> L2 -> L3 in one kernel, 2: L1 -> L2 fused + L3, 1: three kernels
         // postprocess test hooks (multi-launch front end at any map size / separate tail launches / LDS poisoning + forest integrity
         // check / one-lane box fit / the 512-thread block shape the job has inside the stem kernel)

@@ -531,21 +531,35 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
         const int nsteps = rows_eff * grp_eff;
         const TX *xt = (const TX *)buf;
         const float *gt = (const float *)((const char *)buf + XBYTES);
-        for (int s = wid; s < nsteps; s += 4) {
+        // operands of k-step s (14 A values: (tap, ci) rows of the lane's sub-pixel; 2 B values: its gradient channels); the loads of
+        // step s + 4 are issued in front of the 28 MFMAs of step s (round 5: the wave used to wait for every step's LDS round trip)
+        auto ld_step = [&](int s, float (&a)[14], float &b0, float &b1) {
             const int py = (int)((unsigned)s / (unsigned)grp_eff), pg = s - py * grp_eff;
             const int px = pg * 4 + k;                                 // this lane's sub-pixel column
             const TX *xp = xt + (py * WG_XW + px) * UBD_C;             // X-tile pixel of tap (0,0)
             const float *gp = gt + (py * WG_TW + px) * UBD_C;
-            const float b0 = gp[m];
-            const float b1 = m < 8 ? gp[16 + m] : 0.f;
-            float a[14];
+            b0 = gp[m];
+            b1 = m < 8 ? gp[16 + m] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < 13; ++mt) a[mt] = (float)xp[aoff[mt]];
             a[13] = row13_real ? (float)xp[aoff[13]] : (row13_ones ? 1.f : 0.f);
+        };
+        float a0[14], a1[14], b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
+        int s = wid;
+        if (s < nsteps) ld_step(s, a0, b00, b01);
+        for (; s < nsteps; s += 8) {
+            if (s + 4 < nsteps) ld_step(s + 4, a1, b10, b11);
 #pragma unroll
             for (int mt = 0; mt < 14; ++mt) {
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b0, acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt], b00, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt], b01, acc[mt][1], 0, 0, 0);
+            }
+            if (s + 4 >= nsteps) break;
+            if (s + 8 < nsteps) ld_step(s + 8, a0, b00, b01);
+#pragma unroll
+            for (int mt = 0; mt < 14; ++mt) {
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b10, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b11, acc[mt][1], 0, 0, 0);
             }
         }
     }
@@ -572,13 +586,24 @@ template <int CIN, int STRIDE, int XB> struct sepb_cfg {          // XB = bytes 
 
 // TX: element type of a 24-channel input patch; TR: activation type of the model (16-bit: kernels and the depthwise
 // output are used rounded to TR, as in the forward pass)
-template <int CIN, int STRIDE, int IN_U8, typename TX, typename TR>
+// UPS > 0 (round 5, fp32 gradient path): the G tile is COMPUTED in the block instead of being read -- `G` then points at this layer's own
+// output activation (the ReLU mask source, same shape as G), `up_ddw` at the dDW tensor of the layer above (stride UPS, top/left padding
+// up_pad, map up_oh x up_ow) and `up_dw` at that layer's depthwise kernel [9][24]:
+//     G[p][c] = (A[p][c] > 0) * sum_t dDW_up[(p + up_pad - t) / UPS][c] * dw_up[t][c]        (taps in sep_dx_kernel's order: the same bits)
+// i.e. sep_dx_kernel's arithmetic on the tile, so that kernel's launch -- 403 MB read + 403 MB mask + 403 MB written per separable
+// layer at 64 images -- and the G tensor itself disappear.
+template <int CIN, int STRIDE, int IN_U8, typename TX, typename TR, int UPS = 0>
 __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
                                                       const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
-                                                      int OH, int OW, int pad_lo, float pre_sub, float pre_div)
+                                                      int OH, int OW, int pad_lo, float pre_sub, float pre_div,
+                                                      const float *__restrict__ up_ddw = nullptr, const float *__restrict__ up_dw = nullptr,
+                                                      int up_oh = 0, int up_ow = 0, int up_pad = 0)
 {
     using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
+    static_assert(UPS == 0 || sizeof(TX) == 4 || CIN != UBD_C, "the in-block G tile needs an fp32 mask tile of G's size");
+    constexpr int UPH = UPS == 1 ? C::TH + 2 : C::TH / 2 + 2, UPW = UPS == 1 ? 18 : 10;      // patch of the upper layer's dDW
+    __shared__ __attribute__((aligned(16))) float s_up[UPS > 0 ? UPH * UPW * UBD_C + 9 * UBD_C : 4];
     constexpr int CPL = (CIN == UBD_C) ? 6 : 1;
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;           // tiles of the dDW product
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;          // M tiles of the dpw product (CIN rows + ones row)
@@ -686,6 +711,50 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
             }
         }
 
+        if constexpr (UPS > 0) {
+            // ---- the G tile from the layer above: its dDW patch (zeros outside its map) and its depthwise kernel into LDS, then every
+            //      thread turns six 4-channel chunks of the mask tile into G in place
+            float *upk = s_up + UPH * UPW * UBD_C;
+            const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            for (int e = threadIdx.x; e < UPH * UPW * 6; e += 256) {
+                const int pix = e / 6, part = e - pix * 6;
+                const int pr = pix / UPW, pc = pix - pr * UPW;
+                const int gy = uy0 + pr, gx = ux0 + pc;
+                f32x4 v = zero4;
+                if (gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow) v = *(const f32x4 *)(up_ddw + (((size_t)img * up_oh + gy) * up_ow + gx) * UBD_C + 4 * part);
+                *(f32x4 *)(s_up + pix * UBD_C + 4 * part) = v;
+            }
+            if (threadIdx.x < 9 * UBD_C) upk[threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);
+            __syncthreads();
+            for (int e = threadIdx.x; e < C::GPIX * 6; e += 256) {
+                const int pix = e / 6, part = e - pix * 6;
+                const int py = oy0 + (pix >> 4) + up_pad, px = ox0 + (pix & 15) + up_pad;
+                f32x4 acc = zero4;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ty = py - ky;
+                    const bool yok = ty >= 0 && (UPS == 1 || (ty & 1) == 0) && (ty / UPS) < up_oh;
+                    const int ur = (UPS == 1 ? ty : (ty >> 1)) - uy0;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int tx = px - kx;
+                        const bool ok = yok && tx >= 0 && (UPS == 1 || (tx & 1) == 0) && (tx / UPS) < up_ow;
+                        if (ok) {
+                            const int uc = (UPS == 1 ? tx : (tx >> 1)) - ux0;
+                            const f32x4 v = *(const f32x4 *)(s_up + (ur * UPW + uc) * UBD_C + 4 * part);
+                            const f32x4 wv = *(const f32x4 *)(upk + (ky * 3 + kx) * UBD_C + 4 * part);
+                            acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
+                            acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
+                        }
+                    }
+                }
+                f32x4 *pg = (f32x4 *)(gtile + pix * UBD_C + 4 * part);
+                const f32x4 mk = *pg;
+                *pg = (f32x4){mk[0] > 0.f ? acc[0] : 0.f, mk[1] > 0.f ? acc[1] : 0.f, mk[2] > 0.f ? acc[2] : 0.f, mk[3] > 0.f ? acc[3] : 0.f};
+            }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int r = wid; r < C::TH; r += 4) {
             const int oy = oy0 + r;
@@ -961,24 +1030,27 @@ extern "C" size_t ubd_train_workspace_bytes(const ubd_handle *h, int n, int heig
     return T.total;
 }
 
-template <int CIN, int STRIDE, typename TX, typename TR = TX>
+// UPS > 0: G is computed in the kernel from the layer above (G = this layer's output activation, the mask source; up_*: see the kernel)
+template <int CIN, int STRIDE, typename TX, typename TR = TX, int UPS = 0>
 static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const float *G, float *dDW, const float *ffrag,
                            const float *bfrag, float *g_dw, float *g_pw, float *g_b, rp_queue *rq, int n, int H, int W,
-                           int OH, int OW, int pad_lo, float sub, float div, hipStream_t st)
+                           int OH, int OW, int pad_lo, float sub, float div, hipStream_t st,
+                           const float *up_ddw = nullptr, const float *up_dw = nullptr, int up_oh = 0, int up_ow = 0, int up_pad = 0)
 {
     using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
     const int th = C::TH;
     const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
-    const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float);
+    const size_t up_bytes = UPS == 0 ? 16 : ((UPS == 1 ? (size_t)(th + 2) * 18 : (size_t)(th / 2 + 2) * 10) * UBD_C + 9 * UBD_C) * sizeof(float);
+    const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float) + up_bytes;
     int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
     if (grid > tiles) grid = (int)tiles;
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
     float *partials = rp_add(rq, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
     if (!partials) return -1;
     if (in_u8)
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad);
     else
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad);
     return 0;
 }
 
@@ -1222,6 +1294,30 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
     const float *bs0 = bfrag + UBD_BWD_DGRAD_FLOATS, *bs1 = bs0 + UBD_BWD_SEP_FLOATS, *bs2 = bs1 + UBD_BWD_SEP_FLOATS;
     // L3: input a2 (H2 x W2), output H4 x W4, G = gq[cur]
     if (launch_sep_bwd<UBD_C, 2, TX>(h, a2, 0, gq[cur], ddw3, sf2, bs2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2], grads + h->off_sep_b[2], &rq, n, H2, W2, H4, W4, pad_s2, 0.f, 1.f, st)) return -1;
+    float sub = 0.f, div = 1.f;
+    if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
+    const int u8 = in_dtype == UBD_IN_U8;
+    int rc1;
+    if constexpr (sizeof(TX) == 4) {
+        // fp32 activations (round 5): L2's and L1's kernels build their G tiles themselves from the dDW tensor of the layer above and
+        // their own output activation (the ReLU mask) -- no sep_dx launches, no G tensors (UBD_SEPBWD=split keeps the two-kernel form)
+        if (!h->split_sepbwd32) {
+            const float *dwk2 = params + h->off_sep_dw[2], *dwk1 = params + h->off_sep_dw[1];
+            if (launch_sep_bwd<UBD_C, 1, TX, TX, 2>(h, a1, 0, (const float *)a2, gb[1], sf1, bs1, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1], grads + h->off_sep_b[1], &rq, n, H2, W2, H2, W2, 1, 0.f, 1.f, st,
+                                                    ddw3, dwk2, H4, W4, pad_s2)) return -1;
+            if (h->cfg.c_in == 1)
+                rc1 = launch_sep_bwd<1, 2, float, TX, 1>(h, images, u8, (const float *)a1, nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad_s2, sub, div, st,
+                                                         gb[1], dwk1, H2, W2, 1);
+            else
+                rc1 = launch_sep_bwd<3, 2, float, TX, 1>(h, images, u8, (const float *)a1, nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad_s2, sub, div, st,
+                                                         gb[1], dwk1, H2, W2, 1);
+            if (rc1) return -1;
+            rp_flush(&rq, st);
+            UBD_CHECK_HIP(hipGetLastError());
+            if (ubd_comm_fused(h)) return ubd_comm_finish(h, grads, st);
+            return 0;
+        }
+    }
     {
         const long tiles = (long)n * H2 * ((W2 + 15) / 16);
         const int g3 = ubd_grid_for(tiles, h->num_cus, 4, 8);
@@ -1231,10 +1327,6 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         hipLaunchKernelGGL((sep_dx_kernel<1, TX>), dim3(g3), dim3(256), 0, st, gb[1], a1, gb[0], sf1, n, H2, W2, H2, W2, 1);
     }
     // L1: input = images (fp32 / uint8), no data gradient
-    float sub = 0.f, div = 1.f;
-    if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
-    const int u8 = in_dtype == UBD_IN_U8;
-    int rc1;
     if (h->cfg.c_in == 1)
         rc1 = launch_sep_bwd<1, 2, float, TX>(h, images, u8, gb[0], nullptr, sf0, bs0, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0], grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad_s2, sub, div, st);
     else

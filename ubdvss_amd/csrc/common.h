@@ -28,6 +28,7 @@ struct ubd_handle {
     int split_stem16;         // UBD_STEM16=split: 16-bit pass with separate L1 and L2 kernels (diagnostics / tests)
     int pp_global, pp_split, pp_poison, pp_serial_tail, pp_threads_512;   // UBD_PP_* test hooks, read ONCE in ubd_create (never in the launch path)
     int sepb_x_regs;          // UBD_SEPB16_X=regs: bf16 backward of L1 stages its fp32 input patch through registers even where LDS-DMA applies (diagnostics / tests)
+    int split_sepbwd32;       // UBD_SEPBWD=split: fp32 train step with the stand-alone data-gradient kernels of the separable layers (sep_dx_kernel) instead of G tiles built inside the weight-gradient kernels (diagnostics / tests)
     int chain_reduce;         // bf16 train step: weight-gradient kernels total the previous producer's partial rows at their end (default; UBD_REDUCE=batched: the two stand-alone launches)
     int direct_dil16;         // UBD_DILCONV16=direct: 16-bit forward dilated layers with the direct (unstaged) kernel (diagnostics / tests)
     int fuse_stem;            // inference stem: 2 = L1 -> L2 -> L3 in one kernel (default with fml padding), 1 = L2 -> L3 fused, 0 = three kernels (UBD_STEM=fused123|fused|unfused)
