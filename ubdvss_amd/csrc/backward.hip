@@ -717,13 +717,29 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
             float *upk = s_up + UPH * UPW * UBD_C;
             const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            for (int e = threadIdx.x; e < UPH * UPW * 6; e += 256) {
-                const int pix = e / 6, part = e - pix * 6;
-                const int pr = pix / UPW, pc = pix - pr * UPW;
-                const int gy = uy0 + pr, gx = ux0 + pc;
-                f32x4 v = zero4;
-                if (gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow) v = *(const f32x4 *)(up_ddw + (((size_t)img * up_oh + gy) * up_ow + gx) * UBD_C + 4 * part);
-                *(f32x4 *)(s_up + pix * UBD_C + 4 * part) = v;
+            {
+                // all of a thread's chunk loads first, then the LDS stores: one memory round trip per tile (as a load -> store loop the
+                // staging was a chain of up to eight)
+                constexpr int UR = (UPH * UPW * 6 + 255) / 256;
+                f32x4 uv[UR];
+                const float *ubase = up_ddw + (size_t)img * up_oh * up_ow * UBD_C;
+#pragma unroll
+                for (int k = 0; k < UR; ++k) {
+                    const int e = k * 256 + (int)threadIdx.x;
+                    const int ec = e < UPH * UPW * 6 ? e : UPH * UPW * 6 - 1;
+                    const int pix = ec / 6, part = ec - pix * 6;
+                    const int pr = pix / UPW, pc = pix - pr * UPW;
+                    const int gy = uy0 + pr, gx = ux0 + pc;
+                    const bool in = gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow;
+                    const int gyc = gy < 0 ? 0 : (gy >= up_oh ? up_oh - 1 : gy), gxc = gx < 0 ? 0 : (gx >= up_ow ? up_ow - 1 : gx);
+                    const f32x4 ld = *(const f32x4 *)(ubase + ((size_t)gyc * up_ow + gxc) * UBD_C + 4 * part);     // clamped: unconditional load
+                    uv[k] = in ? ld : zero4;
+                }
+#pragma unroll
+                for (int k = 0; k < UR; ++k) {
+                    const int e = k * 256 + (int)threadIdx.x;
+                    if (e < UPH * UPW * 6) *(f32x4 *)(s_up + e * 4) = uv[k];             // chunk e of the patch: pixel e / 6, channels 4 (e % 6) ..
+                }
             }
             if (threadIdx.x < 9 * UBD_C) upk[threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);
             __syncthreads();
