@@ -57,16 +57,23 @@ template <int N, int BF, int NT> __global__ __launch_bounds__(NT) void k(float *
 template <int N, int BF, int NT> void run(float *out, float *in, unsigned long long *cyc)
 {
     const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<N, BF, NT><<<256, NT>>>(out, in, cyc, iters);        // warm
+    hipEventRecord(e0, 0);
     k<N, BF, NT><<<256, NT>>>(out, in, cyc, iters);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256 * 16];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double mx = 0;
     const int nw = NT / 64;
     for (int b = 0; b < 256; ++b) for (int w = 0; w < nw; ++w) mx += (double)h[b * 16 + w];
     mx /= 256.0 * nw;
-    printf("%s + %d fillers each, %d waves/SIMD: %6.1f cycles per slot and wave, %6.1f per slot and SIMD\n", BF == 0 ? "f32 MFMA 16x16x4  " : BF == 1 ? "bf16 MFMA 16x16x32" : "no MFMA           ",
-           N, NT / 256, mx / iters / 8, mx / iters / 8 / (NT / 256));
+    printf("%s + %d fillers each, %d waves/SIMD: %6.1f cycles per slot and wave, %6.1f per slot and SIMD; wall clock %6.2f ns per slot and SIMD (s_memtime ticks at %.2f GHz)\n", BF == 0 ? "f32 MFMA 16x16x4  " : BF == 1 ? "bf16 MFMA 16x16x32" : "no MFMA           ",
+           N, NT / 256, mx / iters / 8, mx / iters / 8 / (NT / 256), ms * 1e6 / iters / 8 / (NT / 256), mx / (ms * 1e6));
 }
 #define RUN3(N, BF) run<N, BF, 256>(out, in, cyc); run<N, BF, 512>(out, in, cyc); run<N, BF, 1024>(out, in, cyc)
 int main()

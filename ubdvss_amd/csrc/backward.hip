@@ -158,20 +158,22 @@ __device__ __forceinline__ void rp_reduce_tail(const rp_job &J, float *s)
 // ([216*24 kernel gradient | 24 bias gradient]).  Waves take turns adding into one lane-linear LDS image
 // (ds_read/write_b128, conflict-free): LDS float atomics cost ~3 cycles per LANE on gfx950 and made this epilogue
 // the longest phase of the kernel.
-__device__ __forceinline__ void wgrad_block_reduce(const f32x4 (&acc)[14][2], float *__restrict__ red /* 28 KiB */,
-                                                   float *__restrict__ prow, int lane, int wid)
+// MT: accumulator tiles per wave, starting at M tile mt0 (a block of 4 x (14 / MT) waves: `ks` = the wave's k-step class, the order of the sum)
+template <int MT = 14>
+__device__ __forceinline__ void wgrad_block_reduce(const f32x4 (&acc)[MT][2], float *__restrict__ red /* 28 KiB */,
+                                                   float *__restrict__ prow, int lane, int ks, int mt0 = 0)
 {
     f32x4 *img = (f32x4 *)red;                         // [(mt, nt)][lane] x 4 floats (r)
     __syncthreads();                                   // tile buffers are free now
     for (int ph = 0; ph < 4; ++ph) {
-        if (wid == ph) {
+        if (ks == ph) {
 #pragma unroll
-            for (int mt = 0; mt < 14; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     f32x4 v = acc[mt][nt];
-                    if (ph > 0) v += img[(mt * 2 + nt) * 64 + lane];
-                    img[(mt * 2 + nt) * 64 + lane] = v;
+                    if (ph > 0) v += img[((mt0 + mt) * 2 + nt) * 64 + lane];
+                    img[((mt0 + mt) * 2 + nt) * 64 + lane] = v;
                 }
         }
         __syncthreads();
@@ -427,27 +429,38 @@ __global__ __launch_bounds__(256) void head_wgrad1_kernel(const void *__restrict
 #define WG_ROUNDS 8                            // (180 * 6 + 128 * 6 + 255) / 256 with fp32 activations (7 with 16-bit)
 #define WG_BUF_FLOATS (WG_ROUNDS * 256 * 4)    // 8192 floats = 32 KiB
 
-template <typename TX>
-__global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restrict__ x, const float *__restrict__ gz,
+// MS = 2 (round 5, fp32 activations): the block has EIGHT waves -- wave (ks = wid & 3, mh = wid >> 2) takes the k-steps ks, ks + 4, ... like
+// before but only the seven M tiles 7 mh .. 7 mh + 6 of them (56 accumulator registers instead of 112, < 128 in all): two blocks per CU are
+// then four waves per SIMD, where the fp32 MFMA issues every ~20 cycles per SIMD instead of every ~25-32 at two (tools/ubench/mfma_fill.hip).
+// The sums are the same numbers added in the same order (k-step classes 0..3 per accumulator tile): bit-identical to MS = 1.
+template <typename TX, int MS = 1>
+__global__ __launch_bounds__(256 * MS, 2 * MS) void dil_wgrad_kernel(const void *__restrict__ x, const float *__restrict__ gz,
                                                            float *__restrict__ partials, int n, int h,
                                                            int w, int d)
 {
+    constexpr int NTH = 256 * MS, MT = 14 / MS;                    // threads per block, M tiles per wave
     __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF_FLOATS];     // 64 KiB: two tile buffers / final reduction
+    __shared__ TX s_one[4];                                                     // 1.0: the A value of the ones row (bias gradient)
+    if (threadIdx.x < 4) s_one[threadIdx.x] = (TX)1.f;                          // visible after the first item's barrier
     const int lane = threadIdx.x & 63, m = lane & 15, k = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ks = wid & 3, mh = wid >> 2;                         // k-step class, M half (MS = 1: mh = 0)
     constexpr int XCH = (int)sizeof(TX) * UBD_C / 16;              // 16-byte chunks per X pixel: 6 (fp32) or 3 (16-bit)
     constexpr int WG_CHUNKS = WG_XPIX * XCH + WG_GPIX * 6;
     constexpr int XBYTES = WG_XPIX * UBD_C * (int)sizeof(TX);      // G tile starts here (multiple of 16)
 
     // A-operand rows of the 14 M-tiles: dword offset of (tap, ci) relative to the X-tile pixel of the output position
-    int aoff[14];
+    int aoff[MT];
 #pragma unroll
-    for (int mt = 0; mt < 14; ++mt) {
-        const int rho = 16 * mt + m;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rho = 16 * (mt + mh * MT) + m;
         const int t = rho / UBD_C, ci = rho % UBD_C;
         aoff[mt] = ((t / 3) * WG_XW + (t % 3)) * UBD_C + ci;          // rows >= 216 are never read (see below)
     }
-    const bool row13_real = m < 8, row13_ones = m == 8;
+    // the last M tile (rows 208..223) holds 8 real rows, the ones row (bias gradient) and zeros: only the wave that owns it treats it specially
+    const bool last_tile = mh == MS - 1;                                        // wave-uniform
+    const bool row13_real = !last_tile || m < 8, row13_ones = last_tile && m == 8;
+    const int aoff13c = row13_real ? aoff[MT - 1] : aoff[MT - 2];               // a valid offset for every lane (rows >= 216 read a neighbour's, unused)
 
     // work items
     const int sh = (h + d - 1) / d, sw = (w + d - 1) / d;              // largest sub-grid
@@ -476,21 +489,40 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
         gy = I.ry + (I.sy0 + sy) * d;
         gx = I.rx + (I.sx0 + sx) * d;
     };
-    auto dma_item = [&](int it, float *buf) {
+    // which pixel / 16-byte part a thread moves in round rd does not depend on the item: decoded ONCE (the divisions by 6, 18, 16 per round
+    // and item were ~100 of the ~500 non-MFMA instructions a wave spends per item; round 5)
+    constexpr int ROUNDS = (WG_CHUNKS + NTH - 1) / NTH;
+    int cpk[ROUNDS];                                                   // (sy + 1) | (sx + 1) << 8 | part << 16 | is_x << 24
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        int c = rd * NTH + (int)threadIdx.x;
+        c = c < WG_CHUNKS ? c : WG_CHUNKS - 1;
+        const bool is_x = c < WG_XPIX * XCH;
+        int sy, sx, part;
+        if (is_x) { const int pix = c / XCH; part = c - pix * XCH; sy = pix / WG_XW - 1; sx = pix % WG_XW - 1; }
+        else { const int cg = c - WG_XPIX * XCH; const int gp = cg / 6; part = cg - gp * 6; sy = gp / WG_TW; sx = gp % WG_TW; }
+        cpk[rd] = (sy + 1) | ((sx + 1) << 8) | (part << 16) | ((is_x ? 1 : 0) << 24);
+    }
+    const unsigned lds_smem = ubd_lds_addr(smem);
+    auto dma_item = [&](int it, int buf_floats) {
         const item_t I = decode(it);
-        constexpr int ROUNDS = (WG_CHUNKS + 255) / 256;
+        const char *xim = (const char *)x + (size_t)I.img * h * w * (UBD_C * sizeof(TX));
+        const char *gim = (const char *)gz + (size_t)I.img * h * w * (UBD_C * sizeof(float));
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int cbase = rd * 256 + wid * 64;
-            bool is_x; int gy, gx, part;
-            chunk_src(I, cbase + lane, is_x, gy, gx, part);
+            const int cbase = rd * NTH + wid * 64;
+            const int pk = cpk[rd];
+            const int sy = (pk & 255) - 1, sx = ((pk >> 8) & 255) - 1, part = (pk >> 16) & 255;
+            const bool is_x = (pk >> 24) != 0;
+            int gy = I.ry + (I.sy0 + sy) * d, gx = I.rx + (I.sx0 + sx) * d;
             gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                 // clamped; out-of-image pixels are zeroed later
             gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-            const size_t pixel = ((size_t)I.img * h + gy) * w + gx;
-            const char *src = is_x ? (const char *)x + pixel * (UBD_C * sizeof(TX)) + part * 16
-                                   : (const char *)gz + pixel * (UBD_C * sizeof(float)) + part * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(buf + cbase * 4), 16, 0, 0);
+            const unsigned pixel = (unsigned)(gy * w + gx);
+            const char *src = is_x ? xim + (size_t)pixel * (UBD_C * sizeof(TX)) + part * 16
+                                   : gim + (size_t)pixel * (UBD_C * sizeof(float)) + part * 16;
+            // the asm form (common.h): hipcc orders every LDS read behind a builtin LDS-DMA in flight (s_waitcnt vmcnt(0) in front of the
+            // first operand load), which put the next item's whole fetch in front of this item's MFMAs (round 5: 161 -> see DESIGN 5.4)
+            ubd_glds16_at(src, lds_smem + (unsigned)(buf_floats + cbase * 4) * 4u);
         }
     };
 
@@ -500,19 +532,20 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
     const int chunk = (items + 7) >> 3;
     const int it_begin = xcd * chunk;
     const int it_end = it_begin + chunk < items ? it_begin + chunk : items;
-    f32x4 acc[14][2] = {};
+    f32x4 acc[MT][2] = {};
     int it = it_begin + (int)(blockIdx.x >> 3);
-    if (it < it_end) dma_item(it, smem);
+    if (it < it_end) dma_item(it, 0);
     for (int iter = 0; it < it_end; ++iter, it += nblk_x) {
         float *buf = smem + (iter & 1) * WG_BUF_FLOATS;
         const item_t I = decode(it);
-        __syncthreads();                              // this item's DMA landed; everyone left the other buffer
-        if (it + nblk_x < it_end) dma_item(it + nblk_x, smem + ((iter + 1) & 1) * WG_BUF_FLOATS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's DMA (issued one item ago, as asm) has landed
+        __syncthreads();                              // ... for every wave; everyone left the other buffer
+        if (it + nblk_x < it_end) dma_item(it + nblk_x, ((iter + 1) & 1) * WG_BUF_FLOATS);
         // zero the pixels that lie outside the image (halo / ragged sub-grid edge)
         const bool ragged = (I.ry + (I.sy0 - 1) * d < 0) || (I.rx + (I.sx0 - 1) * d < 0) ||
                             (I.ry + (I.sy0 + WG_TH) * d >= h) || (I.rx + (I.sx0 + WG_TW) * d >= w);   // block-uniform
         if (ragged) {
-            for (int pix = threadIdx.x; pix < WG_XPIX + WG_GPIX; pix += 256) {
+            for (int pix = threadIdx.x; pix < WG_XPIX + WG_GPIX; pix += NTH) {
                 bool is_x; int gy, gx, part;
                 const bool xp_ = pix < WG_XPIX;
                 chunk_src(I, xp_ ? pix * XCH : WG_XPIX * XCH + (pix - WG_XPIX) * 6, is_x, gy, gx, part);
@@ -533,45 +566,52 @@ __global__ __launch_bounds__(256, 2) void dil_wgrad_kernel(const void *__restric
         const float *gt = (const float *)((const char *)buf + XBYTES);
         // operands of k-step s (14 A values: (tap, ci) rows of the lane's sub-pixel; 2 B values: its gradient channels); the loads of
         // step s + 4 are issued in front of the 28 MFMAs of step s (round 5: the wave used to wait for every step's LDS round trip)
-        auto ld_step = [&](int s, float (&a)[14], float &b0, float &b1) {
+        auto ld_step = [&](int s, float (&a)[MT], float &b0, float &b1) {
             const int py = (int)((unsigned)s / (unsigned)grp_eff), pg = s - py * grp_eff;
             const int px = pg * 4 + k;                                 // this lane's sub-pixel column
             const TX *xp = xt + (py * WG_XW + px) * UBD_C;             // X-tile pixel of tap (0,0)
             const float *gp = gt + (py * WG_TW + px) * UBD_C;
+            // every load unconditional and NO select after a load: an exec-masked load or a v_cndmask on a loaded value sits in the block
+            // of the loads, and hipcc then waits for all of them (lgkmcnt(0)) before the MFMAs of the step in front -- the prefetch
+            // would be gone.  Lanes without a value read a finite neighbour's: columns >= 8 of the second N tile and rows >= 217 are never
+            // stored (wgrad_block_reduce), and the ones row (bias gradient) reads a 1.0 kept in LDS (the select is on the ADDRESS).
             b0 = gp[m];
-            b1 = m < 8 ? gp[16 + m] : 0.f;
+            b1 = gp[16 + (m & 7)];
 #pragma unroll
-            for (int mt = 0; mt < 13; ++mt) a[mt] = (float)xp[aoff[mt]];
-            a[13] = row13_real ? (float)xp[aoff[13]] : (row13_ones ? 1.f : 0.f);
+            for (int mt = 0; mt < MT - 1; ++mt) a[mt] = (float)xp[aoff[mt]];
+            const TX *p13 = row13_ones ? (const TX *)s_one : xp + aoff13c;
+            a[MT - 1] = (float)*p13;
         };
-        float a0[14], a1[14], b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
-        int s = wid;
+        float a0[MT], a1[MT], b00 = 0.f, b01 = 0.f, b10 = 0.f, b11 = 0.f;
+        int s = ks;
         if (s < nsteps) ld_step(s, a0, b00, b01);
         for (; s < nsteps; s += 8) {
             if (s + 4 < nsteps) ld_step(s + 4, a1, b10, b11);
 #pragma unroll
-            for (int mt = 0; mt < 14; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt], b00, acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt], b01, acc[mt][1], 0, 0, 0);
             }
             if (s + 4 >= nsteps) break;
             if (s + 8 < nsteps) ld_step(s + 8, a0, b00, b01);
 #pragma unroll
-            for (int mt = 0; mt < 14; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b10, acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b11, acc[mt][1], 0, 0, 0);
             }
         }
     }
-    wgrad_block_reduce(acc, smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, wid);
+    wgrad_block_reduce<MT>(acc, smem, partials + (size_t)blockIdx.x * (217 * UBD_C), lane, ks, mh * MT);
 }
 
 // ------------------------------------------------------------------------------------ separable backward
 // Persistent blocks over output tiles of 16 columns x TH rows (as the forward sepconv_kernel): the input
 // patch and the G tile are staged in LDS (24 channels: LDS-DMA, clamped + zero-fixed at the image border;
 // 1/3 channels: converted on the way through registers), every tap and both G layouts are then read from LDS.
-template <int CIN, int STRIDE, int XB> struct sepb_cfg {          // XB = bytes per element of a 24-channel input
-    static constexpr int TH = (CIN == UBD_C && STRIDE == 2) ? 8 : 16;
+template <int CIN, int STRIDE, int XB, int UPS = 0> struct sepb_cfg {          // XB = bytes per element of a 24-channel input
+    // 1/3-channel layer with the in-block G tile (fp32 gradient path): 8-row tiles, 43 KB of LDS -- THREE blocks per CU instead of two (the
+    // kernel waits for memory two thirds of its time, PMC round 5)
+    static constexpr int TH = ((CIN == UBD_C && STRIDE == 2) || (CIN != UBD_C && UPS > 0)) ? 8 : 16;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int XPIX = PH * PW;
@@ -593,14 +633,14 @@ template <int CIN, int STRIDE, int XB> struct sepb_cfg {          // XB = bytes 
 // i.e. sep_dx_kernel's arithmetic on the tile, so that kernel's launch -- 403 MB read + 403 MB mask + 403 MB written per separable
 // layer at 64 images -- and the G tensor itself disappear.
 template <int CIN, int STRIDE, int IN_U8, typename TX, typename TR, int UPS = 0>
-__global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
+__global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
                                                       const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
                                                       int OH, int OW, int pad_lo, float pre_sub, float pre_div,
                                                       const float *__restrict__ up_ddw = nullptr, const float *__restrict__ up_dw = nullptr,
                                                       int up_oh = 0, int up_ow = 0, int up_pad = 0)
 {
-    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
+    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX), UPS>;
     static_assert(UPS == 0 || sizeof(TX) == 4 || CIN != UBD_C, "the in-block G tile needs an fp32 mask tile of G's size");
     constexpr int UPH = UPS == 1 ? C::TH + 2 : C::TH / 2 + 2, UPW = UPS == 1 ? 18 : 10;      // patch of the upper layer's dDW
     __shared__ __attribute__((aligned(16))) float s_up[UPS > 0 ? UPH * UPW * UBD_C + 9 * UBD_C : 4];
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void sep_bwd_kernel(const void *__restrict_
     constexpr int NT_A = (CIN == UBD_C) ? 2 : 1;           // tiles of the dDW product
     constexpr int MT_PW = (CIN == UBD_C) ? 2 : 1;          // M tiles of the dpw product (CIN rows + ones row)
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-    __shared__ float s_dw[4][16][UBD_C];
+    __shared__ float s_dw[4][16][CIN == UBD_C ? UBD_C : 4];           // depthwise output of a row, transposed for the dpw product (columns = channels)
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
@@ -1053,12 +1093,12 @@ static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const f
                            int OH, int OW, int pad_lo, float sub, float div, hipStream_t st,
                            const float *up_ddw = nullptr, const float *up_dw = nullptr, int up_oh = 0, int up_ow = 0, int up_pad = 0)
 {
-    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX)>;
+    using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX), UPS>;
     const int th = C::TH;
     const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
     const size_t up_bytes = UPS == 0 ? 16 : ((UPS == 1 ? (size_t)(th + 2) * 18 : (size_t)(th / 2 + 2) * 10) * UBD_C + 9 * UBD_C) * sizeof(float);
-    const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * UBD_C * sizeof(float) + up_bytes;
-    int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : 2);
+    const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * (CIN == UBD_C ? UBD_C : 4) * sizeof(float) + up_bytes;
+    int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : (lds_bytes > 50 * 1024 ? 2 : (lds_bytes > 39 * 1024 || !(CIN != UBD_C && UPS > 0) ? 3 : 4)));
     if (grid > tiles) grid = (int)tiles;
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
     float *partials = rp_add(rq, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
@@ -1293,7 +1333,11 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
             gw = (gw + 7) / 8 * 8;                                  // the item ranges are cut per XCD: all eight need a block
             float *partials = rp_add(&rq, gw, 217 * UBD_C, grads + h->off_dil_k[k], 216 * UBD_C, grads + h->off_dil_b[k], UBD_C, nullptr, st);
             if (!partials) return -1;
-            hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
+            if constexpr (sizeof(TX) == 4) {
+                if (h->split_sepbwd32) hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);     // diagnostics: the four-wave form
+                else hipLaunchKernelGGL((dil_wgrad_kernel<TX, 2>), dim3(gw), dim3(512), 0, st, X, gq[cur], partials, n, H4, W4, dd);
+            } else
+                hipLaunchKernelGGL((dil_wgrad_kernel<TX>), dim3(gw), dim3(256), 0, st, X, gq[cur], partials, n, H4, W4, dd);
         }
         if (h->use_wino)
             ubd_launch_dilconv_wino(h, 1, bfrag + UBD_BWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, X, act_dtype, UBD_DILATIONS[k], gq[cur], gq[cur ^ 1], n, H4, W4, st);
