@@ -67,6 +67,29 @@ def test_gradients_direct_dilated_kernel_path(monkeypatch):
     test_gradients_vs_autograd(3, 2, True, 2, 64, 96)
 
 
+@pytest.mark.parametrize("cin,ncls,n,hh,ww", [(3, 0, 3, 72, 104), (1, 3, 2, 64, 96), (3, 2, 5, 136, 200)])
+def test_fp32_fused_separable_backward_vs_split_kernels(monkeypatch, cin, ncls, n, hh, ww):
+    """Round 5: the fp32 gradient path computes the G tile of separable layers 1 and 2 inside sep_bwd_kernel (UPS template argument) from
+    the upper layer's dDW patch -- sep_dx_kernel's arithmetic, tap for tap.  UBD_SEPBWD=split runs the round-4 form (sep_dx_kernel writes
+    G, 16-row tiles, dil_wgrad in four waves).  The tiles differ (8 rows vs 16), so weight-gradient sums associate differently: equal to
+    rounding, and both inside the autograd tolerance (ragged map sizes included: 72 x 104 and 136 x 200 are no tile multiples)."""
+    model, w, x, labels = _setup(cin, ncls, True, n, hh, ww, 77 + cin)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    grads = {}
+    for mode in ("fused", "split"):
+        if mode == "split":
+            monkeypatch.setenv("UBD_SEPBWD", "split")
+        m = Model(model.net_config, dtype="float32", seed=0)
+        m.set_weights(w)
+        tr = Trainer(m, Adam())
+        tr.backward_on_device(xt, yt)
+        grads[mode] = tr.grads.cpu().numpy().astype(np.float64)
+        assert np.isfinite(grads[mode]).all()
+    scale = np.abs(grads["split"]).max()
+    assert scale > 0
+    assert np.abs(grads["fused"] - grads["split"]).max() <= 2e-5 * scale
+
+
 def test_adam_step_and_training_reduces_loss():
     model, w, x, labels = _setup(3, 0, True, 4, 64, 64, 21)
     tr = Trainer(model, Adam(lr=1e-3))

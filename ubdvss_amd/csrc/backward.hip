@@ -609,19 +609,35 @@ __global__ __launch_bounds__(256 * MS, 2 * MS) void dil_wgrad_kernel(const void 
 // patch and the G tile are staged in LDS (24 channels: LDS-DMA, clamped + zero-fixed at the image border;
 // 1/3 channels: converted on the way through registers), every tap and both G layouts are then read from LDS.
 template <int CIN, int STRIDE, int XB, int UPS = 0> struct sepb_cfg {          // XB = bytes per element of a 24-channel input
-    // 1/3-channel layer with the in-block G tile (fp32 gradient path): 8-row tiles, 43 KB of LDS -- THREE blocks per CU instead of two (the
-    // kernel waits for memory two thirds of its time, PMC round 5)
+    // 1/3-channel layer with the in-block G tile (fp32 gradient path): 8-row tiles, 40 KB of LDS -- FOUR blocks per CU instead of two (the
+    // kernel waited for memory two thirds of its time, PMC round 5)
     static constexpr int TH = ((CIN == UBD_C && STRIDE == 2) || (CIN != UBD_C && UPS > 0)) ? 8 : 16;
     static constexpr int PH = (TH - 1) * STRIDE + 3;
     static constexpr int PW = 15 * STRIDE + 3;
     static constexpr int XPIX = PH * PW;
     static constexpr int GPIX = TH * 16;
     static constexpr int XCH = XB * UBD_C / 16;                                        // DMA chunks per X pixel
-    static constexpr int XFLOATS = (CIN == UBD_C) ? XPIX * XCH * 4 : (XPIX * CIN + 3) / 4 * 4;
-    static constexpr int CHUNKS = ((CIN == UBD_C) ? XPIX * XCH : 0) + GPIX * 6;       // DMA chunks (X if 24 ch, then G)
+    // LDS layout of the fp32 tiles (round 5).  A lane (pixel i, channel group q) reads 8-byte pairs at pixel_position + 6 q: at 24 dwords
+    // per pixel, pixels i and i + 8 (stride 1) or i and i + 4, 8, 12 (stride 2) start in the same bank, every read took 2 (4) passes and
+    // the LDS pipe was busy 54 % of the 24-channel kernel's time, 59 % of that in bank conflicts (profiles/r05_pmc_sep_bwd32.txt).
+    // The LDS-DMA lands 16-byte chunks at consecutive slots, WHICH chunk a slot fetches is free -- so a pad chunk is left out:
+    //   G tile, X patch of a stride-1 layer: 7 slots (28 dwords) per pixel; X patch of a stride-2 layer: 13 slots per PAIR of pixels.
+    // Then the 32 lanes of a half-wave read 64 different banks (tools/lds_bank_model.py).
+    static constexpr bool XSW = (CIN == UBD_C) && XB == 4;
+    static constexpr int XROW_CH = !XSW ? PW * XCH : (STRIDE == 1 ? PW * 7 : (PW / 2) * 13 + (PW % 2) * 6);   // slots per X patch row
+    static constexpr int XROW_DW = XROW_CH * 4;
+    __host__ __device__ static constexpr int xpos_dw(int pc)                           // dword offset of pixel column pc in its row
+    {
+        return !XSW ? pc * (UBD_C * XB / 4) : (STRIDE == 1 ? pc * 28 : pc * 24 + (pc >> 1) * 4);
+    }
+    static constexpr int GPIX_DW = 28;                                                 // G tile: dwords per pixel
+    static constexpr int XFLOATS = (CIN == UBD_C) ? PH * XROW_DW : (XPIX * CIN + 3) / 4 * 4;
+    static constexpr int XCHUNKS = (CIN == UBD_C) ? PH * XROW_CH : 0;
+    static constexpr int GCHUNKS = GPIX * 7;                                           // a multiple of 64: every wave's 64 slots lie in ONE region
+    static constexpr int CHUNKS = GCHUNKS + XCHUNKS;                                   // DMA slots: the G tile, then (24 channels) the X patch
     static constexpr int ROUNDS = (CHUNKS + 255) / 256;
     static constexpr int GOFF = (CIN == UBD_C) ? 0 : XFLOATS;                          // float offset of the DMA region
-    static constexpr int LDS_FLOATS = GOFF + ROUNDS * 256 * 4;
+    static constexpr int LDS_FLOATS = GOFF + CHUNKS * 4;                               // exact: slots past CHUNKS are not fetched
 };
 
 // TX: element type of a 24-channel input patch; TR: activation type of the model (16-bit: kernels and the depthwise
@@ -632,13 +648,20 @@ template <int CIN, int STRIDE, int XB, int UPS = 0> struct sepb_cfg {          /
 //     G[p][c] = (A[p][c] > 0) * sum_t dDW_up[(p + up_pad - t) / UPS][c] * dw_up[t][c]        (taps in sep_dx_kernel's order: the same bits)
 // i.e. sep_dx_kernel's arithmetic on the tile, so that kernel's launch -- 403 MB read + 403 MB mask + 403 MB written per separable
 // layer at 64 images -- and the G tensor itself disappear.
+#ifdef UBD_STAMPS   // diagnostic build: s_memtime of every wave at the phase boundaries of its first 8 tiles (tools/stamps_sepb32.py)
+#define SB32_STAMP_PARAM , unsigned long long *stamps = nullptr
+#define SB32STAMP(k) do { if (stamps && stamp_it < 8 && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + stamp_it) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SB32_STAMP_PARAM
+#define SB32STAMP(k) do {} while (0)
+#endif
 template <int CIN, int STRIDE, int IN_U8, typename TX, typename TR, int UPS = 0>
 __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bwd_kernel(const void *__restrict__ xin, const float *__restrict__ G,
                                                       float *__restrict__ dDW, const float *__restrict__ fwdfrag,
                                                       const float *__restrict__ bwdfrag, float *__restrict__ partials, int n, int H, int W,
                                                       int OH, int OW, int pad_lo, float pre_sub, float pre_div,
                                                       const float *__restrict__ up_ddw = nullptr, const float *__restrict__ up_dw = nullptr,
-                                                      int up_oh = 0, int up_ow = 0, int up_pad = 0)
+                                                      int up_oh = 0, int up_ow = 0, int up_pad = 0 SB32_STAMP_PARAM)
 {
     using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX), UPS>;
     static_assert(UPS == 0 || sizeof(TX) == 4 || CIN != UBD_C, "the in-block G tile needs an fp32 mask tile of G's size");
@@ -652,8 +675,9 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 15, q = lane >> 4;
     const float *dwlane = fwdfrag + UBD_SEP_FRAG_FLOATS;
-    float *xpatch = lds;                                                // CIN==24: part of the DMA region
-    float *gtile = lds + C::GOFF + ((CIN == UBD_C) ? C::XPIX * C::XCH * 4 : 0);
+    float *gtile = lds + C::GOFF;                                       // DMA region: G tile, then the 24-channel X patch
+    float *xpatch = (CIN == UBD_C) ? gtile + C::GCHUNKS * 4 : lds;
+    const unsigned lds_dma = ubd_lds_addr(lds) + C::GOFF * 4u;             // LDS byte address of DMA slot 0
 
     float dwk[9][CPL];
 #pragma unroll
@@ -679,52 +703,137 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
     const int total = n * tiles_y * tiles_x;
     ubd_tile_decoder tdec;
     tdec.init(tiles_x, tiles_y, total);
+    [[maybe_unused]] int stamp_it = -1;
     for (int ltile = blockIdx.x; ltile < total; ltile += gridDim.x) {
         int tx, ty, img;
         tdec.decode(ltile, tx, ty, img);                                   // neighbouring tiles on one XCD (shared halo lines)
         const int oy0 = ty * C::TH, ox0 = tx * 16;
         const int ix0 = ox0 * STRIDE - pad_lo, iy0 = oy0 * STRIDE - pad_lo;
+        ++stamp_it;
+        SB32STAMP(0);
         __syncthreads();                                               // previous tile fully consumed
+        SB32STAMP(1);
+        // the staging below decodes slot / element numbers that depend on the thread only: opaque per tile, or hipcc computes the decode of every
+        // round once, in front of the tile loop, and parks it in scratch (27 spilled registers at the 128 of the four-blocks-per-CU variants)
+        int lane_o = lane, tid_o = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane_o), "+v"(tid_o));
         // ---- stage X patch (24 ch) and G tile by LDS-DMA; clamped addresses, zero-fix below
+        // Every wave-round fetches 64 consecutive slots of ONE region; (row, slot in the row) of its first slot are scalar arithmetic, a lane adds
+        // its number and wraps into the next row at most once (rows are >= 64 slots), small divisions are one multiply, the address is a scalar
+        // image base + a 32-bit lane offset (the launcher checks that an image fits).  Round 5: with one flat slot number per lane decoded by
+        // 32-bit divisions and a 64-bit address per lane a round cost ~500 cycles of (mostly quarter-rate) VALU -- 7500 of the 24-channel
+        // tile's 40000 (profiles/r05_stamps_sepb32.txt).
+        static_assert(C::GCHUNKS % 64 == 0 && 16 * 7 >= 64 && (CIN != UBD_C || C::XROW_CH >= 64 || !C::XSW), "one region, one wrap per wave-round");
+        const char *xim = (const char *)xin + (size_t)img * H * W * (UBD_C * sizeof(TX));     // wave-uniform bases
+        const char *gim = (const char *)G + (size_t)img * OH * OW * (UBD_C * sizeof(float));
 #pragma unroll 2
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int cbase = rd * 256 + wid * 64;
-            int c = cbase + lane;
-            c = c < C::CHUNKS ? c : C::CHUNKS - 1;
-            const char *src;
-            if (CIN == UBD_C && c < C::XPIX * C::XCH) {
-                const int pix = c / C::XCH, part = c - pix * C::XCH;
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
+            if (cbase >= C::CHUNKS) break;                             // wave-uniform
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dma + (unsigned)cbase * 16u));
+            if (cbase < C::GCHUNKS) {
+                const int row0 = cbase / 112;                          // scalar
+                int rc = cbase - row0 * 112 + lane_o;
+                const int wrap = rc >= 112 ? 1 : 0;
+                rc -= wrap * 112;
+                const int px = (rc * 147) >> 10, part = rc - px * 7;   // rc / 7 for rc < 209
+                int gy = oy0 + row0 + wrap, gx = ox0 + px;
+                gy = gy >= OH ? OH - 1 : gy;
+                gx = gx >= OW ? OW - 1 : gx;
+                const unsigned off = (unsigned)(gy * OW + gx) * (unsigned)(UBD_C * 4) + (unsigned)(part * 16);
+                if (part < 6) ubd_glds16_sbase(gim, off, dst);
+            } else if constexpr (CIN == UBD_C) {
+                const int cx = cbase - C::GCHUNKS;
+                int pr, pc, part;
+                bool fetch;
+                if constexpr (C::XSW) {
+                    const int row0 = cx / C::XROW_CH;                  // scalar
+                    int rc = cx - row0 * C::XROW_CH + lane_o;
+                    const int wrap = rc >= C::XROW_CH ? 1 : 0;
+                    rc -= wrap * C::XROW_CH;
+                    pr = row0 + wrap;
+                    if constexpr (STRIDE == 1) { pc = (rc * 147) >> 10; part = rc - pc * 7; fetch = part < 6; }
+                    else {
+                        const int pp = (rc * 79) >> 10, r13 = rc - pp * 13;      // rc / 13 for rc < 350: pair of pixels, slot inside (12: the pad)
+                        const int hi = r13 >= 6 ? 1 : 0;
+                        pc = 2 * pp + hi; part = r13 - 6 * hi; fetch = r13 < 12;
+                    }
+                } else {
+                    const int c = cx + lane_o;
+                    pr = c / C::XROW_CH;
+                    const int rc = c - pr * C::XROW_CH;
+                    pc = rc / C::XCH; part = rc - pc * C::XCH; fetch = true;
+                }
+                fetch = fetch && pr < C::PH;
                 int gy = iy0 + pr, gx = ix0 + pc;
                 gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
                 gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-                src = (const char *)xin + (((size_t)img * H + gy) * W + gx) * (UBD_C * sizeof(TX)) + part * 16;
-            } else {
-                const int cg = c - ((CIN == UBD_C) ? C::XPIX * C::XCH : 0);
-                const int pix = cg / 6, part = cg - pix * 6;
-                int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
-                gy = gy >= OH ? OH - 1 : gy;
-                gx = gx >= OW ? OW - 1 : gx;
-                src = (const char *)(G + (((size_t)img * OH + gy) * OW + gx) * UBD_C) + part * 16;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(lds + C::GOFF + cbase * 4), 16, 0, 0);
-        }
-        if constexpr (CIN != UBD_C) {                                  // small-channel input: through registers
-            for (int e = threadIdx.x; e < C::XPIX * CIN; e += 256) {
-                const int pix = e / CIN, ch = e - pix * CIN;
-                const int pr = pix / C::PW, pc = pix - pr * C::PW;
-                const int gy = iy0 + pr, gx = ix0 + pc;
-                float v = 0.f;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    const size_t ge = (((size_t)img * H + gy) * W + gx) * CIN + ch;
-                    if constexpr (IN_U8) v = ((float)((const unsigned char *)xin)[ge] - pre_sub) / pre_div;
-                    else v = (((const float *)xin)[ge] - pre_sub) / pre_div;
-                }
-                xpatch[e] = v;
+                const unsigned off = (unsigned)(gy * W + gx) * (unsigned)(UBD_C * sizeof(TX)) + (unsigned)(part * 16);
+                if (fetch) ubd_glds16_sbase(xim, off, dst);
             }
         }
-        __syncthreads();                                               // DMA drained (vmcnt(0)) + LDS writes visible
+        // small-channel input: through registers (converted on the way).  All of a thread's loads first (clamped addresses, unconditional), the
+        // LDS stores behind the upper patch's below: as a load -> store loop of seven trips this was 7 memory round trips per tile, most of the
+        // 1/3-channel kernel's time (profiles/r05_stamps_sepb32.txt)
+        constexpr int NXR = (CIN != UBD_C) ? (C::XPIX * CIN + 255) / 256 : 1;
+        [[maybe_unused]] float xv[NXR];
+        if constexpr (CIN != UBD_C) {
+            constexpr unsigned ROWE = C::PW * CIN;                     // a patch row is ROWE consecutive elements of the image row
+            const size_t ibase = (size_t)img * H * W * CIN;
+#pragma unroll
+            for (int k = 0; k < NXR; ++k) {
+                const unsigned e = (unsigned)(k * 256 + tid_o);
+                const unsigned ec = e < (unsigned)(C::XPIX * CIN) ? e : (unsigned)(C::XPIX * CIN - 1);
+                const unsigned pr = ec / ROWE, col = ec - pr * ROWE;
+                const unsigned pc = col / (unsigned)CIN, ch = col - pc * CIN;
+                const int gy = iy0 + (int)pr, gx = ix0 + (int)pc;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                const size_t ge = ibase + ((size_t)gyc * W + gxc) * CIN + ch;
+                float raw;
+                if constexpr (IN_U8) raw = (float)((const unsigned char *)xin)[ge];
+                else raw = ((const float *)xin)[ge];
+                xv[k] = in ? (raw - pre_sub) / pre_div : 0.f;
+            }
+        }
+        if constexpr (UPS > 0) {
+            // ---- the dDW patch of the layer above (zeros outside its map) and its depthwise kernel, through registers: the loads fly together
+            //      with the LDS-DMA above (round 5: they used to start behind the DMA's barrier -- a second memory round trip per tile)
+            const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            constexpr int UR = (UPH * UPW * 6 + 255) / 256;
+            f32x4 uv[UR];
+            const float *ubase = up_ddw + (size_t)img * up_oh * up_ow * UBD_C;
+#pragma unroll
+            for (int k = 0; k < UR; ++k) {
+                const int e = k * 256 + tid_o;
+                const int ec = e < UPH * UPW * 6 ? e : UPH * UPW * 6 - 1;
+                const int pix = ec / 6, part = ec - pix * 6;
+                const int pr = pix / UPW, pc = pix - pr * UPW;
+                const int gy = uy0 + pr, gx = ux0 + pc;
+                const bool in = gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow;
+                const int gyc = gy < 0 ? 0 : (gy >= up_oh ? up_oh - 1 : gy), gxc = gx < 0 ? 0 : (gx >= up_ow ? up_ow - 1 : gx);
+                const f32x4 ld = *(const f32x4 *)(ubase + ((size_t)gyc * up_ow + gxc) * UBD_C + 4 * part);     // clamped: unconditional load
+                uv[k] = in ? ld : zero4;
+            }
+            if (threadIdx.x < 9 * UBD_C) s_up[UPH * UPW * UBD_C + threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);
+#pragma unroll
+            for (int k = 0; k < UR; ++k) {
+                const int e = k * 256 + tid_o;
+                if (e < UPH * UPW * 6) *(f32x4 *)(s_up + e * 4) = uv[k];             // chunk e of the patch: pixel e / 6, channels 4 (e % 6) ..
+            }
+        }
+        if constexpr (CIN != UBD_C) {
+#pragma unroll
+            for (int k = 0; k < NXR; ++k) {
+                const int e = k * 256 + tid_o;
+                if (e < C::XPIX * CIN) xpatch[e] = xv[k];
+            }
+        }
+        SB32STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's LDS-DMA has landed (asm form: hipcc keeps no count of it)
+        __syncthreads();                                               // ... every wave's; LDS writes visible
+        SB32STAMP(3);
         {
             const bool xborder = (CIN == UBD_C) && ((iy0 < 0) || (ix0 < 0) || (iy0 + C::PH > H) || (ix0 + C::PW > W));
             const bool gborder = (oy0 + C::TH > OH) || (ox0 + 16 > OW);
@@ -735,7 +844,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
                         const int pr = pix / C::PW, pc = pix - pr * C::PW;
                         const int gy = iy0 + pr, gx = ix0 + pc;
                         if (gy < 0 || gy >= H || gx < 0 || gx >= W) {
-                            f32x4 *z = (f32x4 *)((char *)xpatch + pix * (UBD_C * (int)sizeof(TX)));
+                            f32x4 *z = (f32x4 *)(xpatch + pr * C::XROW_DW + C::xpos_dw(pc));
 #pragma unroll
                             for (int k6 = 0; k6 < C::XCH; ++k6) z[k6] = zero;
                         }
@@ -743,7 +852,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
                 if (gborder)
                     for (int pix = threadIdx.x; pix < C::GPIX; pix += 256)
                         if (oy0 + (pix >> 4) >= OH || ox0 + (pix & 15) >= OW) {
-                            f32x4 *z = (f32x4 *)(gtile + pix * UBD_C);
+                            f32x4 *z = (f32x4 *)(gtile + pix * C::GPIX_DW);
 #pragma unroll
                             for (int k6 = 0; k6 < 6; ++k6) z[k6] = zero;
                         }
@@ -751,66 +860,52 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
             }
         }
 
+        SB32STAMP(4);
         if constexpr (UPS > 0) {
             // ---- the G tile from the layer above: its dDW patch (zeros outside its map) and its depthwise kernel into LDS, then every
             //      thread turns six 4-channel chunks of the mask tile into G in place
             float *upk = s_up + UPH * UPW * UBD_C;
             const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            {
-                // all of a thread's chunk loads first, then the LDS stores: one memory round trip per tile (as a load -> store loop the
-                // staging was a chain of up to eight)
-                constexpr int UR = (UPH * UPW * 6 + 255) / 256;
-                f32x4 uv[UR];
-                const float *ubase = up_ddw + (size_t)img * up_oh * up_ow * UBD_C;
-#pragma unroll
-                for (int k = 0; k < UR; ++k) {
-                    const int e = k * 256 + (int)threadIdx.x;
-                    const int ec = e < UPH * UPW * 6 ? e : UPH * UPW * 6 - 1;
-                    const int pix = ec / 6, part = ec - pix * 6;
-                    const int pr = pix / UPW, pc = pix - pr * UPW;
-                    const int gy = uy0 + pr, gx = ux0 + pc;
-                    const bool in = gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow;
-                    const int gyc = gy < 0 ? 0 : (gy >= up_oh ? up_oh - 1 : gy), gxc = gx < 0 ? 0 : (gx >= up_ow ? up_ow - 1 : gx);
-                    const f32x4 ld = *(const f32x4 *)(ubase + ((size_t)gyc * up_ow + gxc) * UBD_C + 4 * part);     // clamped: unconditional load
-                    uv[k] = in ? ld : zero4;
-                }
-#pragma unroll
-                for (int k = 0; k < UR; ++k) {
-                    const int e = k * 256 + (int)threadIdx.x;
-                    if (e < UPH * UPW * 6) *(f32x4 *)(s_up + e * 4) = uv[k];             // chunk e of the patch: pixel e / 6, channels 4 (e % 6) ..
-                }
-            }
-            if (threadIdx.x < 9 * UBD_C) upk[threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);
-            __syncthreads();
             for (int e = threadIdx.x; e < C::GPIX * 6; e += 256) {
                 const int pix = e / 6, part = e - pix * 6;
                 const int py = oy0 + (pix >> 4) + up_pad, px = ox0 + (pix & 15) + up_pad;
                 f32x4 acc = zero4;
+                // No branch around the two LDS reads of a tap (round 5: as `if (ok) { read; read; fma }` every tap was an LDS round trip of its
+                // own): the patch index is clamped into the patch, a tap that does not exist contributes 0 * w (the same sum: x + 0 = x).
+                // Stride 2: only taps of the pixel's parity can exist ((p - k) even), 2 x 2 of the 9 -- visited in the same ky, kx order.
+                constexpr int NTAP = UPS == 1 ? 3 : 2;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+                for (int a = 0; a < NTAP; ++a) {
+                    const int ky = UPS == 1 ? a : (py & 1) + 2 * a;
                     const int ty = py - ky;
-                    const bool yok = ty >= 0 && (UPS == 1 || (ty & 1) == 0) && (ty / UPS) < up_oh;
-                    const int ur = (UPS == 1 ? ty : (ty >> 1)) - uy0;
+                    const bool yok = ky <= 2 && ty >= 0 && (ty / UPS) < up_oh;
+                    int ur = (UPS == 1 ? ty : (ty >> 1)) - uy0;
+                    ur = ur < 0 ? 0 : (ur > UPH - 1 ? UPH - 1 : ur);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
+                    for (int b = 0; b < NTAP; ++b) {
+                        const int kx = UPS == 1 ? b : (px & 1) + 2 * b;
                         const int tx = px - kx;
-                        const bool ok = yok && tx >= 0 && (UPS == 1 || (tx & 1) == 0) && (tx / UPS) < up_ow;
-                        if (ok) {
-                            const int uc = (UPS == 1 ? tx : (tx >> 1)) - ux0;
-                            const f32x4 v = *(const f32x4 *)(s_up + (ur * UPW + uc) * UBD_C + 4 * part);
-                            const f32x4 wv = *(const f32x4 *)(upk + (ky * 3 + kx) * UBD_C + 4 * part);
-                            acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
-                            acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
-                        }
+                        const bool ok = yok && kx <= 2 && tx >= 0 && (tx / UPS) < up_ow;
+                        int uc = (UPS == 1 ? tx : (tx >> 1)) - ux0;
+                        uc = uc < 0 ? 0 : (uc > UPW - 1 ? UPW - 1 : uc);
+                        int t = ky * 3 + kx;
+                        t = t > 8 ? 8 : t;
+                        const f32x4 vl = *(const f32x4 *)(s_up + (ur * UPW + uc) * UBD_C + 4 * part);
+                        const f32x4 wv = *(const f32x4 *)(upk + t * UBD_C + 4 * part);
+                        const f32x4 v = ok ? vl : zero4;
+                        acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
+                        acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
                     }
                 }
-                f32x4 *pg = (f32x4 *)(gtile + pix * UBD_C + 4 * part);
+                f32x4 *pg = (f32x4 *)(gtile + pix * C::GPIX_DW + 4 * part);
                 const f32x4 mk = *pg;
                 *pg = (f32x4){mk[0] > 0.f ? acc[0] : 0.f, mk[1] > 0.f ? acc[1] : 0.f, mk[2] > 0.f ? acc[2] : 0.f, mk[3] > 0.f ? acc[3] : 0.f};
             }
+            SB32STAMP(7);
             __syncthreads();
         }
+        SB32STAMP(8);
 #pragma unroll 1
         for (int r = wid; r < C::TH; r += 4) {
             const int oy = oy0 + r;
@@ -820,7 +915,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
             // ---- 1. G of this pixel, channels 6q..6q+5 (zero outside the map: zero-fixed tile)
             float g6[6];
             {
-                const f32x2 *pg = (const f32x2 *)(gtile + (r * 16 + i) * UBD_C + 6 * q);
+                const f32x2 *pg = (const f32x2 *)(gtile + (r * 16 + i) * C::GPIX_DW + 6 * q);
                 const f32x2 v0 = pg[0], v1 = pg[1], v2 = pg[2];
                 g6[0] = v0[0]; g6[1] = v0[1]; g6[2] = v1[0]; g6[3] = v1[1]; g6[4] = v2[0]; g6[5] = v2[1];
             }
@@ -846,7 +941,8 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int t = ky * 3 + kx;
-                    const int pe = ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * ((CIN == UBD_C) ? UBD_C : CIN) + cb;
+                    const int pe = (CIN == UBD_C) ? (r * STRIDE + ky) * (C::XROW_DW * 4 / (int)sizeof(TX)) + C::xpos_dw(i * STRIDE + kx) * 4 / (int)sizeof(TX) + cb
+                                                  : ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * CIN + cb;     // element index (TX units)
                     const float *p = xpatch + pe;
                     if constexpr (CIN == UBD_C) {
                         float v[6];
@@ -867,7 +963,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int pr = 4 * g4 + q;               // lane (m = i, k = q): pixel pr of this row tile
-                const float *gp = gtile + (r * 16 + pr) * UBD_C;
+                const float *gp = gtile + (r * 16 + pr) * C::GPIX_DW;
                 const float b0 = gp[i];
                 const float b1 = i < 8 ? gp[16 + i] : 0.f;
                 float a0, a1 = 0.f;
@@ -896,6 +992,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
                 }
             }
         }
+        SB32STAMP(9);
     }
     // ---- flush: block-level reduction in LDS, then this block's row of the partial-sum matrix
     //      row layout: [9*CIN depthwise | CIN*24 pointwise | 24 bias]
@@ -1094,19 +1191,24 @@ static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const f
                            const float *up_ddw = nullptr, const float *up_dw = nullptr, int up_oh = 0, int up_ow = 0, int up_pad = 0)
 {
     using C = sepb_cfg<CIN, STRIDE, (int)sizeof(TX), UPS>;
+    // the kernel addresses a tile's pieces as image base + 32-bit byte offset
+    if ((CIN == UBD_C && (unsigned long long)H * W * UBD_C * sizeof(TX) > 0xFFFFFFFFull) || (unsigned long long)OH * OW * UBD_C * 4 > 0xFFFFFFFFull) {
+        ubd_set_error("separable backward: one image's activation map exceeds 4 GiB (%d x %d)", H, W);
+        return -1;
+    }
     const int th = C::TH;
     const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
     const size_t up_bytes = UPS == 0 ? 16 : ((UPS == 1 ? (size_t)(th + 2) * 18 : (size_t)(th / 2 + 2) * 10) * UBD_C + 9 * UBD_C) * sizeof(float);
     const size_t lds_bytes = C::LDS_FLOATS * sizeof(float) + 4 * 16 * (CIN == UBD_C ? UBD_C : 4) * sizeof(float) + up_bytes;
-    int grid = h->num_cus * (lds_bytes > 76 * 1024 ? 1 : (lds_bytes > 50 * 1024 ? 2 : (lds_bytes > 39 * 1024 || !(CIN != UBD_C && UPS > 0) ? 3 : 4)));
+    int grid = h->num_cus * (lds_bytes > 80 * 1024 ? 1 : (lds_bytes > 53 * 1024 ? 2 : (lds_bytes > 40 * 1024 || !(CIN != UBD_C && UPS > 0) ? 3 : 4)));   // 160 KB of LDS per CU
     if (grid > tiles) grid = (int)tiles;
     const int part = 9 * CIN + CIN * UBD_C + UBD_C;
     float *partials = rp_add(rq, grid, part, g_dw, 9 * CIN, g_pw, CIN * UBD_C, g_b, st);
     if (!partials) return -1;
     if (in_u8)
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 1, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad SB_STAMP_ARG);
     else
-        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad);
+        hipLaunchKernelGGL((sep_bwd_kernel<CIN, STRIDE, 0, TX, TR, UPS>), dim3(grid), dim3(256), 0, st, x, G, dDW, ffrag, bfrag, partials, n, H, W, OH, OW, pad_lo, sub, div, up_ddw, up_dw, up_oh, up_ow, up_pad SB_STAMP_ARG);
     return 0;
 }
 
