@@ -16,7 +16,7 @@ x = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32)
 y = torch.from_numpy(lab).cuda()
 for _ in range(40): tr.train_step_on_device(x, y)
 lib.ubd_debug_set_stamps_sepb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; lib.ubd_debug_set_stamps_sepb.restype = None
-names = ["top barrier", "issue DMA / X regs", "barrier (DMA landed)", "border fix", "upper patch loads", "barrier", "G tile", "barrier", "row loop"]
+names = ["top barrier", "issue DMA (G, X, upper patch) / X regs", "wait + barrier (DMA landed)", "border fix", "-", "-", "G tile", "barrier", "row loop"]
 for cin, stride in ((24, 1), (3, 2), (24, 2)):
     st = torch.zeros((1024, 4, 8, 12), dtype=torch.int64, device="cuda")
     lib.ubd_debug_set_stamps_sepb(st.data_ptr(), cin, stride)
@@ -25,8 +25,8 @@ for cin, stride in ((24, 1), (3, 2), (24, 2)):
     s = st.cpu().numpy()
     used = s[:, 0, 2, 0] > 0
     s = s[used]
-    if not (s[0, 0, 2, 5] > 0):                      # no in-block G tile: stamps 5, 6, 7 are not taken
-        for k in (5, 6, 7): s[:, :, :, k] = s[:, :, :, 4]
+    for k in (5, 6): s[:, :, :, k] = s[:, :, :, 4]       # stamps 5, 6 (upper patch through registers) are no longer taken
+    if not (s[0, 0, 2, 7] > 0): s[:, :, :, 7] = s[:, :, :, 4]   # no in-block G tile
     seg = np.diff(s[:, :, 1:7, :10], axis=-1)          # (blk, wave, tile 1..6, 9 segments between the 10 stamps)
     period = s[:, 0, 2:8, 0] - s[:, 0, 1:7, 0]
     print(f"sep_bwd<{cin},{stride}> fp32: blocks {used.sum()}, tile period median {np.median(period):.0f} cycles (s_memtime)")

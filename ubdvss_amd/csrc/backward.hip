@@ -631,7 +631,9 @@ template <int CIN, int STRIDE, int XB, int UPS = 0> struct sepb_cfg {          /
         return !XSW ? pc * (UBD_C * XB / 4) : (STRIDE == 1 ? pc * 28 : pc * 24 + (pc >> 1) * 4);
     }
     static constexpr int GPIX_DW = 28;                                                 // G tile: dwords per pixel
-    static constexpr int XFLOATS = (CIN == UBD_C) ? PH * XROW_DW : (XPIX * CIN + 3) / 4 * 4;
+    // 1/3-channel patch: rows of XROW_E floats = whole 16-byte chunks with room for the skew between a chunk boundary and the patch's first float
+    static constexpr int XROWC = (PW * CIN + 3 + 3) / 4, XROW_E = XROWC * 4;
+    static constexpr int XFLOATS = (CIN == UBD_C) ? PH * XROW_DW : PH * XROW_E;
     static constexpr int XCHUNKS = (CIN == UBD_C) ? PH * XROW_CH : 0;
     static constexpr int GCHUNKS = GPIX * 7;                                           // a multiple of 64: every wave's 64 slots lie in ONE region
     static constexpr int CHUNKS = GCHUNKS + XCHUNKS;                                   // DMA slots: the G tile, then (24 channels) the X patch
@@ -704,6 +706,14 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
     ubd_tile_decoder tdec;
     tdec.init(tiles_x, tiles_y, total);
     [[maybe_unused]] int stamp_it = -1;
+    const unsigned lds_up = ubd_lds_addr(s_up);
+    if constexpr (UPS > 0) {
+        if (threadIdx.x < 9 * UBD_C) s_up[UPH * UPW * UBD_C + threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);     // the upper layer's depthwise kernel: visible after the first tile's barrier
+    }
+    // 1/3-channel fp32 input whose rows are whole 16-byte chunks: fetched 16 bytes per lane (see the staging); xsk = floats between a chunk
+    // boundary and the patch's first float
+    const bool xwide = (CIN != UBD_C) && !IN_U8 && ((W * CIN) & 3) == 0 && (unsigned long long)H * W * CIN * 4 < (1ull << 31);
+    const int xsk = xwide ? ((-(CIN * pad_lo)) & 3) : 0;
     for (int ltile = blockIdx.x; ltile < total; ltile += gridDim.x) {
         int tx, ty, img;
         tdec.decode(ltile, tx, ty, img);                                   // neighbouring tiles on one XCD (shared halo lines)
@@ -772,62 +782,97 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
                 if (fetch) ubd_glds16_sbase(xim, off, dst);
             }
         }
-        // small-channel input: through registers (converted on the way).  All of a thread's loads first (clamped addresses, unconditional), the
-        // LDS stores behind the upper patch's below: as a load -> store loop of seven trips this was 7 memory round trips per tile, most of the
-        // 1/3-channel kernel's time (profiles/r05_stamps_sepb32.txt)
-        constexpr int NXR = (CIN != UBD_C) ? (C::XPIX * CIN + 255) / 256 : 1;
-        [[maybe_unused]] float xv[NXR];
-        if constexpr (CIN != UBD_C) {
-            constexpr unsigned ROWE = C::PW * CIN;                     // a patch row is ROWE consecutive elements of the image row
-            const size_t ibase = (size_t)img * H * W * CIN;
-#pragma unroll
-            for (int k = 0; k < NXR; ++k) {
-                const unsigned e = (unsigned)(k * 256 + tid_o);
-                const unsigned ec = e < (unsigned)(C::XPIX * CIN) ? e : (unsigned)(C::XPIX * CIN - 1);
-                const unsigned pr = ec / ROWE, col = ec - pr * ROWE;
-                const unsigned pc = col / (unsigned)CIN, ch = col - pc * CIN;
-                const int gy = iy0 + (int)pr, gx = ix0 + (int)pc;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-                const size_t ge = ibase + ((size_t)gyc * W + gxc) * CIN + ch;
-                float raw;
-                if constexpr (IN_U8) raw = (float)((const unsigned char *)xin)[ge];
-                else raw = ((const float *)xin)[ge];
-                xv[k] = in ? (raw - pre_sub) / pre_div : 0.f;
-            }
-        }
         if constexpr (UPS > 0) {
-            // ---- the dDW patch of the layer above (zeros outside its map) and its depthwise kernel, through registers: the loads fly together
-            //      with the LDS-DMA above (round 5: they used to start behind the DMA's barrier -- a second memory round trip per tile)
+            // ---- the dDW patch of the layer above, by LDS-DMA too (clamped addresses: the G tile below reads a patch pixel only where it lies
+            //      inside the upper map).  Round 5: first loaded behind the DMA's barrier (a second memory round trip per tile), then through
+            //      registers in flight with the DMA -- 20 registers the four-blocks-per-CU variants do not have.
             const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            constexpr int UR = (UPH * UPW * 6 + 255) / 256;
-            f32x4 uv[UR];
-            const float *ubase = up_ddw + (size_t)img * up_oh * up_ow * UBD_C;
+            const char *uim = (const char *)up_ddw + (size_t)img * up_oh * up_ow * (UBD_C * 4);
+            constexpr int UCH = UPH * UPW * 6;
 #pragma unroll
-            for (int k = 0; k < UR; ++k) {
-                const int e = k * 256 + tid_o;
-                const int ec = e < UPH * UPW * 6 ? e : UPH * UPW * 6 - 1;
-                const int pix = ec / 6, part = ec - pix * 6;
-                const int pr = pix / UPW, pc = pix - pr * UPW;
-                const int gy = uy0 + pr, gx = ux0 + pc;
-                const bool in = gy >= 0 && gy < up_oh && gx >= 0 && gx < up_ow;
-                const int gyc = gy < 0 ? 0 : (gy >= up_oh ? up_oh - 1 : gy), gxc = gx < 0 ? 0 : (gx >= up_ow ? up_ow - 1 : gx);
-                const f32x4 ld = *(const f32x4 *)(ubase + ((size_t)gyc * up_ow + gxc) * UBD_C + 4 * part);     // clamped: unconditional load
-                uv[k] = in ? ld : zero4;
+            for (int rd = 0; rd < (UCH + 255) / 256; ++rd) {
+                const int cbase = rd * 256 + wid * 64;
+                if (cbase >= UCH) break;                               // wave-uniform
+                const unsigned c = (unsigned)(cbase + lane_o);
+                const unsigned cc = c < (unsigned)UCH ? c : (unsigned)(UCH - 1);
+                const unsigned pix = cc / 6u, part = cc - pix * 6u;
+                const unsigned pr = pix / (unsigned)UPW, pc = pix - pr * UPW;
+                int gy = uy0 + (int)pr, gx = ux0 + (int)pc;
+                gy = gy < 0 ? 0 : (gy >= up_oh ? up_oh - 1 : gy);
+                gx = gx < 0 ? 0 : (gx >= up_ow ? up_ow - 1 : gx);
+                const unsigned off = (unsigned)(gy * up_ow + gx) * (unsigned)(UBD_C * 4) + part * 16u;
+                if (c < (unsigned)UCH) ubd_glds16_sbase(uim, off, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_up + (unsigned)cbase * 16u)));
             }
-            if (threadIdx.x < 9 * UBD_C) s_up[UPH * UPW * UBD_C + threadIdx.x] = rnd_act<TR>(up_dw[threadIdx.x]);
+        }
+        // small-channel input: through registers (converted on the way).  All of a thread's loads first (unconditional), the LDS stores behind
+        // the upper patch's below: as a load -> store loop of seven trips this was 7 memory round trips per tile.  fp32 rows that are a whole
+        // number of 16-byte chunks (`xwide`): 16 bytes per lane -- chunks left / right of the row or above / below the image are outside as a
+        // whole and become zeros -- 7 wave-loads per tile instead of 27 (the vector memory pipe takes
+        // ~170-200 cycles per wave-load whatever its width, tools/ubench/dma_issue.hip); patch rows then start `xsk` floats into their LDS row.
+        constexpr int NXR = (CIN != UBD_C) ? (C::XPIX * CIN + 255) / 256 : 1;
+        constexpr int NXW = (CIN != UBD_C) ? (C::PH * C::XROWC + 255) / 256 : 1;
+        [[maybe_unused]] float xv[IN_U8 ? NXR : 1];
+        [[maybe_unused]] f32x4 xw[IN_U8 ? 1 : NXW];
+        if constexpr (CIN != UBD_C) {
+            if (xwide) {
+                // loaded, converted and stored in one piece below
+            } else if constexpr (IN_U8) {
+                constexpr unsigned ROWE = C::PW * CIN;                 // a patch row is ROWE consecutive elements of the image row
+                const size_t ibase = (size_t)img * H * W * CIN;
 #pragma unroll
-            for (int k = 0; k < UR; ++k) {
-                const int e = k * 256 + tid_o;
-                if (e < UPH * UPW * 6) *(f32x4 *)(s_up + e * 4) = uv[k];             // chunk e of the patch: pixel e / 6, channels 4 (e % 6) ..
+                for (int k = 0; k < NXR; ++k) {
+                    const unsigned e = (unsigned)(k * 256 + tid_o);
+                    const unsigned ec = e < (unsigned)(C::XPIX * CIN) ? e : (unsigned)(C::XPIX * CIN - 1);
+                    const unsigned pr = ec / ROWE, col = ec - pr * ROWE;
+                    const unsigned pc = col / (unsigned)CIN, ch = col - pc * CIN;
+                    const int gy = iy0 + (int)pr, gx = ix0 + (int)pc;
+                    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+                    const float raw = (float)((const unsigned char *)xin)[ibase + ((size_t)gyc * W + gxc) * CIN + ch];
+                    xv[k] = in ? (raw - pre_sub) / pre_div : 0.f;
+                }
+            } else {
+                // fp32 rows that are no whole number of chunks (W * CIN % 4 != 0): element by element, stored at once (the slow path)
+                for (int e = tid_o; e < C::XPIX * CIN; e += 256) {
+                    const int pr = e / (C::PW * CIN), col = e - pr * (C::PW * CIN);
+                    const int pc = col / CIN, ch = col - pc * CIN;
+                    const int gy = iy0 + pr, gx = ix0 + pc;
+                    float v = 0.f;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (((const float *)xin)[(((size_t)img * H + gy) * W + gx) * CIN + ch] - pre_sub) / pre_div;
+                    xpatch[pr * C::XROW_E + col] = v;
+                }
             }
         }
         if constexpr (CIN != UBD_C) {
+            if (xwide) {
+                const int a0f = ix0 * CIN - xsk, WC = W * CIN;                 // a0f: a multiple of 4 (tile origins are multiples of 32 pixels)
+                const float *xim = (const float *)xin + (size_t)img * H * WC;
+                bool okk[NXW];
 #pragma unroll
-            for (int k = 0; k < NXR; ++k) {
-                const int e = k * 256 + tid_o;
-                if (e < C::XPIX * CIN) xpatch[e] = xv[k];
+                for (int k = 0; k < NXW; ++k) {
+                    const unsigned c = (unsigned)(k * 256 + tid_o);
+                    const unsigned pr = c / (unsigned)C::XROWC, pc = c - pr * C::XROWC;
+                    const int gy = iy0 + (int)pr, f0 = a0f + 4 * (int)pc;
+                    // a chunk is inside the image row or outside as a whole (rows are whole chunks): outside -> any valid address, zeroed below
+                    okk[k] = c < (unsigned)(C::PH * C::XROWC) && (unsigned)gy < (unsigned)H && (unsigned)f0 < (unsigned)WC;
+                    xw[k] = *(const f32x4 *)(xim + (okk[k] ? gy * WC + f0 : 0));
+                }
+#pragma unroll
+                for (int k = 0; k < NXW; ++k) {
+                    const unsigned c = (unsigned)(k * 256 + tid_o);
+                    const bool ok = okk[k];                            // else: padding, exactly 0 after the preprocessing too
+                    f32x4 v;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) v[e4] = ok ? (xw[k][e4] - pre_sub) / pre_div : 0.f;
+                    if (c < (unsigned)(C::PH * C::XROWC)) *(f32x4 *)(xpatch + c * 4) = v;
+                }
+            } else if constexpr (IN_U8) {
+#pragma unroll
+                for (int k = 0; k < NXR; ++k) {
+                    const unsigned e = (unsigned)(k * 256 + tid_o);
+                    const unsigned pr = e / (unsigned)(C::PW * CIN);
+                    if (e < (unsigned)(C::XPIX * CIN)) xpatch[e + pr * (unsigned)(C::XROW_E - C::PW * CIN)] = xv[k];     // rows of XROW_E floats
+                }
             }
         }
         SB32STAMP(2);
@@ -942,7 +987,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
                 for (int kx = 0; kx < 3; ++kx) {
                     const int t = ky * 3 + kx;
                     const int pe = (CIN == UBD_C) ? (r * STRIDE + ky) * (C::XROW_DW * 4 / (int)sizeof(TX)) + C::xpos_dw(i * STRIDE + kx) * 4 / (int)sizeof(TX) + cb
-                                                  : ((r * STRIDE + ky) * C::PW + i * STRIDE + kx) * CIN + cb;     // element index (TX units)
+                                                  : (r * STRIDE + ky) * C::XROW_E + xsk + (i * STRIDE + kx) * CIN + cb;     // element index (TX units)
                     const float *p = xpatch + pe;
                     if constexpr (CIN == UBD_C) {
                         float v[6];
@@ -1196,6 +1241,7 @@ static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const f
         ubd_set_error("separable backward: one image's activation map exceeds 4 GiB (%d x %d)", H, W);
         return -1;
     }
+    if (UPS > 0 && (unsigned long long)up_oh * up_ow * UBD_C * 4 > 0xFFFFFFFFull) { ubd_set_error("separable backward: upper map exceeds 4 GiB"); return -1; }
     const int th = C::TH;
     const long tiles = (long)n * ((OH + th - 1) / th) * ((OW + 15) / 16);
     const size_t up_bytes = UPS == 0 ? 16 : ((UPS == 1 ? (size_t)(th + 2) * 18 : (size_t)(th / 2 + 2) * 10) * UBD_C + 9 * UBD_C) * sizeof(float);
