@@ -83,7 +83,7 @@ def committed_profile(kernel_prefix):
     traffic = avg_us = None
     files = {}
     meta = {}
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         if traffic is None:
             try:
                 for ln in open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_fwd_fp32.txt")):
