@@ -912,6 +912,51 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
             float *upk = s_up + UPH * UPW * UBD_C;
             const int uy0 = UPS == 1 ? oy0 + up_pad - 2 : ((oy0 + up_pad - 2) >> 1), ux0 = UPS == 1 ? ox0 + up_pad - 2 : ((ox0 + up_pad - 2) >> 1);
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            // Tiles all of whose taps lie inside the upper map (all but the map's border tiles; block-uniform): no bounds, no clamps -- a chunk's
+            // patch and weight addresses are ONE base each plus compile-time offsets (stride 2: the parity of the pixel is in the bases, a tap with
+            // ky or kx = 3 is switched off by a select).  Same taps, same order, same sums as the general loop below.
+            const bool interior = oy0 + up_pad - 2 >= 0 && ox0 + up_pad - 2 >= 0 && (oy0 + up_pad + C::TH - 1) / UPS < up_oh && (ox0 + up_pad + 15) / UPS < up_ow;
+            if (interior) {
+                for (int e = threadIdx.x; e < C::GPIX * 6; e += 256) {
+                    const int pix = e / 6, part = e - pix * 6;
+                    const int r = pix >> 4, c = pix & 15;
+                    f32x4 acc = zero4;
+                    if constexpr (UPS == 1) {
+                        const float *pb = s_up + ((r + 2) * UPW + (c + 2)) * UBD_C + 4 * part;      // patch pixel of tap (0, 0): row oy0 + up_pad + r - uy0 = r + 2
+                        const float *wb = upk + 4 * part;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const f32x4 v = *(const f32x4 *)(pb - (ky * UPW + kx) * UBD_C);
+                                const f32x4 wv = *(const f32x4 *)(wb + (ky * 3 + kx) * UBD_C);
+                                acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
+                                acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
+                            }
+                    } else {
+                        const int py = oy0 + r + up_pad, px = ox0 + c + up_pad;
+                        const int qy = py & 1, qx = px & 1;
+                        const float *pb = s_up + (((py >> 1) - uy0) * UPW + ((px >> 1) - ux0)) * UBD_C + 4 * part;   // tap (qy, qx)
+                        const int t0 = qy * 3 + qx;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const bool ok = (a == 0 || qy == 0) && (b == 0 || qx == 0);          // ky = qy + 2 a <= 2, kx = qx + 2 b <= 2
+                                int t = t0 + 6 * a + 2 * b;
+                                t = t > 8 ? 8 : t;
+                                const f32x4 vl = *(const f32x4 *)(pb - (a * UPW + b) * UBD_C);
+                                const f32x4 wv = *(const f32x4 *)(upk + t * UBD_C + 4 * part);
+                                const f32x4 v = ok ? vl : zero4;
+                                acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
+                                acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
+                            }
+                    }
+                    f32x4 *pg = (f32x4 *)(gtile + pix * C::GPIX_DW + 4 * part);
+                    const f32x4 mk = *pg;
+                    *pg = (f32x4){mk[0] > 0.f ? acc[0] : 0.f, mk[1] > 0.f ? acc[1] : 0.f, mk[2] > 0.f ? acc[2] : 0.f, mk[3] > 0.f ? acc[3] : 0.f};
+                }
+            } else
             for (int e = threadIdx.x; e < C::GPIX * 6; e += 256) {
                 const int pix = e / 6, part = e - pix * 6;
                 const int py = oy0 + (pix >> 4) + up_pad, px = ox0 + (pix & 15) + up_pad;
