@@ -52,6 +52,9 @@ typedef struct ubd_handle ubd_handle;
 int ubd_abi_version(void);
 const char *ubd_build_id(void);                         /* 16 hex digits: fingerprint of the kernel sources (every .hip and .h file of csrc) THIS library was compiled from */
 const char *ubd_last_error(void);                       /* thread-local message of the last failure */
+/* Host staging helper of the streaming seam (ModelRunner.predict_stream; the loop of model_runner.py:60-67): copies n bytes with `threads`
+ * native threads (1..16) -- a batch of pageable numpy memory into a pinned staging buffer without the interpreter in the way.  Returns 0. */
+int ubd_host_memcpy_mt(void *dst, const void *src, size_t n, int threads);
 int ubd_create(const ubd_config *cfg, ubd_handle **out); /* replaces NetManager.build_model (net.py:273-314) */
 void ubd_destroy(ubd_handle *h);
 

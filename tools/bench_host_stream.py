@@ -4,6 +4,10 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ubdvss_amd import NetConfig, Model, ModelRunner, PreprocessingType, synthetic
+if os.environ.get("UBD_MR_OLD"):          # same-box A/B against a saved copy of the module (tools/_ab/host_ab.py)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ubdvss_amd.model_runner_old", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", "model_runner_old.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod); ModelRunner = mod.ModelRunner
 torch.cuda.set_device(0)
 labels = synthetic.rectangle_maps(3, 32, 128, 128)
 imgs = [synthetic.textured_images(4 + k, labels, 4, 3) for k in range(4)]
@@ -17,8 +21,12 @@ for name in ("uint8", "float32"):
     t0 = time.perf_counter()
     for k in range(nb): runner.predict(model, arrs[k % 4])
     t_seq = (time.perf_counter() - t0) / nb
-    for threads in (1, 2, 4, 8):
-        list(runner.predict_stream(model, [arrs[k % 4] for k in range(6)], copy_threads=threads))
+    for threads in (2, 4, 8):
+        # steady state of a streaming job: a fresh process needs ~100 batches to settle (pinned-allocator cache, clocks), so four untimed
+        # 24-batch runs first (bench.py's protocol), then 48 timed batches in one pipeline
+        for _ in range(4):
+            list(runner.predict_stream(model, [arrs[k % 4] for k in range(24)], copy_threads=threads))
+        nb = 48
         t0 = time.perf_counter()
         n = sum(1 for _ in runner.predict_stream(model, (arrs[k % 4] for k in range(nb)), copy_threads=threads))
         t_str = (time.perf_counter() - t0) / nb

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ubd_abi_version": (_i, []),
     "ubd_build_id": (ctypes.c_char_p, []),
     "ubd_last_error": (ctypes.c_char_p, []),
+    "ubd_host_memcpy_mt": (_i, [_vp, _vp, _sz, _i]),
     "ubd_create": (_i, [ctypes.POINTER(UbdConfig), ctypes.POINTER(_vp)]),
     "ubd_destroy": (None, [_vp]),
     "ubd_param_count": (_sz, [_vp]),

@@ -1,6 +1,8 @@
 // Handle lifecycle and error reporting of libubd_hip.so.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
+#include <thread>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -18,6 +20,25 @@ extern "C" int ubd_abi_version(void) { return UBD_ABI_VERSION; }
 #ifndef UBD_BUILD_ID
 #define UBD_BUILD_ID "unknown"
 #endif
+// host staging helper (include/ubd.h): n bytes in `threads` contiguous pieces, one std::thread each (the caller's thread takes the first piece)
+extern "C" int ubd_host_memcpy_mt(void *dst, const void *src, size_t n, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 16) threads = 16;
+    if (n < ((size_t)1 << 20)) threads = 1;
+    const size_t piece = ((n + threads - 1) / threads + 4095) & ~(size_t)4095;
+    std::thread th[16];
+    int started = 0;
+    for (int t = 1; t < threads; ++t) {
+        const size_t a = (size_t)t * piece;
+        if (a >= n) break;
+        const size_t len = n - a < piece ? n - a : piece;
+        th[started++] = std::thread([=] { memcpy((char *)dst + a, (const char *)src + a, len); });
+    }
+    memcpy(dst, src, n < piece ? n : piece);
+    for (int t = 0; t < started; ++t) th[t].join();
+    return 0;
+}
 extern "C" const char *ubd_build_id(void) { return UBD_BUILD_ID; }   // sha256 over the kernel sources at build time (build.sh); bench.py compares it with the committed profiles' fingerprint
 
 extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)

@@ -115,12 +115,12 @@ class ModelRunner:
             found_objects = self.rescale(found_objects, meta_infos)
         return detection_logits, classification_logits, found_objects
 
-    def predict_stream(self, model, batches, rescale=False, meta_infos=None, copy_threads=4):
+    def predict_stream(self, model, batches, rescale=False, meta_infos=None, copy_threads=8):
         """The loop of the reference's ``ModelRunner.run`` (model_runner.py:60-67: ``predict`` batch after batch) as ONE pipeline:
         generator over ``predict``'s return triple, one per batch of ``batches`` (an iterable of numpy (N,H,W,C) arrays, uint8 or
         float32), in order.  Batch k + 1 is staged and transferred while batch k computes:
-          staging thread: the batch is copied into one of three PINNED staging buffers by ``copy_threads`` pool threads (numpy
-            releases the GIL) -- the transfer of pageable memory would otherwise be staged by the runtime, synchronously;
+          staging thread: the batch is copied into one of three PINNED staging buffers by ``copy_threads`` native threads (one foreign call,
+            ``ubd_host_memcpy_mt``) -- the transfer of pageable memory would otherwise be staged by the runtime, synchronously;
           copy-in stream: pinned -> device (three device input buffers), enqueued as soon as the batch is staged and BEFORE the
             consumer blocks on an older batch's results; an event hands the buffer to the compute stream;
           compute stream: the pipelined runner -- forward pass of batch k with the postprocess of batch k - 1 inside its stem kernel;
@@ -128,7 +128,6 @@ class ModelRunner:
           consumer (this generator): the object lists of batch k - 2 are built while all of that is in flight.
         ``meta_infos``: one list per batch when ``rescale``.  Results are identical to calling ``predict`` per batch
         (tests/test_gpu_end_to_end.py::test_predict_stream_equals_predict)."""
-        import concurrent.futures as cf
         import queue
         import threading
         import time
@@ -137,7 +136,7 @@ class ModelRunner:
         runner._logit_threshold = self._logit_threshold
         s_main = torch.cuda.current_stream(dev)
         s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        pool = cf.ThreadPoolExecutor(max_workers=max(1, int(copy_threads)))
+        lib = _lib.load()
         NPIN, NDEV, NRES = 3, 3, 3
         pinned, dev_in, host_res = [None] * NPIN, [None] * NDEV, [None] * NRES
         fwd_done, d2h_done = [None] * NDEV, [None] * NRES
@@ -147,6 +146,8 @@ class ModelRunner:
         for slot in range(NPIN):
             free_slots.put((slot, None))
         stop = threading.Event()
+        stats = {"wait_staged_s": 0.0, "enqueue_s": 0.0, "deliver_s": 0.0, "deliver_wait_s": 0.0, "stager_copy_s": 0.0, "batches": 0}
+        self.last_stream_stats = stats                  # where the consumer thread's time went (tools/bench_host_stream.py prints it)
 
         def stager():
             """host side of the copy-in, its own thread: batch -> pinned staging buffer, ahead of the stream work"""
@@ -165,12 +166,11 @@ class ModelRunner:
                     if pinned[slot] is None or tuple(pinned[slot].shape) != x.shape or pinned[slot].dtype != tdt:
                         pinned[slot] = torch.empty(x.shape, dtype=tdt, pin_memory=True)
                     dst = pinned[slot].numpy()
-                    n = x.shape[0]
-                    parts = max(1, min(int(copy_threads), n))
-                    bounds = [n * i // parts for i in range(parts + 1)]
-                    futs = [pool.submit(np.copyto, dst[bounds[i]:bounds[i + 1]], x[bounds[i]:bounds[i + 1]]) for i in range(parts)]
-                    for f in futs:
-                        f.result()
+                    tc = time.perf_counter()
+                    # one foreign call (ctypes drops the GIL), native threads inside: as `copy_threads` python pool tasks the copy took the
+                    # interpreter away from the consumer thread at every hand-over (enqueue 0.15 -> 0.35 -> 0.8 ms at 2 / 4 / 8 threads)
+                    lib.ubd_host_memcpy_mt(dst.ctypes.data, x.ctypes.data, x.nbytes, int(copy_threads))
+                    stats["stager_copy_s"] += time.perf_counter() - tc       # the staging thread's own time (not the consumer's)
                     staged.put((k, slot, next(metas) if metas is not None else None))
                 staged.put(None)
             except BaseException as e:                  # noqa: BLE001 -- re-raised by the consumer
@@ -206,12 +206,12 @@ class ModelRunner:
             entry[2] = ev
 
         def deliver(entry):
+            tw = time.perf_counter()
             entry[2].synchronize()
+            stats["deliver_wait_s"] += time.perf_counter() - tw     # of deliver_s: blocked on the device (results not there yet)
             logits_h, bmap_h, quads_h, classes_h, counts_h = [None if h is None else h.numpy() for h in host_res[entry[0] % NRES]]
             return self._assemble(counts_h, quads_h, classes_h, logits_h, bmap_h, rescale, entry[3], copy=True)
 
-        stats = {"wait_staged_s": 0.0, "enqueue_s": 0.0, "deliver_s": 0.0, "batches": 0}
-        self.last_stream_stats = stats                  # where the consumer thread's time went (tools/bench_host_stream.py prints it)
         th = threading.Thread(target=stager, daemon=True)
         th.start()
         try:
@@ -272,7 +272,6 @@ class ModelRunner:
                 except queue.Empty:
                     pass
                 th.join(timeout=0.05)
-            pool.shutdown(wait=True)
 
     @staticmethod
     def rescale(found_objects, meta_infos):
