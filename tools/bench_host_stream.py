@@ -4,10 +4,6 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ubdvss_amd import NetConfig, Model, ModelRunner, PreprocessingType, synthetic
-if os.environ.get("UBD_MR_OLD"):          # same-box A/B against a saved copy of the module (tools/_ab/host_ab.py)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("ubdvss_amd.model_runner_old", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", "model_runner_old.py"))
-    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod); ModelRunner = mod.ModelRunner
 torch.cuda.set_device(0)
 labels = synthetic.rectangle_maps(3, 32, 128, 128)
 imgs = [synthetic.textured_images(4 + k, labels, 4, 3) for k in range(4)]
