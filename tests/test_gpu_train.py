@@ -90,6 +90,25 @@ def test_fp32_fused_separable_backward_vs_split_kernels(monkeypatch, cin, ncls, 
     assert np.abs(grads["fused"] - grads["split"]).max() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("cin", [1, 3])
+def test_fp32_backward_input_base_not_16_byte_aligned(cin):
+    """The 1/3-channel fp32 input patch of the L1 backward kernel is loaded 16 bytes per lane when the base is 16-byte aligned (rows are whole
+    chunks: W % 4 == 0); a batch that starts 4 bytes into an allocation takes the element-by-element path.  Same patch, same arithmetic:
+    the gradients are bit-identical."""
+    model, w, x, labels = _setup(cin, 0, True, 2, 72, 104, 55 + cin)
+    tr = Trainer(model, Adam())
+    yt = torch.from_numpy(labels).cuda()
+    xa = torch.from_numpy(x).cuda()
+    tr.backward_on_device(xa, yt)
+    g_aligned = tr.grads.clone()
+    buf = torch.empty(x.size + 4, dtype=torch.float32, device="cuda")
+    xm = buf[1:1 + x.size].view(x.shape)
+    xm.copy_(xa)
+    assert xm.data_ptr() % 16 == 4
+    tr.backward_on_device(xm, yt)
+    assert torch.equal(tr.grads, g_aligned)
+
+
 def test_adam_step_and_training_reduces_loss():
     model, w, x, labels = _setup(3, 0, True, 4, 64, 64, 21)
     tr = Trainer(model, Adam(lr=1e-3))

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256, (CIN != UBD_C && UPS > 0) ? 4 : 2) void sep_bw
     }
     // 1/3-channel fp32 input whose rows are whole 16-byte chunks: fetched 16 bytes per lane (see the staging); xsk = floats between a chunk
     // boundary and the patch's first float
-    const bool xwide = (CIN != UBD_C) && !IN_U8 && ((W * CIN) & 3) == 0 && (unsigned long long)H * W * CIN * 4 < (1ull << 31);
+    const bool xwide = (CIN != UBD_C) && !IN_U8 && ((W * CIN) & 3) == 0 && ((uintptr_t)xin & 15) == 0 && (unsigned long long)H * W * CIN * 4 < (1ull << 31);   // 16-byte loads: aligned base, rows of whole chunks
     const int xsk = xwide ? ((-(CIN * pad_lo)) & 3) : 0;
     for (int ltile = blockIdx.x; ltile < total; ltile += gridDim.x) {
         int tx, ty, img;
