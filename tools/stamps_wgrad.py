@@ -17,7 +17,7 @@ y = torch.from_numpy(lab).cuda()
 for _ in range(100): tr.train_step_on_device(x, y)
 lib.ubd_debug_set_stamps_sepb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; lib.ubd_debug_set_stamps_sepb.restype = None
 names = ["wait DMA", "barrier", "decode + issue next DMA", "weight-gradient MFMAs", "data-gradient phase"]
-for d in (2, 4, 8):
+for d in (1, 2, 4, 8, 16):
     st = torch.zeros((1024, 4, 8, 8), dtype=torch.int64, device="cuda")
     lib.ubd_debug_set_stamps_sepb(st.data_ptr(), -1, d)
     tr.train_step_on_device(x, y); torch.cuda.synchronize()
