@@ -708,7 +708,7 @@ def main():
         lists out): per-batch ``predict`` (synchronous pageable copies) and ``predict_stream`` (pinned staging ring, copy-in / compute /
         copy-out streams, the postprocess of batch k inside the stem kernel of batch k + 1).  Never the headline value."""
         res = {"protocol": "numpy batches of 32 x 512 x 512 x 3 (4 distinct arrays in turn, 1-8 objects per image) -> (maps, class logits, object lists); wall clock; "
-                           "predict: median of 8 calls after 2 warm-up calls; predict_stream: 48 batches in one pipeline after four untimed 24-batch runs (steady state of a streaming job)",
+                           "predict: median of 8 calls after 2 warm-up calls; predict_stream: the median of five pipelines of 48 batches after four untimed 24-batch runs (steady state of a streaming job); stream_thread_ms: consumer thread's wait_staged / enqueue / deliver (of which deliver_wait blocked on the device) and the staging thread's copy",
                "pcie_note": "uint8: 25.2 MB per batch = 0.49 ms at the ~51 GB/s this link sustains (63 GB/s spec) -> <= 65 k img/s; "
                             "float32: 100.7 MB = 1.97 ms -> <= 16.2 k img/s: the float32 stream runs AT the link rate"}
         hr = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=1024)
@@ -728,14 +728,19 @@ def main():
             for _ in range(4):                           # a streaming job's steady state: the first ~100 batches of a process run up to 3 x slower (staging buffers, clocks)
                 list(hr.predict_stream(mdl, [arrs[k % 4] for k in range(24)]))
             nb = 48
-            t0 = time.perf_counter()
-            n_out = sum(1 for _ in hr.predict_stream(mdl, (arrs[k % 4] for k in range(nb))))
-            per = (time.perf_counter() - t0) / nb
-            assert n_out == nb
+            runs = []                                    # five pipelines of 48 batches; the median one is reported (the host side shares a 16-CPU quota with whatever else runs on the box)
+            for _ in range(5):
+                t0 = time.perf_counter()
+                n_out = sum(1 for _ in hr.predict_stream(mdl, (arrs[k % 4] for k in range(nb))))
+                runs.append(((time.perf_counter() - t0) / nb, dict(hr.last_stream_stats)))
+                assert n_out == nb
+            runs.sort(key=lambda r: r[0])
+            per, stream_stats = runs[2]
             res[name] = {"ms_per_batch": round(med * 1e3, 3), "images_per_s": round(BATCH / med, 1), "h2d_MB": round(arrs[0].nbytes / 1e6, 1),
                          "stream_ms_per_batch": round(per * 1e3, 3), "stream_images_per_s": round(BATCH / per, 1),
                          "stream_host_to_device_GBps": round(arrs[0].nbytes / per / 1e9, 1), "objects_per_image_mean": round(float(np.mean([len(o) for o in last[2]])), 2),
-                         "stream_consumer_thread_ms_per_batch": {k[:-2]: round(v / nb * 1e3, 3) for k, v in hr.last_stream_stats.items() if k.endswith("_s")}}
+                         "stream_images_per_s_five_runs": [round(BATCH / r[0], 1) for r in runs],
+                         "stream_thread_ms_per_batch": {k[:-2]: round(v / nb * 1e3, 3) for k, v in stream_stats.items() if k.endswith("_s")}}
         return res
 
 
