@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE, WRITE_SIZE: separate --pmc passes, kernel-trace only) of EVERY kernel of one pass:
-# UBD_PMC_DTYPE=float32|bfloat16|float16, UBD_PMC_TRAIN=1 for a train step at batch 32.  Table -> gpurun_out/pmc_traffic_<tag>.txt
+# UBD_PMC_DTYPE=float32|bfloat16|float16, UBD_PMC_TRAIN=1 for a train step at batch 64 (forward passes: batch 32).  Table -> gpurun_out/pmc_traffic_<tag>.txt
 TAG=${UBD_PMC_DTYPE:-float32}${UBD_PMC_TRAIN:+_train}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic_${TAG}.txt"
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out; rm -f "$OUT"
@@ -15,7 +15,7 @@ x = torch.from_numpy(synthetic.noise_images(2, 32, 512, 512, 3)).cuda()
 if os.environ.get("UBD_PMC_TRAIN"):
     import numpy as np
     from ubdvss_amd import Trainer, Adam
-    lab = synthetic.rectangle_maps(30, 32, 128, 128)
+    lab = synthetic.rectangle_maps(30, 64, 128, 128)      # the train configuration: 64 images per GPU
     tx = torch.from_numpy(synthetic.textured_images(31, lab, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
     tr = Trainer(m, Adam())
     for _ in range(2): tr.train_step_on_device(tx, torch.from_numpy(lab).cuda())
@@ -34,7 +34,8 @@ for f in sys.argv[1:3]:
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in acc:
             acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
-print("# per launch, batch 32 of 512x512x3; FETCH_SIZE doubled (gfx950 64-byte units, MI355X_MICROARCH.md), KiB -> MB")
+import os
+print("# per launch, batch " + ("64 (the train configuration)" if os.environ.get("UBD_PMC_TRAIN") else "32") + " of 512x512x3; FETCH_SIZE doubled (gfx950 64-byte units, MI355X_MICROARCH.md), KiB -> MB")
 print(f"{'kernel':70s} {'launches':>8s} {'read MB':>9s} {'write MB':>9s}")
 names = sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"]), key=lambda k: -sum(acc["FETCH_SIZE"].get(k, [0])))
 for k in names:
