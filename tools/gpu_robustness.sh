@@ -21,6 +21,6 @@ echo "== kernel variants that must agree bit for bit, 40 random shapes + the fix
 python3 tools/stress_variants.py 2>&1 | grep -v amdgpu.ids
 } > gpurun_out/robust_stress_variants.log 2>&1
 {
-for i in 1 2 3 4 5 6 7 8 9 10; do echo "== full suite, run $i"; python3 -m pytest tests -m gpu -q 2>&1 | tail -1; done
+for i in 1 2 3 4 5 6 7 8 9 10; do echo "== full suite, run $i"; python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -1; done
 } > gpurun_out/robust_gpu_suite_repeats.log 2>&1
 tail -3 gpurun_out/robust_soak.log; tail -3 gpurun_out/robust_stress_variants.log; tail -4 gpurun_out/robust_gpu_suite_repeats.log
