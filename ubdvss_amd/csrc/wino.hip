@@ -102,7 +102,7 @@ struct wsamples {
 
 // TAUX: element type of the ReLU-mask source (EPI 1): fp32 or a 16-bit activation type
 template <int EPI, typename TAUX>
-__global__ __launch_bounds__(256, (EPI == 1) ? 2 : 3) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
+__global__ __launch_bounds__(256, 3) void dilconv_wino_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                               const float *__restrict__ ufrag,
                                                               const void *__restrict__ aux_, int n, int h, int w, int d,
                                                               int log2d, unsigned in_bytes, const float *__restrict__ head
@@ -373,7 +373,7 @@ void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, co
     const int d = dilation;
     const long half_rows = ((H4 + 2 * d - 1) / (2 * d)) * d, half_cols = ((W4 + 2 * d - 1) / (2 * d)) * d;
     const long groups = (long)n * half_rows * ((half_cols + 15) / 16);
-    int grid = ubd_grid_for(groups, h->num_cus, 4, epi != 1 ? 3 : 2);     // forward: 150 VGPRs, three waves per SIMD
+    int grid = ubd_grid_for(groups, h->num_cus, 4, 3);     // <= 168 VGPRs in every form: three waves per SIMD (the data-gradient form ran two until round 5)
     grid = (grid + 7) / 8 * 8;
     if (epi == 0)
         hipLaunchKernelGGL((dilconv_wino_kernel<0, float>), dim3(grid), dim3(256), 0, st, in, out, frag, aux, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
