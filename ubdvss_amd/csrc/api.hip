@@ -29,13 +29,20 @@ extern "C" int ubd_host_memcpy_mt(void *dst, const void *src, size_t n, int thre
     const size_t piece = ((n + threads - 1) / threads + 4095) & ~(size_t)4095;
     std::thread th[16];
     int started = 0;
+    size_t done_to = n < piece ? n : piece;              // [0, done_to) is the caller's piece; pieces whose thread could not be started are copied here too
     for (int t = 1; t < threads; ++t) {
         const size_t a = (size_t)t * piece;
         if (a >= n) break;
         const size_t len = n - a < piece ? n - a : piece;
-        th[started++] = std::thread([=] { memcpy((char *)dst + a, (const char *)src + a, len); });
+        try {
+            th[started] = std::thread([=] { memcpy((char *)dst + a, (const char *)src + a, len); });
+            ++started;
+        } catch (...) {                                  // no more threads to be had (resource limits): the rest in this thread
+            memcpy((char *)dst + a, (const char *)src + a, n - a);
+            break;
+        }
     }
-    memcpy(dst, src, n < piece ? n : piece);
+    memcpy(dst, src, done_to);
     for (int t = 0; t < started; ++t) th[t].join();
     return 0;
 }

@@ -5,6 +5,8 @@ The reference runs ``model.predict`` on the device, then thresholds with numpy a
 threshold, the component labelling and the box fitting all run on the MI355X; only the final
 (count, quads, classes) lists cross PCIe.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -137,6 +139,10 @@ class ModelRunner:
         s_main = torch.cuda.current_stream(dev)
         s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         lib = _lib.load()
+        try:                                            # never more staging threads than half of the CPUs this process may run on
+            copy_threads = max(1, min(int(copy_threads), len(os.sched_getaffinity(0)) // 2))
+        except (AttributeError, OSError):
+            copy_threads = max(1, int(copy_threads))
         NPIN, NDEV, NRES = 3, 3, 3
         pinned, dev_in, host_res = [None] * NPIN, [None] * NDEV, [None] * NRES
         fwd_done, d2h_done = [None] * NDEV, [None] * NRES
