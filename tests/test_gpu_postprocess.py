@@ -14,20 +14,24 @@ from ubdvss_amd import NetConfig, Model, ModelRunner, SegmapManager, synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["lds", "lds_split", "global"], autouse=True)
+@pytest.fixture(params=["lds", "lds_512", "lds_split", "global"], autouse=True)
 def front_end(request, monkeypatch):
     """Every case runs through every code path: "lds" = the whole postprocess of a batch as ONE launch (maps of <= 16384
     pixels: front end, boxes, class vote and emit in one block per image), "lds_split" = the one-launch front end followed by
     the separate boxes / vote / emit kernels (UBD_PP_SPLIT; what maps too tall for the in-block box scratch take) with the
     ONE-LANE form of the box fit (UBD_PP_SERIAL_TAIL: hull clean-up and rotating calipers on lane 0 over LDS arrays, what hulls
     of more than 64 vertices take; the other two variants run the wave-uniform register form), "global" = the multi-launch
-    global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size)."""
+    global-memory path that larger maps take (UBD_PP_GLOBAL forces it at any size); "lds_512" = the one-launch form in 512-thread
+    blocks (UBD_PP_THREADS_512): the block shape the job has when it rides inside the stem kernel."""
     from ubdvss_amd import segmap_manager
     segmap_manager._reset_handles()          # the switches are read when a handle is created
     monkeypatch.delenv("UBD_PP_GLOBAL", raising=False)
     monkeypatch.delenv("UBD_PP_SPLIT", raising=False)
     monkeypatch.delenv("UBD_PP_SERIAL_TAIL", raising=False)
-    if request.param == "global":
+    monkeypatch.delenv("UBD_PP_THREADS_512", raising=False)
+    if request.param == "lds_512":
+        monkeypatch.setenv("UBD_PP_THREADS_512", "1")
+    elif request.param == "global":
         monkeypatch.setenv("UBD_PP_GLOBAL", "1")
     elif request.param == "lds_split":
         monkeypatch.setenv("UBD_PP_SPLIT", "1")
