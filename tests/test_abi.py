@@ -64,3 +64,19 @@ def test_netconfig_mirror():
     c3 = NetConfig(class_names=["ean13", "qr"], grey=False, preprocessing=PreprocessingType.MOBILENET_LIKE)
     assert c3.get_n_classes() == 2 and c3.get_class_id("qr") == 1 and c3.is_classification_supported()
     assert c3.get_preprocessing_fn()(255.0) == 1.0
+
+
+def test_host_staging_copy_is_exact_for_every_size_and_thread_count():
+    """ubd_host_memcpy_mt (the staging helper of ModelRunner.predict_stream) is host code: it runs here.  Sizes around the one-thread
+    threshold (1 MiB), sizes that are no multiple of the 4 KiB piece rounding, thread counts outside 1..16 (clamped), zero bytes."""
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 4095, 4096, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 3 * (1 << 20) + 12345, 25165824):
+        src = rng.integers(0, 256, n, dtype=np.uint8)
+        for threads in (-3, 1, 2, 3, 7, 8, 16, 99):
+            dst = np.full(n + 64, 0xAB, dtype=np.uint8)
+            assert lib.ubd_host_memcpy_mt(dst.ctypes.data + 32, src.ctypes.data, n, threads) == 0
+            assert np.array_equal(dst[32:32 + n], src), (n, threads)
+            assert (dst[:32] == 0xAB).all() and (dst[32 + n:] == 0xAB).all(), (n, threads)     # nothing outside [dst, dst + n)
