@@ -69,8 +69,8 @@ def test_netconfig_mirror():
 def test_host_staging_copy_is_exact_for_every_size_and_thread_count():
     """ubd_host_memcpy_mt (the staging helper of ModelRunner.predict_stream) is host code: it runs here.  Sizes around the one-thread
     threshold (1 MiB), sizes that are no multiple of the 4 KiB piece rounding, thread counts outside 1..16 (clamped), zero bytes."""
-    import ctypes
     import numpy as np
+    from ubdvss_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(5)
     for n in (0, 1, 4095, 4096, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 3 * (1 << 20) + 12345, 25165824):
