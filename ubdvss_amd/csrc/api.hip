@@ -71,6 +71,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
     {
         const char *e = getenv("UBD_DILCONV");
         h->use_wino = !(e && strcmp(e, "direct") == 0);
+        h->wino_x6 = h->use_wino && !(e && strcmp(e, "wino32") == 0);
         // Inference runs L2 -> L3 as ONE kernel with L2's output in LDS (stem23.h) when the model uses the fml padding (the
         // variant that inherits the 33rd L2 column from the tile to its left: 0.405 vs 0.417 ms per forward pass at
         // 32 x 512 x 512); with TF 'same' padding the fused kernel only ties the two separate kernels and they

@@ -15,7 +15,7 @@ print(h.hexdigest()[:16])
 PY
 )
 pids=()
-for f in api forward fwd16 wino postprocess loss backward train comm raster; do
+for f in api forward fwd16 wino wino6 postprocess loss backward train comm raster; do
   [ -f $f.hip ] || continue
   extra=""
   # OpenCV-exact float geometry: no FMA contraction in postprocess
@@ -24,6 +24,7 @@ for f in api forward fwd16 wino postprocess loss backward train comm raster; do
   [ "$f" = "raster" ] && extra="-ffp-contract=off"
   # no SLP packing of adjacent fp32 adds into v_pk_add_f32: beside MFMAs the packed form issues slower than two scalar adds
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
+  [ "$f" = "wino6" ] && extra="$extra -fno-slp-vectorize"
   stale=0
   for dep in $f.hip *.h ../../include/ubd.h; do [ "$dep" -nt _obj/$f.o ] && stale=1; done
   if [ "$f" = "api" ]; then   # carries the fingerprint of ALL kernel sources
@@ -37,7 +38,7 @@ for f in api forward fwd16 wino postprocess loss backward train comm raster; do
 done
 for p in "${pids[@]}"; do wait $p; done
 objs=""
-for f in api forward fwd16 wino postprocess loss backward train comm raster; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
+for f in api forward fwd16 wino wino6 postprocess loss backward train comm raster; do [ -f _obj/$f.o ] && objs="$objs _obj/$f.o"; done
 echo "$BUILD_ID" > _obj/api.build_id
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs -ldl
 echo "built $OUT"

@@ -33,6 +33,7 @@ struct ubd_handle {
     int direct_dil16;         // UBD_DILCONV16=direct: 16-bit forward dilated layers with the direct (unstaged) kernel (diagnostics / tests)
     int fuse_stem;            // inference stem: 2 = L1 -> L2 -> L3 in one kernel (default with fml padding), 1 = L2 -> L3 fused, 0 = three kernels (UBD_STEM=fused123|fused|unfused)
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
+    int wino_x6;              // forward Winograd products as three-way bf16 split products on the bf16 MFMA (wino6.hip; default), 0: on the fp32 MFMA (UBD_DILCONV=wino32)
 };
 
 static const int UBD_DILATIONS[UBD_NUM_DIL] = {1, 2, 4, 8, 16, 1};
@@ -183,7 +184,9 @@ static inline size_t ubd_align_up(size_t v, size_t a) { return (v + a - 1) / a *
 #define UBD_SEP_DW_FLOATS (9 * 6 * 64)           // per-lane depthwise taps per separable layer
 #define UBD_WINO_FRAG_FLOATS (16 * 6 * 64 * 2)   // Winograd-domain weights per dilated layer (wino.hip)
 #define UBD_FWD_DIRECT_FLOATS (3 * (UBD_SEP_FRAG_FLOATS + UBD_SEP_DW_FLOATS) + UBD_NUM_DIL * UBD_DIL_FRAG_FLOATS)
-#define UBD_FWD_FRAG_FLOATS (UBD_FWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)
+#define UBD_WINO6_FRAG_U32 (16 * 2 * 3 * 64 * 4)  // the same weights as three bf16 pieces per value (wino6.hip): [xi 16][nt 2][piece 3][lane 64] x 4 dwords
+#define UBD_FWD_WINO6_OFF (UBD_FWD_DIRECT_FLOATS + UBD_NUM_DIL * UBD_WINO_FRAG_FLOATS)      // in floats (= dwords) from the start of the packed weights
+#define UBD_FWD_FRAG_FLOATS (UBD_FWD_WINO6_OFF + UBD_NUM_DIL * UBD_WINO6_FRAG_U32)
 
 struct ubd_fwd_layout {
     size_t off_tickets;   // int32 [64]: strip ticket counter of the one-kernel inference stem (zeroed per pass)
@@ -225,6 +228,9 @@ extern "C" size_t ubd_loss_workspace_bytes(const ubd_handle *h, int n, int map_h
 void ubd_launch_pack_wino(const ubd_handle *h, const float *params, float *out, int transpose, hipStream_t st);
 void ubd_launch_dilconv_wino(const ubd_handle *h, int epi, const float *frag, const void *aux, int aux_dtype, int dilation,
                              const float *in, float *out, int n, int H4, int W4, hipStream_t st, const float *head = nullptr);
+void ubd_launch_pack_wino6(const ubd_handle *h, const float *params, unsigned *out, hipStream_t st);
+void ubd_launch_dilconv_wino6(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, int dilation,
+                              const float *in, float *out, int n, int H4, int W4, hipStream_t st, const float *head = nullptr);
 void ubd_launch_pack_direct(const ubd_handle *h, const float *params, float *wfrag, hipStream_t st);
 size_t ubd_forward16_workspace_bytes(int n, int H, int W);
 int ubd_pack16_workspace(ubd_handle *h, const float *params, char *ws, size_t ws_bytes, hipStream_t st);

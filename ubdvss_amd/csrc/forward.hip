@@ -679,6 +679,7 @@ static void launch_pack(const ubd_handle *h, const float *params, float *wfrag, 
     pa.c_in = h->cfg.c_in;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, st, params, wfrag, pa);
     if (h->use_wino) ubd_launch_pack_wino(h, params, wfrag + UBD_FWD_DIRECT_FLOATS, 0, st);
+    if (h->wino_x6) ubd_launch_pack_wino6(h, params, (unsigned *)(wfrag + UBD_FWD_WINO6_OFF), st);
 }
 
 // frag: this layer's 6912 packed floats; aux: bias (epi 0) or mask source activation (epi 1)
@@ -698,6 +699,11 @@ void ubd_launch_dilconv(const ubd_handle *h, int epi, const float *frag, const f
 static void launch_dil(const ubd_handle *h, const float *params, const float *wfrag, int k, const float *in, float *out,
                        int n, int H4, int W4, hipStream_t st)
 {
+    if (h->wino_x6) {
+        ubd_launch_dilconv_wino6(h, 0, (const unsigned *)(wfrag + UBD_FWD_WINO6_OFF) + (size_t)k * UBD_WINO6_FRAG_U32, params + h->off_dil_b[k],
+                                 UBD_DILATIONS[k], in, out, n, H4, W4, st);
+        return;
+    }
     if (h->use_wino) {
         ubd_launch_dilconv_wino(h, 0, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k], UBD_F32,
                                 UBD_DILATIONS[k], in, out, n, H4, W4, st);
@@ -837,6 +843,12 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     const bool fuse_head = inference && h->use_wino && h->k_out == 1 && h->off_head_b == h->off_head_k + UBD_C;
     for (int k = 0; k < UBD_NUM_DIL; ++k) {
         float *nxt = (float *)(ws + L.off_acts[k + 1]);
+        if (fuse_head && k == UBD_NUM_DIL - 1 && h->wino_x6) {
+            ubd_launch_dilconv_wino6(h, 2, (const unsigned *)(wfrag + UBD_FWD_WINO6_OFF) + (size_t)k * UBD_WINO6_FRAG_U32, params + h->off_dil_b[k],
+                                     UBD_DILATIONS[k], cur, logits, n, H4, W4, st, params + h->off_head_k);
+            UBD_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         if (fuse_head && k == UBD_NUM_DIL - 1) {
             ubd_launch_dilconv_wino(h, 2, wfrag + UBD_FWD_DIRECT_FLOATS + (size_t)k * UBD_WINO_FRAG_FLOATS, params + h->off_dil_b[k], UBD_F32,
                                     UBD_DILATIONS[k], cur, logits, n, H4, W4, st, params + h->off_head_k);
