@@ -7,11 +7,12 @@ OBJ=../../tools/_ab/_obj_diag
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS -DUBD_EXPERIMENTAL_STEM123W $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
 pids=()
-for f in ${DIAG_FILES:-api forward fwd16 wino postprocess loss backward train comm raster}; do
+for f in ${DIAG_FILES:-api forward fwd16 wino wino6 postprocess loss backward train comm raster}; do
   extra=""
   [ "$f" = "postprocess" ] && extra="-ffp-contract=off"
   [ "$f" = "raster" ] && extra="-ffp-contract=off"
   [ "$f" = "wino" ] && extra="$extra -fno-slp-vectorize"
+  [ "$f" = "wino6" ] && extra="$extra -fno-slp-vectorize"
   ( /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o ) &
   pids+=($!)
 done

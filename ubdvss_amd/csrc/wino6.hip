@@ -77,22 +77,22 @@ void ubd_launch_pack_wino6(const ubd_handle *h, const float *params, unsigned *o
     hipLaunchKernelGGL(pack_wino6_kernel, dim3(48), dim3(256), 0, st, params, out, a);
 }
 
-// the instructions themselves, so that no pass re-packs or re-associates them (the file is also built with -fno-slp-vectorize)
-__device__ __forceinline__ float sadd(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float ssub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ f32x4 vadd(f32x4 a, f32x4 b) { return (f32x4){sadd(a[0], b[0]), sadd(a[1], b[1]), sadd(a[2], b[2]), sadd(a[3], b[3])}; }
-__device__ __forceinline__ f32x4 vsub(f32x4 a, f32x4 b) { return (f32x4){ssub(a[0], b[0]), ssub(a[1], b[1]), ssub(a[2], b[2]), ssub(a[3], b[3])}; }
-__device__ __forceinline__ f32x2 vadd(f32x2 a, f32x2 b) { return (f32x2){sadd(a[0], b[0]), sadd(a[1], b[1])}; }
-__device__ __forceinline__ f32x2 vsub(f32x2 a, f32x2 b) { return (f32x2){ssub(a[0], b[0]), ssub(a[1], b[1])}; }
-// Sums that CONSUME matrix-pipe results stay plain C++ (component-wise, so that nothing packs them): hipcc's hazard recogniser does
-// not look inside inline asm, so an asm v_add_f32 that reads an MFMA destination gets none of the wait states the read needs
-// (observed: register 0 of the result correct, registers 1..3 stale).
-__device__ __forceinline__ f32x4 madd(f32x4 a, f32x4 b) { return (f32x4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}; }
-__device__ __forceinline__ f32x4 msub(f32x4 a, f32x4 b) { return (f32x4){a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]}; }
+// All arithmetic below is plain C++ on vector types (no inline asm):
+//   * hipcc's scheduler and hazard recogniser see every instruction -- an asm v_add_f32 that reads an MFMA destination gets none of
+//     the wait states the read needs (observed with the first version of this kernel: register 0 of the result correct, 1..3 stale);
+//   * the two-component adds compile to v_pk_add_f32.  Measured on gfx950 (tools/ubench/valu_ops.hip): a wave issues a simple vector
+//     instruction every ~2.9 ns when it runs alone and the SIMD sustains one per ~1.1 ns from 2+ waves, while v_pk_add_f32 takes
+//     ~2.25 ns per instruction at ANY occupancy.  At the two waves per SIMD this kernel's 250 registers allow, the waves are bound by
+//     their own issue interval, so halving the number of add instructions halves their time (the fp32-MFMA kernel next door avoided the
+//     packed form for the opposite reason: beside fp32 MFMAs it sits in the MFMA's shadow at one wave per SIMD).
+//   Other per-instruction prices that shaped the code (same file): v_perm_b32 / v_cvt_pk_bf16_f32 / v_max_f32 / v_add3_u32 / any
+//   instruction with an SGPR source ~1.95 ns, v_and_b32 with a literal 1.05 ns, s_nop and scalar ALU ~1.9 ns of the wave's time.
 // residual of the truncation to bf16: v - hi16(v), exact
-__device__ __forceinline__ float resid(float v) { return ssub(v, __uint_as_float(__float_as_uint(v) & 0xffff0000u)); }
+__device__ __forceinline__ f32x4 resid(f32x4 v) { return v - __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, v) & 0xffff0000u); }
+__device__ __forceinline__ f32x2 resid(f32x2 v) { return v - __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, v) & 0xffff0000u); }
 // {hi16(lo), hi16(hi)} as one dword of two bf16 k-slots
 __device__ __forceinline__ unsigned pack_hi(float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); }
+__device__ __forceinline__ u32x4 pack6(f32x4 a, f32x2 b) { return (u32x4){pack_hi(a[0], a[1]), pack_hi(a[2], a[3]), pack_hi(b[0], b[1]), 0u}; }
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -106,18 +106,35 @@ extern "C" void ubd_debug_set_stamps_wino6(void *p) { g_wino6_stamps = (unsigned
 #define WSTAMP(k) do {} while (0)
 #endif
 
+#ifndef W6_WAVES
 #define W6_WAVES 8
+#endif
 struct w6samples {
     f32x4 v4[4][4];
     f32x2 v2[4][4];
+};
+// launch geometry (host): everything the group decode needs, so that the loop holds no integer division
+struct w6geom {
+    int n, h, w, d, log2d;
+    unsigned in_bytes;
+    unsigned groups_x, half_rows, total;
+    unsigned magic_gx, magic_hr;      // floor(v / groups_x) = umulhi(v, magic_gx) for v < total (ubd_tile_decoder's rule)
+};
+// addresses of one group: wave-uniform row terms (scalar registers; they ride in the buffer instructions' soffset, which IS part of
+// the hardware range check: tools/ubench/buf_soffset.hip) and per-lane column terms.  An invalid row or column is 2^30 (host: tensor
+// bytes <= 2^30), so any sum with an invalid term is out of range: loads return the zero padding, stores are dropped.
+struct w6addr {
+    unsigned row[4];      // byte offset of pixel (sample row a, x = 0)
+    unsigned lrow[2];     // EPI 2: byte offset of logit (output row rr, x = 0)
+    unsigned c4[4];       // column b: this lane's 16-byte chunk (channels 4q ..)
+    unsigned c2[4];       // column b: this lane's 8-byte chunk (channels 16 + 2q, 17 + 2q)
 };
 
 // EPI 0: y = relu(conv + bias);  EPI 2: logits = head(relu(conv + bias)) (one output channel; y is never written)
 template <int EPI>
 __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                      const unsigned *__restrict__ ufrag,
-                                                                     const float *__restrict__ bias, int n, int h, int w, int d,
-                                                                     int log2d, unsigned in_bytes, const float *__restrict__ head
+                                                                     const float *__restrict__ bias, w6geom G, const float *__restrict__ head
 #ifdef UBD_STAMPS
                                                                      , unsigned long long *__restrict__ stamps
 #endif
@@ -126,83 +143,81 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     __shared__ __attribute__((aligned(16))) unsigned s_u[UBD_WINO6_FRAG_U32];       // 96 KiB
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
-    // products are issued as D = U^T . V^T (A operand = weights): D col = lane & 15 = tile, row = 4q + reg = channel, so
-    // a lane ends up with four consecutive channels (4q.. of N-tile 0, 16+4q.. of N-tile 1 for q < 2) of its own tile
-    f32x4 bA = *(const f32x4 *)(bias + 4 * q), bB = {0.f, 0.f, 0.f, 0.f};
-    if (q < 2) bB = *(const f32x4 *)(bias + 16 + 4 * q);
+    const int h = G.h, w = G.w, d = G.d, log2d = G.log2d, dm1 = G.d - 1;
+    // Bias and head weights stay in registers for the whole kernel (8 + 8): loaded in the epilogue they cost a vmcnt(0) wait behind the
+    // NEXT group's sample rows, which are in flight by then; read from an LDS table there (two ds_read_b128 per group) they came back
+    // with element 1 of the second read in lanes 12..15 of every 16 on a few per cent of the groups, run to run different -- not
+    // understood (tools/_ab notes, round 6), so the table was dropped.
+    const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
+    const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
     float hbias = 0.f;
     if constexpr (EPI == 2) {
         hA = *(const f32x4 *)(head + 4 * q);
         if (q < 2) hB = *(const f32x4 *)(head + 16 + 4 * q);
-        hbias = head[UBD_C];
+        hbias = head[UBD_C];            // wave-uniform: one scalar load
     }
-    const int dm1 = d - 1;
-    const int half_rows = ((h + 2 * d - 1) / (2 * d)) * d;       // rows y that pair with y + d
-    const int half_cols = ((w + 2 * d - 1) / (2 * d)) * d;
-    const int groups_x = (half_cols + 15) >> 4;
-    const int total = n * half_rows * groups_x;
     // XCD-aware split (see dilconv_f32_kernel)
     const int xcd = blockIdx.x & 7;
     const int nblk_x = (gridDim.x + 7 - xcd) >> 3;
-    const int chunk = (total + 7) >> 3;
+    const int chunk = (int)((G.total + 7) >> 3);
     const int g_begin = xcd * chunk;
-    const int g_end = (g_begin + chunk < total) ? g_begin + chunk : total;
+    const int g_end = (g_begin + chunk < (int)G.total) ? g_begin + chunk : (int)G.total;
     const int stride = nblk_x * W6_WAVES;
 
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)(EPI == 2 ? in_bytes / UBD_C : in_bytes), 0x00020000);
-    const unsigned oob = in_bytes;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)G.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)(EPI == 2 ? G.in_bytes / UBD_C : G.in_bytes), 0x00020000);
 
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int g = g_begin + (int)(blockIdx.x >> 3) * W6_WAVES + wave_in_block;
     const int g_last = g_end - 1;
-
-    // separable offsets as in wino.hip: wave-uniform row term + per-lane column term; an out-of-image term is 2^30, so the
-    // sum of any invalid pair is out of range for the descriptor and the load returns the zero padding
     const unsigned BIG = 0x40000000u;
-    unsigned cq4[4];
-    const unsigned dq2 = 64u - 8u * q;
-    auto tile_col = [&](int gg) {
-        const int gx = (int)((unsigned)gg % (unsigned)groups_x);
-        const int tcol = gx * 16 + i;
-        return ((tcol >> log2d) << (log2d + 1)) + (tcol & dm1);
-    };
-    auto set_cols = [&](int gg) {
-        const int xj = tile_col(gg);
+    const unsigned lane4 = 16u * q, lane2 = 64u + 8u * q;
+
+    auto set_addr = [&](w6addr &A, int gg) {
+        const unsigned rs = G.groups_x == 1u ? (unsigned)gg : __umulhi((unsigned)gg, G.magic_gx);           // gg / groups_x
+        const unsigned gx = (unsigned)gg - rs * G.groups_x;
+        const unsigned img = G.half_rows == 1u ? rs : __umulhi(rs, G.magic_hr);                             // rs / half_rows
+        const unsigned s = rs - img * G.half_rows;
+        const int y0 = (int)(((s >> log2d) << (log2d + 1)) + (s & (unsigned)dm1));
+        const unsigned img_row = img * (unsigned)h;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int iy = y0 + (a - 1) * d;
+            const bool ok = iy >= 0 && iy < h;
+            A.row[a] = ok ? (img_row + (unsigned)iy) * (unsigned)w * (unsigned)(UBD_C * 4) : BIG;
+            if (EPI == 2 && (a == 1 || a == 2)) A.lrow[a - 1] = ok ? (img_row + (unsigned)iy) * (unsigned)w * 4u : BIG;
+        }
+        const int tcol = (int)gx * 16 + i;
+        const int xj = ((tcol >> log2d) << (log2d + 1)) + (tcol & dm1);   // this lane's tile column (pixel x of output (., 0))
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int ix = xj + (b - 1) * d;
             const bool ok = (unsigned)ix < (unsigned)w;
             const unsigned cb = (unsigned)ix * (unsigned)(UBD_C * 4);
-            cq4[b] = ok ? cb + 16u * q : BIG;
+            A.c4[b] = ok ? cb + lane4 : BIG;
+            A.c2[b] = ok ? cb + lane2 : BIG;
         }
     };
-    auto row_term = [&](int gg, int dy) {
-        const int rs = (int)((unsigned)gg / (unsigned)groups_x);
-        const int s = (int)((unsigned)rs % (unsigned)half_rows);
-        const int img = (int)((unsigned)rs / (unsigned)half_rows);
-        const int iy = ((s >> log2d) << (log2d + 1)) + (s & dm1) + dy;
-        return (iy >= 0 && iy < h) ? (unsigned)((img * h + iy) * w) * (unsigned)(UBD_C * 4) : BIG;
-    };
-    auto load_row = [&](w6samples &D, int gg, int a) {
-        const unsigned rb = row_term(gg, (a - 1) * d);
+    auto load_row = [&](w6samples &D, const w6addr &A, int a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(rb + cq4[b]), 0, 0);
-            u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(rb + cq4[b] + dq2), 0, 0);
-            D.v4[a][b] = __builtin_bit_cast(f32x4, r4);
-            D.v2[a][b] = __builtin_bit_cast(f32x2, r2);
+            D.v4[a][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)A.c4[b], (int)A.row[a], 0));
+            D.v2[a][b] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)A.c2[b], (int)A.row[a], 0));
         }
     };
 
+    // Sample rows are fetched just in time so that at most three of the four are live.  The first samples are requested before the
+    // block copies U into LDS: their latency hides behind the copy.
     w6samples D;
+    w6addr A, An;
     WSTAMP(0);
-    set_cols(g < g_last ? g : g_last);
-    load_row(D, g < g_last ? g : g_last, 0);
-    load_row(D, g < g_last ? g : g_last, 2);
+    set_addr(A, g < g_last ? g : g_last);
+    load_row(D, A, 0);
+    load_row(D, A, 2);
     {
-        // U (96 KiB) to LDS by LDS-DMA: 96 pieces of 1 KiB, 12 per wave
+        // U (96 KiB) to LDS by LDS-DMA: 96 pieces of 1 KiB, 12 per wave (asm form: outside hipcc's bookkeeping, retired by the
+        // vmcnt(0) below whatever hipcc does with the sample loads around it; the raw barrier publishes everyone's pieces)
         constexpr int PER_WAVE = UBD_WINO6_FRAG_U32 * 4 / 1024 / W6_WAVES;
         const unsigned lds_u = ubd_lds_addr(s_u);
 #pragma unroll
@@ -217,126 +232,160 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     if (g >= g_end) return;
     int gcount = 0;
     const u32x4 *su4 = (const u32x4 *)s_u + lane;
+    // Schedule of one transform point xi = 4a + b (16 per group, fully unrolled):
+    //   1. request the point's weights (6 ds_read_b128: 2 N tiles x 3 pieces);
+    //   2. split the lane's six values of V[a][b] into three bf16 pieces (12 v_and + 6 v_pk_add + 9 v_perm; hides the LDS latency);
+    //   3. 12 MFMAs, the two N tiles' chains alternating (no back-to-back dependent pair), with the vector work that does not
+    //      feed them in the gaps: the output transform of point xi - 1 (whose accumulators are complete by now) and, at b = 3,
+    //      the input transform of row a + 1.
     for (;;) {
         f32x4 Y[2][2][2];      // [output row rr][output col c][nt]
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            // T = (B^T D)[a], V[a][b] = (T B)[b]
-            f32x4 V4[4];
-            f32x2 V2[4];
-            {
-                f32x4 T4[4];
-                f32x2 T2[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (a == 0) { T4[b] = vsub(D.v4[0][b], D.v4[2][b]); T2[b] = vsub(D.v2[0][b], D.v2[2][b]); }
-                    else if (a == 1) { T4[b] = vadd(D.v4[1][b], D.v4[2][b]); T2[b] = vadd(D.v2[1][b], D.v2[2][b]); }
-                    else if (a == 2) { T4[b] = vsub(D.v4[2][b], D.v4[1][b]); T2[b] = vsub(D.v2[2][b], D.v2[1][b]); }
-                    else { T4[b] = vsub(D.v4[1][b], D.v4[3][b]); T2[b] = vsub(D.v2[1][b], D.v2[3][b]); }
-                }
-                V4[0] = vsub(T4[0], T4[2]); V4[1] = vadd(T4[1], T4[2]); V4[2] = vsub(T4[2], T4[1]); V4[3] = vsub(T4[1], T4[3]);
-                V2[0] = vsub(T2[0], T2[2]); V2[1] = vadd(T2[1], T2[2]); V2[2] = vsub(T2[2], T2[1]); V2[3] = vsub(T2[1], T2[3]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (a == 0) load_row(D, g, 1);                   // sample row 0 is dead
-            if (a == 2) load_row(D, g, 3);                   // sample row 2 is dead
-            if (a == 3) {
-                const int gn = g + stride;
-                set_cols(gn < g_last ? gn : g_last);
-                load_row(D, gn < g_last ? gn : g_last, 0);
-                load_row(D, gn < g_last ? gn : g_last, 2);
-            }
-            f32x4 Z0[2], Z1[2];
+        f32x4 Z0[2], Z1[2];    // output transform along b of the current row a
+        f32x4 mprev[2];        // accumulators of the previous point
+        f32x4 V4[4];           // V[a][b], channels 4q .. 4q+3
+        f32x2 V2[4];           //          channels 16+2q, 17+2q
+        // V[a] = (B^T D)[a] B from the sample rows that row a needs
+        auto make_v = [&](int a) {
+            f32x4 T4[4];
+            f32x2 T2[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int xi = a * 4 + b;
-                // this point's weights: 2 N tiles x 3 pieces, requested before the split so that their latency hides under it
-                u32x4 U[2][3];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) U[nt][pc] = su4[((xi * 2 + nt) * 3 + pc) * 64];
-                // three-way split of the lane's six values of V[a][b]
-                const float v0 = V4[b][0], v1 = V4[b][1], v2 = V4[b][2], v3 = V4[b][3], v4 = V2[b][0], v5 = V2[b][1];
-                const float r0 = resid(v0), r1 = resid(v1), r2 = resid(v2), r3 = resid(v3), r4 = resid(v4), r5 = resid(v5);
-                const float s0 = resid(r0), s1 = resid(r1), s2 = resid(r2), s3 = resid(r3), s4 = resid(r4), s5 = resid(r5);
-                const u32x4 P1 = {pack_hi(v0, v1), pack_hi(v2, v3), pack_hi(v4, v5), 0u};
-                const u32x4 P2 = {pack_hi(r0, r1), pack_hi(r2, r3), pack_hi(r4, r5), 0u};
-                const u32x4 P3 = {pack_hi(s0, s1), pack_hi(s2, s3), pack_hi(s4, s5), 0u};
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 m = {0.f, 0.f, 0.f, 0.f};
-                    m = mfma16(U[nt][2], P1, m);             // smallest terms first: the large one is rounded once
-                    m = mfma16(U[nt][0], P3, m);
-                    m = mfma16(U[nt][1], P2, m);
-                    m = mfma16(U[nt][1], P1, m);
-                    m = mfma16(U[nt][0], P2, m);
-                    m = mfma16(U[nt][0], P1, m);
-                    // output transform along b
-                    if (b == 0) Z0[nt] = m;
-                    else if (b == 1) { Z0[nt] = madd(Z0[nt], m); Z1[nt] = m; }
-                    else if (b == 2) { Z0[nt] = madd(Z0[nt], m); Z1[nt] = msub(Z1[nt], m); }
-                    else Z1[nt] = msub(Z1[nt], m);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                if (a == 0) { T4[b] = D.v4[0][b] - D.v4[2][b]; T2[b] = D.v2[0][b] - D.v2[2][b]; }
+                else if (a == 1) { T4[b] = D.v4[1][b] + D.v4[2][b]; T2[b] = D.v2[1][b] + D.v2[2][b]; }
+                else if (a == 2) { T4[b] = D.v4[2][b] - D.v4[1][b]; T2[b] = D.v2[2][b] - D.v2[1][b]; }
+                else { T4[b] = D.v4[1][b] - D.v4[3][b]; T2[b] = D.v2[1][b] - D.v2[3][b]; }
             }
-            // accumulate along a
+            V4[0] = T4[0] - T4[2]; V4[1] = T4[1] + T4[2]; V4[2] = T4[2] - T4[1]; V4[3] = T4[1] - T4[3];
+            V2[0] = T2[0] - T2[2]; V2[1] = T2[1] + T2[2]; V2[2] = T2[2] - T2[1]; V2[3] = T2[1] - T2[3];
+        };
+        // output transform of point (a, b) with accumulators m: along b into Z, at b == 3 along a into Y
+        auto consume = [&](int a, int b, const f32x4 (&m)[2]) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                if (a == 0) { Y[0][0][nt] = Z0[nt]; Y[0][1][nt] = Z1[nt]; }
-                else if (a == 1) { Y[0][0][nt] = madd(Y[0][0][nt], Z0[nt]); Y[0][1][nt] = madd(Y[0][1][nt], Z1[nt]); Y[1][0][nt] = Z0[nt]; Y[1][1][nt] = Z1[nt]; }
-                else if (a == 2) { Y[0][0][nt] = madd(Y[0][0][nt], Z0[nt]); Y[0][1][nt] = madd(Y[0][1][nt], Z1[nt]); Y[1][0][nt] = msub(Y[1][0][nt], Z0[nt]); Y[1][1][nt] = msub(Y[1][1][nt], Z1[nt]); }
-                else { Y[1][0][nt] = msub(Y[1][0][nt], Z0[nt]); Y[1][1][nt] = msub(Y[1][1][nt], Z1[nt]); }
+                if (b == 0) Z0[nt] = m[nt];
+                else if (b == 1) { Z0[nt] += m[nt]; Z1[nt] = m[nt]; }
+                else if (b == 2) { Z0[nt] += m[nt]; Z1[nt] -= m[nt]; }
+                else {
+                    Z1[nt] -= m[nt];
+                    if (a == 0) { Y[0][0][nt] = Z0[nt]; Y[0][1][nt] = Z1[nt]; }
+                    else if (a == 1) { Y[0][0][nt] += Z0[nt]; Y[0][1][nt] += Z1[nt]; Y[1][0][nt] = Z0[nt]; Y[1][1][nt] = Z1[nt]; }
+                    else if (a == 2) { Y[0][0][nt] += Z0[nt]; Y[0][1][nt] += Z1[nt]; Y[1][0][nt] -= Z0[nt]; Y[1][1][nt] -= Z1[nt]; }
+                    else { Y[1][0][nt] -= Z0[nt]; Y[1][1][nt] -= Z1[nt]; }
+                }
             }
+        };
+        make_v(0);                                           // sample rows 0 and 2 (requested under the previous group)
+        load_row(D, A, 1);                                   // sample row 0 is dead
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const int a = xi >> 2, b = xi & 3;
+            u32x4 U[2][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) U[nt][pc] = su4[((xi * 2 + nt) * 3 + pc) * 64];
+            const f32x4 r4 = resid(V4[b]), t4 = resid(r4);
+            const f32x2 r2 = resid(V2[b]), t2 = resid(r2);
+            const u32x4 P1 = pack6(V4[b], V2[b]);
+#ifndef W6_EXP_NOSPLIT
+            const u32x4 P2 = pack6(r4, r2);
+            const u32x4 P3 = pack6(t4, t2);
+#else
+#define P2 P1
+#define P3 P1
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 m[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#ifdef W6_EXP_FEWMFMA
+            const u32x4 PX = P1 ^ P2 ^ P3;
+            m[0] = mfma16(U[0][0] ^ U[0][1] ^ U[0][2], PX, m[0]); m[1] = mfma16(U[1][0] ^ U[1][1] ^ U[1][2], PX, m[1]);
+#else
+            // smallest terms first: the large one is rounded once
+            m[0] = mfma16(U[0][2], P1, m[0]); m[1] = mfma16(U[1][2], P1, m[1]);
+            m[0] = mfma16(U[0][0], P3, m[0]); m[1] = mfma16(U[1][0], P3, m[1]);
+            m[0] = mfma16(U[0][1], P2, m[0]); m[1] = mfma16(U[1][1], P2, m[1]);
+            m[0] = mfma16(U[0][1], P1, m[0]); m[1] = mfma16(U[1][1], P1, m[1]);
+            m[0] = mfma16(U[0][0], P2, m[0]); m[1] = mfma16(U[1][0], P2, m[1]);
+            m[0] = mfma16(U[0][0], P1, m[0]); m[1] = mfma16(U[1][0], P1, m[1]);
+#endif
+#ifndef W6_LEAN
+            if (xi > 0) consume((xi - 1) >> 2, (xi - 1) & 3, mprev);
+#endif
+            if (b == 3 && a < 3) {
+                make_v(a + 1);
+                if (a == 1) load_row(D, A, 3);               // sample row 2 is dead (rows 1 and 3 make row 3)
+                if (a == 2) {
+                    // all sample rows are dead: rows 0 and 2 of the next group.  Unconditional (clamped) so that hipcc counts
+                    // the outstanding loads exactly.
+                    const int gn = g + stride;
+                    set_addr(An, gn < g_last ? gn : g_last);
+                    load_row(D, An, 0);
+                    load_row(D, An, 2);
+                }
+            }
+#ifndef W6_NOSHADOW
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions in its shadow
+            }
+#else
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);         // the MFMAs back to back, the rest after them
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef W6_LEAN
+            consume(a, b, m);
+#else
+            mprev[0] = m[0]; mprev[1] = m[1];
+#endif
+#ifdef UBD_STAMPS
+            if (gcount == 1 && (xi & 3) == 3) WSTAMP(2 + (xi >> 2));
+#endif
         }
+#ifndef W6_LEAN
+        consume(3, 3, mprev);
+#endif
 
-        // ---- epilogue: lane = (tile i of the group, channel quarter q); registers = 4 consecutive channels
+        // ---- epilogue: lane = (tile i of the group, channel quarter q); registers = 4 consecutive channels.
+        // Output (rr, c) is the pixel of sample (row 1 + rr, column 1 + c): its address terms are already there.
         {
-            const int xo0 = tile_col(g);
-            const int rs_e = (int)((unsigned)g / (unsigned)groups_x);
-            const int s_e = (int)((unsigned)rs_e % (unsigned)half_rows);
-            const int img = (int)((unsigned)rs_e / (unsigned)half_rows);
-            const int y0 = ((s_e >> log2d) << (log2d + 1)) + (s_e & dm1);
-            unsigned st0[2], st1[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int xo = xo0 + c * d;
-                const unsigned cb = (unsigned)xo * (unsigned)(UBD_C * 4) + 16u * q;
-                st0[c] = xo < w ? cb : BIG;
-                st1[c] = (xo < w && q < 2) ? cb + 64u : BIG;
-            }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int yo = y0 + rr * d;
-                const unsigned rb = row_term(g, rr * d);     // BIG below the image
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const int xo = xo0 + c * d;
-                    const bool ok = yo < h && xo < w;
-                    f32x4 v0, v1;
+                    f32x4 v0 = Y[rr][c][0] + bA, v1 = Y[rr][c][1] + bB;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(Y[rr][c][0][r] + bA[r], 0.f); v1[r] = fmaxf(Y[rr][c][1][r] + bB[r], 0.f); }
+                    for (int r = 0; r < 4; ++r) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
                     if constexpr (EPI == 2) {
                         float part = 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) part = fmaf(v0[r], hA[r], part);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) part = fmaf(v1[r], hB[r], part);      // hB = 0 for q >= 2
-                        part += __shfl_xor(part, 16, 64);
+                        part += __shfl_xor(part, 16, 64);                                   // sum over the four channel quarters
                         part += __shfl_xor(part, 32, 64);
-                        const unsigned pix = (unsigned)(img * h + yo) * (unsigned)w + (unsigned)xo;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part + hbias), yrsrc, (int)((ok && q == 0) ? pix * 4u : oob), 0, 0);
+                        // logit offset = pixel * 4: the column term is (c4 - 16q) / 24 for lane quarter 0
+                        const unsigned lcol = (q == 0 && A.c4[1 + c] != BIG) ? A.c4[1 + c] / (unsigned)UBD_C : BIG;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part + hbias), yrsrc, (int)(lcol + A.lrow[rr]), 0, 0);
                     } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)(rb + st0[c]), 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)(rb + st1[c]), 0, 0);
+                        const unsigned st1 = (q < 2 && A.c4[1 + c] != BIG) ? A.c4[1 + c] + 64u : BIG;
+                        // Stores take the row term in the VECTOR offset: with it in soffset, hipcc's hazard recogniser assumes that a wide
+                        // store followed at once by a vector write to its data registers is safe (true of older chips) and inserts no
+                        // wait state; on gfx950 ~0.1 % of the pixels of a 32 x 128 x 128 launch then carried a LATER value (an address
+                        // integer) in one dword, different ones run to run (tools/_ab/chk_bias.py, round 6).
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)(A.c4[1 + c] + A.row[1 + rr]), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)(st1 + A.row[1 + rr]), 0, 0);
                     }
                 }
-            }
         }
+#ifdef UBD_STAMPS
+        if (gcount == 1) WSTAMP(6);
+        if (gcount == 0) WSTAMP(1);                          // re-stamped: start of the second group
+#endif
         ++gcount;
-        if (gcount <= 5) WSTAMP(1 + gcount);
         g += stride;
         if (g >= g_end) break;
+        A = An;
     }
     WSTAMP(7);
 }
@@ -352,14 +401,22 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 void ubd_launch_dilconv_wino6(const ubd_handle *h, int epi, const unsigned *frag, const float *bias, int dilation,
                               const float *in, float *out, int n, int H4, int W4, hipStream_t st, const float *head)
 {
-    const unsigned in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
     const int d = dilation;
     const long half_rows = ((H4 + 2 * d - 1) / (2 * d)) * d, half_cols = ((W4 + 2 * d - 1) / (2 * d)) * d;
-    const long groups = (long)n * half_rows * ((half_cols + 15) / 16);
+    const long groups_x = (half_cols + 15) / 16;
+    const long groups = (long)n * half_rows * groups_x;
+    w6geom G;
+    G.n = n; G.h = H4; G.w = W4; G.d = d; G.log2d = ilog2(d);
+    G.in_bytes = (unsigned)((size_t)n * H4 * W4 * UBD_C * 4);
+    G.groups_x = (unsigned)groups_x; G.half_rows = (unsigned)half_rows; G.total = (unsigned)groups;
+    // floor(v / D) = (v * m) >> 32 with m = floor((2^32 - 1) / D) + 1, exact while v * D < 2^32: v < groups <= 2^30 / 96 / 4 pixels
+    // ... / 16 and D <= 2^12 for every supported shape (tensor bytes <= 2^30); D = 1 needs the identity
+    G.magic_gx = groups_x == 1 ? 0u : (unsigned)(0xFFFFFFFFul / (unsigned long)groups_x + 1ul);
+    G.magic_hr = half_rows == 1 ? 0u : (unsigned)(0xFFFFFFFFul / (unsigned long)half_rows + 1ul);
     int grid = ubd_grid_for(groups, h->num_cus, W6_WAVES, 1);     // 96 KiB of LDS: one 8-wave block per CU
     grid = (grid + 7) / 8 * 8;
     if (epi == 2)
-        hipLaunchKernelGGL((dilconv_wino6_kernel<2>), dim3(grid), dim3(64 * W6_WAVES), 0, st, in, out, frag, bias, n, H4, W4, d, ilog2(d), in_bytes, head WSTAMP_ARG);
+        hipLaunchKernelGGL((dilconv_wino6_kernel<2>), dim3(grid), dim3(64 * W6_WAVES), 0, st, in, out, frag, bias, G, head WSTAMP_ARG);
     else
-        hipLaunchKernelGGL((dilconv_wino6_kernel<0>), dim3(grid), dim3(64 * W6_WAVES), 0, st, in, out, frag, bias, n, H4, W4, d, ilog2(d), in_bytes, nullptr WSTAMP_ARG);
+        hipLaunchKernelGGL((dilconv_wino6_kernel<0>), dim3(grid), dim3(64 * W6_WAVES), 0, st, in, out, frag, bias, G, nullptr WSTAMP_ARG);
 }
