@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define UBD_ABI_VERSION 2
+#define UBD_ABI_VERSION 3
 
 /* activation storage / compute dtype (weights, logits, loss and gradients are fp32) */
 enum { UBD_F32 = 0, UBD_BF16 = 1, UBD_F16 = 2 };

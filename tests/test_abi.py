@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/ubd.h but not exported"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.ubd_abi_version() == 2
+    assert lib.ubd_abi_version() == 3
 
 
 def test_no_cpu_fallback():

@@ -28,6 +28,9 @@
 #define OP_ADD3(d) "v_add3_u32 " d ", %0, %3, %3\n"
 #define OP_ADDU(d) "v_add_u32 " d ", %0, %3\n"
 #define OP_ADDUS(d) "v_add_u32 " d ", %2, %3\n"
+#define OP_SDWA(d) "v_or_b32_sdwa " d ", %0, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define OP_MAXI(d) "v_max_i32 " d ", 0, %0\n"
+#define OP_OR(d) "v_or_b32 " d ", %0, %3\n"
 #define OP_SNOP(d) "s_nop 0\n"
 #define OP_SADD(d) "s_add_i32 s40, s41, s42\n"
 #define CLOB : "+v"(a) : "s"(sel), "s"(mask), "v"(b), "v"(pa), "v"(pb) : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v30", "v31", "s40", "s41", "s42"
@@ -61,12 +64,15 @@ template <int MODE, int NT> __global__ __launch_bounds__(NT) void k(float *out, 
         if constexpr (MODE == 20) asm volatile(R48(OP_ADDU) CLOB);
         if constexpr (MODE == 21) asm volatile(R48(OP_ADDUS) CLOB);
         if constexpr (MODE == 22) asm volatile(R48(OP_SNOP) CLOB);
-        if constexpr (MODE == 23) asm volatile(R48(OP_SADD) CLOB);
+        if constexpr (MODE == 23) asm volatile(R48(OP_SNOP) CLOB);
+        if constexpr (MODE == 24) asm volatile(R48(OP_SDWA) CLOB);
+        if constexpr (MODE == 25) asm volatile(R48(OP_MAXI) CLOB);
+        if constexpr (MODE == 26) asm volatile(R48(OP_OR) CLOB);
     }
     out[blockIdx.x * NT + threadIdx.x] = a;
 }
 static const char *names[] = {"v_add_f32", "v_sub_f32 (dependent on itself, 8 chains)", "v_and_b32 literal", "v_and_b32 sgpr", "v_perm_b32", "v_cvt_pk_bf16_f32", "v_pack_b32_f16 op_sel hi,hi",
-                              "v_and_or_b32", "v_bfi_b32", "v_alignbit_b32", "v_lshrrev_b32", "v_xor_b32", "v_fma_f32 (8 chains)", "v_mov_b32", "v_pk_add_f32", "v_pk_add_f32 neg", "v_pk_mul_f32", "v_med3_f32", "v_max_f32", "v_add3_u32", "v_add_u32", "v_add_u32 sgpr", "s_nop 0", "s_add_i32"};
+                              "v_and_or_b32", "v_bfi_b32", "v_alignbit_b32", "v_lshrrev_b32", "v_xor_b32", "v_fma_f32 (8 chains)", "v_mov_b32", "v_pk_add_f32", "v_pk_add_f32 neg", "v_pk_mul_f32", "v_med3_f32", "v_max_f32", "v_add3_u32", "v_add_u32", "v_add_u32 sgpr", "s_nop 0", "s_nop 0 (again)", "v_or_b32_sdwa src1 WORD_1", "v_max_i32", "v_or_b32"};
 template <int MODE, int NT> void run(float *out, float *in)
 {
     const int iters = 4000;
@@ -116,5 +122,8 @@ int main(int argc, char **argv)
     maybe<21>(want, out, in);
     maybe<22>(want, out, in);
     maybe<23>(want, out, in);
+    maybe<24>(want, out, in);
+    maybe<25>(want, out, in);
+    maybe<26>(want, out, in);
     return 0;
 }

@@ -13,7 +13,7 @@ UBD_PRE_NONE, UBD_PRE_MOBILENET = 0, 1
 UBD_COMM_FUSED = 1
 UBD_COMM_GLOBAL_LOSS = 2
 UBD_UNIQUE_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class UbdConfig(ctypes.Structure):
@@ -67,12 +67,14 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  ubdvss_amd has no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)
+        lib.ubd_abi_version.restype = ctypes.c_int
+        lib.ubd_abi_version.argtypes = []
+        if lib.ubd_abi_version() != ABI_VERSION:              # checked BEFORE the symbol table: a stale build says so instead of an AttributeError
+            raise RuntimeError(f"{LIB_PATH}: ABI {lib.ubd_abi_version()} != expected {ABI_VERSION}; rebuild (ubdvss_amd/csrc/build.sh)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError = stale build, surface it
             fn.restype = res
             fn.argtypes = args
-        if lib.ubd_abi_version() != ABI_VERSION:
-            raise RuntimeError(f"libubd_hip.so ABI {lib.ubd_abi_version()} != expected {ABI_VERSION}; rebuild")
         _lib = lib
     return _lib
 

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     set_addr(A, g < g_last ? g : g_last);
     load_row(D, A, 0);
     load_row(D, A, 2);
+    load_row(D, A, 1);
     {
         // U (96 KiB) to LDS by LDS-DMA: 96 pieces of 1 KiB, 12 per wave (asm form: outside hipcc's bookkeeping, retired by the
         // vmcnt(0) below whatever hipcc does with the sample loads around it; the raw barrier publishes everyone's pieces)
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     __builtin_amdgcn_s_barrier();
     WSTAMP(1);
     if (g >= g_end) return;
-    int gcount = 0;
+    [[maybe_unused]] int gcount = 0;
     const u32x4 *su4 = (const u32x4 *)s_u + lane;
     // Schedule of one transform point xi = 4a + b (16 per group, fully unrolled):
     //   1. request the point's weights (6 ds_read_b128: 2 N tiles x 3 pieces);
@@ -241,7 +242,6 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     for (;;) {
         f32x4 Y[2][2][2];      // [output row rr][output col c][nt]
         f32x4 Z0[2], Z1[2];    // output transform along b of the current row a
-        f32x4 mprev[2];        // accumulators of the previous point
         f32x4 V4[4];           // V[a][b], channels 4q .. 4q+3
         f32x2 V2[4];           //          channels 16+2q, 17+2q
         // V[a] = (B^T D)[a] B from the sample rows that row a needs
@@ -274,32 +274,28 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
                 }
             }
         };
-        make_v(0);                                           // sample rows 0 and 2 (requested under the previous group)
-        load_row(D, A, 1);                                   // sample row 0 is dead
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            const int a = xi >> 2, b = xi & 3;
-            u32x4 U[2][3];
+        make_v(0);                                           // sample rows 0 and 2 (requested under the previous group, like row 1)
+        // Software pipeline over the 16 points: the MFMA phase of point xi carries, two vector instructions behind each MFMA (the part
+        // of an MFMA's 16 cycles in which the vector issue port is free), the truncation residuals of point xi + 1; the tail of the
+        // phase requests the weights of xi + 1, packs its three operand quads, and transforms the accumulators of xi.
+        u32x4 U[2][3];
+        u32x4 P1, P2, P3;
+        f32x4 r4, t4;
+        f32x2 r2, t2;
+        auto load_u = [&](int xi) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) U[nt][pc] = su4[((xi * 2 + nt) * 3 + pc) * 64];
-            const f32x4 r4 = resid(V4[b]), t4 = resid(r4);
-            const f32x2 r2 = resid(V2[b]), t2 = resid(r2);
-            const u32x4 P1 = pack6(V4[b], V2[b]);
-#ifndef W6_EXP_NOSPLIT
-            const u32x4 P2 = pack6(r4, r2);
-            const u32x4 P3 = pack6(t4, t2);
-#else
-#define P2 P1
-#define P3 P1
-#endif
+        };
+        load_u(0);
+        r4 = resid(V4[0]); t4 = resid(r4); r2 = resid(V2[0]); t2 = resid(r2);
+        P1 = pack6(V4[0], V2[0]); P2 = pack6(r4, r2); P3 = pack6(t4, t2);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const int a = xi >> 2, b = xi & 3;
             __builtin_amdgcn_sched_barrier(0);
             f32x4 m[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#ifdef W6_EXP_FEWMFMA
-            const u32x4 PX = P1 ^ P2 ^ P3;
-            m[0] = mfma16(U[0][0] ^ U[0][1] ^ U[0][2], PX, m[0]); m[1] = mfma16(U[1][0] ^ U[1][1] ^ U[1][2], PX, m[1]);
-#else
             // smallest terms first: the large one is rounded once
             m[0] = mfma16(U[0][2], P1, m[0]); m[1] = mfma16(U[1][2], P1, m[1]);
             m[0] = mfma16(U[0][0], P3, m[0]); m[1] = mfma16(U[1][0], P3, m[1]);
@@ -307,10 +303,16 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
             m[0] = mfma16(U[0][1], P1, m[0]); m[1] = mfma16(U[1][1], P1, m[1]);
             m[0] = mfma16(U[0][0], P2, m[0]); m[1] = mfma16(U[1][0], P2, m[1]);
             m[0] = mfma16(U[0][0], P1, m[0]); m[1] = mfma16(U[1][0], P1, m[1]);
-#endif
-#ifndef W6_LEAN
-            if (xi > 0) consume((xi - 1) >> 2, (xi - 1) & 3, mprev);
-#endif
+            // in the MFMAs' shadows: residuals of the next point of this row (b < 3: V[b + 1] is there; the next row's V does not exist yet)
+            if (b < 3) { r4 = resid(V4[b + 1]); t4 = resid(r4); r2 = resid(V2[b + 1]); t2 = resid(r2); }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions in its shadow
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // tail: weights of the next point (the MFMAs above have read theirs), its operands, this point's output transform
+            if (xi < 15) load_u(xi + 1);
             if (b == 3 && a < 3) {
                 make_v(a + 1);
                 if (a == 1) load_row(D, A, 3);               // sample row 2 is dead (rows 1 and 3 make row 3)
@@ -322,29 +324,19 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
                     load_row(D, An, 0);
                     load_row(D, An, 2);
                 }
+                r4 = resid(V4[0]); t4 = resid(r4); r2 = resid(V2[0]); t2 = resid(r2);
             }
-#ifndef W6_NOSHADOW
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two vector instructions in its shadow
-            }
-#else
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);         // the MFMAs back to back, the rest after them
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef W6_LEAN
+            if (xi < 15) { const int bn = (b + 1) & 3; P1 = pack6(V4[bn], V2[bn]); P2 = pack6(r4, r2); P3 = pack6(t4, t2); }
             consume(a, b, m);
-#else
-            mprev[0] = m[0]; mprev[1] = m[1];
-#endif
 #ifdef UBD_STAMPS
             if (gcount == 1 && (xi & 3) == 3) WSTAMP(2 + (xi >> 2));
 #endif
         }
-#ifndef W6_LEAN
-        consume(3, 3, mprev);
-#endif
+        // Row 1 of the NEXT group is requested here, BEFORE this group's stores: the vector-memory counter retires in issue order, so a
+        // load issued after the stores is only known to have landed once the stores have been acknowledged -- the wait for row 1 (three
+        // points into the next group) then ended with the stores' round trip to L2, ~1 us later than the load itself (the kernel ran
+        // in 27.6 us without its stores and 21 us without its loads against 33 us, round 6).  Rows 0 and 2 went out at point 11.
+        load_row(D, An, 1);
 
         // ---- epilogue: lane = (tile i of the group, channel quarter q); registers = 4 consecutive channels.
         // Output (rr, c) is the pixel of sample (row 1 + rr, column 1 + c): its address terms are already there.

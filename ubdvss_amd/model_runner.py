@@ -147,7 +147,10 @@ class ModelRunner:
         pinned, dev_in, host_res = [None] * NPIN, [None] * NDEV, [None] * NRES
         fwd_done, d2h_done = [None] * NDEV, [None] * NRES
         inflight = []                                   # [batch index, device results, d2h event or None, meta]
+        if rescale and meta_infos is None:
+            raise AssertionError("rescale=True needs meta_infos (one list of meta_info per batch)")     # predict()'s rule (model_runner.py:116-117)
         metas = iter(meta_infos) if meta_infos is not None else None
+        _MISSING = object()
         free_slots, staged = queue.Queue(), queue.Queue(maxsize=NPIN - 1)
         for slot in range(NPIN):
             free_slots.put((slot, None))
@@ -158,6 +161,7 @@ class ModelRunner:
         def stager():
             """host side of the copy-in, its own thread: batch -> pinned staging buffer, ahead of the stream work"""
             try:
+                torch.cuda.set_device(dev)              # a new thread starts on cuda:0: pinned allocations / event waits belong to the model's device
                 for k, x in enumerate(batches):
                     if stop.is_set():
                         return
@@ -177,9 +181,14 @@ class ModelRunner:
                     # interpreter away from the consumer thread at every hand-over (enqueue 0.15 -> 0.35 -> 0.8 ms at 2 / 4 / 8 threads)
                     lib.ubd_host_memcpy_mt(dst.ctypes.data, x.ctypes.data, x.nbytes, int(copy_threads))
                     stats["stager_copy_s"] += time.perf_counter() - tc       # the staging thread's own time (not the consumer's)
-                    staged.put((k, slot, next(metas) if metas is not None else None))
+                    meta = None
+                    if metas is not None:
+                        meta = next(metas, _MISSING)
+                        if meta is _MISSING:
+                            raise ValueError(f"meta_infos ended before the batches did (batch {k} has none)")
+                    staged.put((k, slot, meta))
                 staged.put(None)
-            except BaseException as e:                  # noqa: BLE001 -- re-raised by the consumer
+            except Exception as e:                      # noqa: BLE001 -- re-raised by the consumer
                 staged.put(e)
 
         def copy_in(item):
@@ -272,7 +281,15 @@ class ModelRunner:
                 yield deliver(inflight.pop(0))
         finally:
             stop.set()
-            while th.is_alive():                                    # a consumer that stopped early: unblock the stager
+            # An early exit (the consumer stopped, the stager failed, _assemble raised) can leave a prefetched host -> device copy or a
+            # device -> host copy in flight on the side streams.  The buffers they touch were allocated on the compute stream: once this
+            # frame drops them the caching allocator may hand the blocks to the next allocation on that stream, and the late copy would
+            # write into an unrelated tensor.  Drain both side streams before anything goes out of scope.
+            s_in.synchronize()
+            s_out.synchronize()
+            for _ in range(40):                                     # a consumer that stopped early: unblock the stager (bounded: the thread is a
+                if not th.is_alive():                               # daemon, and one that is blocked inside next(batches) cannot see `stop`)
+                    break
                 try:
                     staged.get_nowait()
                 except queue.Empty:
