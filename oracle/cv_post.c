@@ -19,6 +19,36 @@
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, so that float32
  * arithmetic is plain IEEE like OpenCV's generic x86-64 build).
+ *
+ * ATTRIBUTION.  The operation order, the tie rules and several identifiers below
+ * (lnbd, Sklansky_, tl_stack, inv_vect_length, rotatingCalipers ...) follow the
+ * OpenCV 3.4 sources named above on purpose: bit-exact quads need OpenCV's exact
+ * float32 arithmetic.  OpenCV is distributed under the 3-clause BSD license:
+ *   Copyright (C) 2000-2008, Intel Corporation, all rights reserved.
+ *   Copyright (C) 2009-2011, Willow Garage Inc., all rights reserved.
+ *   Copyright (C) 2009-2016, NVIDIA Corporation, all rights reserved.
+ *   Copyright (C) 2010-2013, Advanced Micro Devices, Inc., all rights reserved.
+ *   Copyright (C) 2015-2016, OpenCV Foundation, all rights reserved.
+ *   Copyright (C) 2015-2016, Itseez Inc., all rights reserved.
+ *   Third party copyrights are property of their respective owners.
+ * Redistribution and use in source and binary forms, with or without modification,
+ * are permitted provided that the following conditions are met: redistributions of
+ * source code must retain the above copyright notice, this list of conditions and
+ * the following disclaimer; redistributions in binary form must reproduce them in
+ * the documentation and/or other materials provided with the distribution; neither
+ * the names of the copyright holders nor the names of the contributors may be used
+ * to endorse or promote products derived from this software without specific prior
+ * written permission.  This software is provided by the copyright holders and
+ * contributors "as is" and any express or implied warranties, including, but not
+ * limited to, the implied warranties of merchantability and fitness for a
+ * particular purpose are disclaimed.  In no event shall the copyright holders or
+ * contributors be liable for any direct, indirect, incidental, special, exemplary,
+ * or consequential damages however caused and on any theory of liability arising in
+ * any way out of the use of this software.
+ * The same notice covers the box fit of ubdvss_amd/csrc/postprocess.hip and
+ * pp_lds.h, which repeats this arithmetic on the device.
+ * An INDEPENDENT cross-check written from Suzuki & Abe's paper, not from OpenCV,
+ * is oracle/suzuki_abe.py (tests/test_oracle_hardening.py).
  */
 #include <math.h>
 #include <stdint.h>
