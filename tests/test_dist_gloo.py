@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -64,3 +65,15 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_readiness_command_picks_its_world_sizes():
+    """tools/dist_rccl_check.py (the one command for an 8-GPU node): world sizes 2, 4, 8 as far as the GPUs go, a clear refusal otherwise"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dist_rccl_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dist_rccl_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.worlds_for(8) == [2, 4, 8] and mod.worlds_for(4) == [2, 4] and mod.worlds_for(3) == [2] and mod.worlds_for(8, 8) == [8]
+    for bad in ((1, None), (8, 1), (2, 4)):
+        with pytest.raises(SystemExit):
+            mod.worlds_for(*bad)

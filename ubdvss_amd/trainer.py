@@ -44,7 +44,8 @@ class Trainer:
                 _lib.check(self._lib.ubd_broadcast_params(self.model._h, self.model.params.data_ptr(), self.model.params.numel(),
                                                           src, self.model._stream()), "ubd_broadcast_params")
         else:
-            distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
+            if self._pg is not False:
+                distributed.broadcast_parameters(self.model.params, src=src, group=self._pg)
         # c10d writes the tensor without bumping its version counter: invalidate the packed weight fragments
         self.model.invalidate_packed_weights()
 
@@ -80,6 +81,8 @@ class Trainer:
             # per-replica losses are averaged; the batch-global loss (UBD_COMM_GLOBAL_LOSS) is ONE objective whose parameter
             # gradient is the sum of the ranks' contributions
             grad_scale = 1.0 if getattr(self.model, "_global_loss", False) else 1.0 / world
+        elif self._pg is False:                                 # process_group=False: no collective at all, whatever torch.distributed holds
+            grad_scale = 1.0                                    # (the timing reference of tools/dist_rccl_check.py: one GPU on its shard alone)
         else:
             grad_scale = distributed.allreduce_gradients(self.grads, group=self._pg)
         self.iterations += 1
