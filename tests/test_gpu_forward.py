@@ -197,6 +197,56 @@ def test_direct_dilated_kernel_path(monkeypatch):
         _check(_model(cin, ncls, fml, w).predict(x), ref)
 
 
+def test_fp32_mfma_winograd_path_and_split_product_path(monkeypatch):
+    """UBD_DILCONV=wino32 keeps the round-2 form of the Winograd layer (products on v_mfma_f32_16x16x4_f32, wino.hip); the default since
+    round 6 computes every fp32 product of the transform-domain GEMMs as an exact three-way bf16 split on v_mfma_f32_16x16x32_bf16
+    (wino6.hip).  Both against the oracle with the SAME bounds, on shapes whose tile runs are ragged for every dilation (maps 18 x 25 and
+    33 x 17: sub-grids of one pixel at dilation 16, runs of 1 / 2 / 4 / 8 tiles), with and without the head in the last layer's epilogue;
+    and against each other: the two forms differ by rounding only (a few ulp of the layer's largest value per layer)."""
+    res = {}
+    for mode in ("wino32", ""):
+        if mode: monkeypatch.setenv("UBD_DILCONV", mode)
+        else: monkeypatch.delenv("UBD_DILCONV", raising=False)
+        for cin, ncls, fml, n, hh, ww in ((3, 0, True, 2, 72, 100), (1, 2, False, 1, 132, 68), (3, 0, False, 3, 64, 256)):
+            w = onet.init_weights(400 + cin + ncls, cin, ncls, bias_scale=0.25)
+            x = synthetic.noise_images(13, n, hh, ww, cin)
+            ref = onet.forward(x.astype(np.float64), w, fml)
+            lg = _model(cin, ncls, fml, w).predict(x)
+            _check(lg, ref)
+            res.setdefault((cin, ncls, hh), []).append((lg, ref))
+    for (a, ref), (b, _) in res.values():
+        assert np.abs(a.astype(np.float64) - b).max() <= 4e-6 * np.abs(ref).max() + 1e-7
+
+
+def test_split_product_layer_is_homogeneous_and_deterministic():
+    """The three-way split commutes with powers of two (every piece scales exactly): with zero biases the layer satisfies
+    f(2x) = 2 f(x) and f(x / 4) = f(x) / 4 BIT for bit; and two launches on the same input give the same bits (no atomics, fixed
+    order of the six products).  One dilated layer through ubd_dilated_layer, every dilation, 5 x 72 x 100 x 24."""
+    import ctypes
+    from ubdvss_amd import _lib
+    lib = _lib.load()
+    m = Model(NetConfig(grey=False), seed=21)
+    w = m.get_weights()
+    for i in range(10, 22, 2):
+        w[i] = np.zeros(24, np.float32)                      # biases of L4..L9
+    m.set_weights(w)
+    ws = torch.empty(int(lib.ubd_forward_workspace_bytes(m._h, 1, 4, 4)), dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ubd_pack_weights(m._h, m.params.data_ptr(), ws.data_ptr(), ws.numel(), st), "pack")
+    x = torch.rand((5, 72, 100, 24), device="cuda") - 0.3
+
+    def layer(k, inp):
+        y = torch.empty_like(inp)
+        _lib.check(lib.ubd_dilated_layer(m._h, m.params.data_ptr(), k, inp.data_ptr(), y.data_ptr(), 5, 72, 100, ws.data_ptr(), st), "dil")
+        return y
+    for k in range(6):
+        y1 = layer(k, x)
+        assert torch.equal(layer(k, x), y1)
+        assert torch.equal(layer(k, 2.0 * x), 2.0 * y1)
+        assert torch.equal(layer(k, 0.25 * x), 0.25 * y1)
+        assert float(y1.abs().max()) > 0.1
+
+
 def test_broadcast_invalidates_packed_fragments(monkeypatch):
     """c10d collectives write ``model.params`` without bumping its version counter: a rank that predicted
     before ``Trainer.broadcast_weights`` must not keep its old packed fragments.  The broadcast is emulated by a

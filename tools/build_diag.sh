@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../ubdvss_amd/csrc"
 OBJ=../../tools/_ab/_obj_diag
 mkdir -p $OBJ
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS -DUBD_EXPERIMENTAL_STEM123W $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -DUBD_STAMPS $DIAG_FLAGS"   # DIAG_FLAGS / DIAG_OUT: experiment builds
 pids=()
 for f in ${DIAG_FILES:-api forward fwd16 wino wino6 postprocess loss backward train comm raster}; do
   extra=""

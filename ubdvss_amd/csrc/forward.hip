@@ -444,9 +444,6 @@ extern "C" void ubd_debug_set_stamps(void *p) { g_ubd_stamps = (unsigned long lo
 #include "pp_lds.h"
 #include "stem23.h"
 #include "stem123.h"
-#ifdef UBD_EXPERIMENTAL_STEM123W   // tools/build_diag.sh only: the sixteen-wave re-cut of the one-kernel stem (measured slower, profiles/r05_experiment_notes.txt)
-#include "stem123w.h"
-#endif
 
 // ------------------------------------------------------------------------------------
 // Dense dilated 3x3 conv 24 -> 24 (+bias+ReLU), fp32 MFMA, weights resident in VGPRs.
@@ -803,12 +800,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
 #else
 #define S123_STAMP_ARG
 #endif
-#ifdef UBD_EXPERIMENTAL_STEM123W
-#define UBD_LAUNCH_S123(CINV, U8V, PLV) do { if (h->fuse_stem == 3) hipLaunchKernelGGL((stem123w_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s123w_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG); \
-        else hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG); } while (0)
-#else
 #define UBD_LAUNCH_S123(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123_STAMP_ARG)
-#endif
         const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30) && ((uintptr_t)images & 15) == 0;   // fp32 fed as it is: 16-byte LDS-DMA path (offsets of one image in 30 bits, 16-byte aligned base)
         if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123(1, 1, 0); else if (plain) UBD_LAUNCH_S123(1, 0, 1); else UBD_LAUNCH_S123(1, 0, 0); }
         else { if (u8) UBD_LAUNCH_S123(3, 1, 0); else if (plain) UBD_LAUNCH_S123(3, 0, 1); else UBD_LAUNCH_S123(3, 0, 0); }
@@ -897,9 +889,6 @@ extern "C" int ubd_forward_postprocess(ubd_handle *h, const float *params, const
         pp_lds_args job;
         const int fits = ubd_pp_fill_job(h, pp_logits, pp_n, pp_map_h, pp_map_w, logit_threshold, scale, min_area, binary_map, quads, classes,
                                          counts, cap, pp_workspace, pp_workspace_bytes,
-#ifdef UBD_EXPERIMENTAL_STEM123W
-                                         h->fuse_stem == 3 ? s123w_cfg::NT :
-#endif
                                          s23_cfg::NT, &job);
         if (fits < 0) return 1;
         if (fits == 1) {
