@@ -403,3 +403,30 @@ def test_unfused_call_then_prepacked_fused_call_on_a_poisoned_workspace(monkeypa
     assert torch.equal(m.predict_on_device(xb), got)              # and the counters reset themselves for the call after
     if few_cus:
         _check(got.cpu().numpy(), onet.forward(xb.cpu().numpy().astype(np.float64), w))
+
+
+def test_graphed_forward_equals_the_launches_and_follows_the_weights():
+    """Model.graphed_forward: the captured HIP graph of one shape is bit-identical to predict_on_device, Model.predict uses it for one image
+    per call (the reference's latency protocol, predict.py:73-78), a parameter change is picked up, and another shape in between (which
+    moves the workspace) does not leave a stale graph behind."""
+    cfg = NetConfig(grey=True)
+    m = Model(cfg, seed=3)
+    x = torch.rand((1, 128, 192, 1), device="cuda")
+    ref = m.predict_on_device(x).clone()
+    gf = m.graphed_forward(1, 128, 192)
+    for _ in range(3):
+        assert torch.equal(gf(x), ref)
+    assert np.array_equal(m.predict(x.cpu().numpy()), ref.cpu().numpy())
+    big = torch.rand((4, 256, 256, 1), device="cuda")
+    m.predict_on_device(big)                                  # a larger workspace: the graph of the small shape is re-captured
+    assert torch.equal(gf(x), ref)
+    w = m.get_weights()
+    w[0] = w[0] * 1.5
+    m.set_weights(w)
+    ref2 = m.predict_on_device(x).clone()
+    assert not torch.equal(ref2, ref)
+    assert torch.equal(gf(x), ref2)
+    x2 = torch.rand((1, 128, 192, 1), device="cuda")           # other images: copied into the graph's static input
+    assert torch.equal(gf(x2), m.predict_on_device(x2))
+    with pytest.raises(ValueError):
+        gf(big)

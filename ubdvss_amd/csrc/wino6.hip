@@ -119,6 +119,7 @@ struct w6geom {
     unsigned in_bytes;
     unsigned groups_x, half_rows, total;
     unsigned magic_gx, magic_hr;      // floor(v / groups_x) = umulhi(v, magic_gx) for v < total (ubd_tile_decoder's rule)
+    int wpb;                          // waves per block that take groups (1..8): small launches spread over more CUs (all 8 waves copy the weights)
 };
 // addresses of one group: wave-uniform row terms (scalar registers; they ride in the buffer instructions' soffset, which IS part of
 // the hardware range check: tools/ubench/buf_soffset.hip) and per-lane column terms.  An invalid row or column is 2^30 (host: tensor
@@ -163,13 +164,13 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     const int chunk = (int)((G.total + 7) >> 3);
     const int g_begin = xcd * chunk;
     const int g_end = (g_begin + chunk < (int)G.total) ? g_begin + chunk : (int)G.total;
-    const int stride = nblk_x * W6_WAVES;
+    const int stride = nblk_x * G.wpb;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)G.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, (int)(EPI == 2 ? G.in_bytes / UBD_C : G.in_bytes), 0x00020000);
 
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int g = g_begin + (int)(blockIdx.x >> 3) * W6_WAVES + wave_in_block;
+    int g = g_begin + (int)(blockIdx.x >> 3) * G.wpb + wave_in_block;
     const int g_last = g_end - 1;
     const unsigned BIG = 0x40000000u;
     const unsigned lane4 = 16u * q, lane2 = 64u + 8u * q;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     WSTAMP(1);
-    if (g >= g_end) return;
+    if (g >= g_end || wave_in_block >= G.wpb) return;
     [[maybe_unused]] int gcount = 0;
     const u32x4 *su4 = (const u32x4 *)s_u + lane;
     // Schedule of one transform point xi = 4a + b (16 per group, fully unrolled):
@@ -405,7 +406,14 @@ void ubd_launch_dilconv_wino6(const ubd_handle *h, int epi, const unsigned *frag
     // ... / 16 and D <= 2^12 for every supported shape (tensor bytes <= 2^30); D = 1 needs the identity
     G.magic_gx = groups_x == 1 ? 0u : (unsigned)(0xFFFFFFFFul / (unsigned long)groups_x + 1ul);
     G.magic_hr = half_rows == 1 ? 0u : (unsigned)(0xFFFFFFFFul / (unsigned long)half_rows + 1ul);
-    int grid = ubd_grid_for(groups, h->num_cus, W6_WAVES, 1);     // 96 KiB of LDS: one 8-wave block per CU
+    // 96 KiB of LDS: one 8-wave block per CU.  A launch with fewer than eight groups per CU (one 512 x 512 image: 256 groups) lets only
+    // `wpb` waves of a block take groups, so that the groups spread over all CUs instead of filling 32 of them (batch-1 latency,
+    // predict.py:73-78: 10.2 -> 7 us per layer); the other waves still copy their share of the weights and leave.
+    int wpb = (int)((groups + h->num_cus - 1) / h->num_cus);
+    if (wpb < 1) wpb = 1;
+    if (wpb > W6_WAVES) wpb = W6_WAVES;
+    G.wpb = wpb;
+    int grid = ubd_grid_for(groups, h->num_cus, wpb, 1);
     grid = (grid + 7) / 8 * 8;
     if (epi == 2)
         hipLaunchKernelGGL((dilconv_wino6_kernel<2>), dim3(grid), dim3(64 * W6_WAVES), 0, st, in, out, frag, bias, G, head WSTAMP_ARG);
