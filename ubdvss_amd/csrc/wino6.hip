@@ -217,21 +217,32 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     load_row(D, A, 0);
     load_row(D, A, 2);
     load_row(D, A, 1);
+    // U (96 KiB) to LDS by LDS-DMA: 96 pieces of 1 KiB, 12 per wave, handed out in ROUNDS (round r, wave w -> piece 8 r + w), so that the
+    // pieces of the first transform points are the first to land: pieces 0..23 (points 0..3, the first transform row) are rounds 0..2.
+    // The block starts computing behind THOSE (barrier A); the other nine rounds land under the first row of the first group and are
+    // awaited once, before point 4's weights are read (barrier B; waves without a group wait there too, then leave).  The copy used to
+    // stand in front of every launch whole: ~3.5 us of a 33 us launch, x 6 launches per pass.
+    // (asm form: outside hipcc's bookkeeping -- its own waits for the sample rows can only over-wait, the DMAs being younger.)
+    constexpr int PER_WAVE = UBD_WINO6_FRAG_U32 * 4 / 1024 / W6_WAVES;          // 12
+    constexpr int EARLY_ROUNDS = 4 * 6 / W6_WAVES;                                // 3: the 24 pieces of points 0..3
+    static_assert(PER_WAVE - EARLY_ROUNDS == 9, "the counted wait below is written for nine late rounds");
     {
-        // U (96 KiB) to LDS by LDS-DMA: 96 pieces of 1 KiB, 12 per wave (asm form: outside hipcc's bookkeeping, retired by the
-        // vmcnt(0) below whatever hipcc does with the sample loads around it; the raw barrier publishes everyone's pieces)
-        constexpr int PER_WAVE = UBD_WINO6_FRAG_U32 * 4 / 1024 / W6_WAVES;
         const unsigned lds_u = ubd_lds_addr(s_u);
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
-            const int piece = wave_in_block * PER_WAVE + k;
+            const int piece = k * W6_WAVES + wave_in_block;
             ubd_glds16_sbase((const char *)ufrag + (size_t)piece * 1024, (unsigned)lane * 16u, lds_u + (unsigned)piece * 1024u);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // the sample rows (older) and this wave's rounds 0..2 have landed
+    __builtin_amdgcn_s_barrier();                             // A: points 0..3 of the weights are in LDS
     WSTAMP(1);
-    if (g >= g_end || wave_in_block >= G.wpb) return;
+    if (g >= g_end || wave_in_block >= G.wpb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // B
+        return;
+    }
+    bool weights_pending = true;                              // wave-uniform: barrier B is still owed (first group only)
     [[maybe_unused]] int gcount = 0;
     const u32x4 *su4 = (const u32x4 *)s_u + lane;
     // Schedule of one transform point xi = 4a + b (16 per group, fully unrolled):
@@ -313,6 +324,11 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
             }
             __builtin_amdgcn_sched_barrier(0);
             // tail: weights of the next point (the MFMAs above have read theirs), its operands, this point's output transform
+            if (xi == 3 && weights_pending) {                 // first group of the launch: the rest of the weight copy (rounds 3..11)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // B
+                weights_pending = false;
+            }
             if (xi < 15) load_u(xi + 1);
             if (b == 3 && a < 3) {
                 make_v(a + 1);
