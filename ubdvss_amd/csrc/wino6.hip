@@ -146,9 +146,9 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
     const int i = lane & 15, q = lane >> 4;
     const int h = G.h, w = G.w, d = G.d, log2d = G.log2d, dm1 = G.d - 1;
     // Bias and head weights stay in registers for the whole kernel (8 + 8): loaded in the epilogue they cost a vmcnt(0) wait behind the
-    // NEXT group's sample rows, which are in flight by then; read from an LDS table there (two ds_read_b128 per group) they came back
-    // with element 1 of the second read in lanes 12..15 of every 16 on a few per cent of the groups, run to run different -- not
-    // understood (tools/_ab notes, round 6), so the table was dropped.
+    // NEXT group's sample rows, which are in flight by then.  (An LDS table read in the epilogue was tried and looked corrupted in a few
+    // per cent of the groups; the cause was the store hazard described at the stores below -- a LATER value in a store's data register --
+    // not the table.  Registers are the cheaper home anyway: no reads in the epilogue.)
     const f32x4 bA = *(const f32x4 *)(bias + 4 * q);
     const f32x4 bB = q < 2 ? *(const f32x4 *)(bias + 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 hA = {0.f, 0.f, 0.f, 0.f}, hB = {0.f, 0.f, 0.f, 0.f};
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * W6_WAVES) void dilconv_wino6_kernel(const floa
                         // Stores take the row term in the VECTOR offset: with it in soffset, hipcc's hazard recogniser assumes that a wide
                         // store followed at once by a vector write to its data registers is safe (true of older chips) and inserts no
                         // wait state; on gfx950 ~0.1 % of the pixels of a 32 x 128 x 128 launch then carried a LATER value (an address
-                        // integer) in one dword, different ones run to run (tools/_ab/chk_bias.py, round 6).
+                        // integer) in one dword, different ones run to run (tools/wino6_chk_bias.py, round 6).
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), yrsrc, (int)(A.c4[1 + c] + A.row[1 + rr]), 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), yrsrc, (int)(st1 + A.row[1 + rr]), 0, 0);
                     }
