@@ -430,3 +430,15 @@ def test_graphed_forward_equals_the_launches_and_follows_the_weights():
     assert torch.equal(gf(x2), m.predict_on_device(x2))
     with pytest.raises(ValueError):
         gf(big)
+
+
+def test_split_product_layer_fuzz_against_the_fp32_mfma_form():
+    """tools/wino6_fuzz_layer.py: one dilated layer through ubd_dilated_layer, split-product form vs fp32-MFMA form, on random map sizes
+    from 1 x 1 to 70 x 150 (any residue against the tile runs), batch sizes, every dilation, inputs scaled by 1e-3 / 1 / 100: every output
+    written, difference <= 4e-6 of the layer's largest value."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wino6_fuzz_layer.py")], env=dict(os.environ, FUZZ_CASES="150", FUZZ_SEED="7"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
+    assert "failures 0" in r.stdout
