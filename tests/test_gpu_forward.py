@@ -442,3 +442,34 @@ def test_split_product_layer_fuzz_against_the_fp32_mfma_form():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
     assert "failures 0" in r.stdout
+
+
+def test_zero_kernel_layer_writes_exactly_the_bias_at_full_size():
+    """Regression test of two silent hazards found while building the split-product layer (profiles/r06_experiment_notes.txt A.6): with
+    an all-zero 3x3 kernel every output of a dilated layer is relu(bias) EXACTLY, whatever the input -- any stale register (a vector
+    add reading an MFMA result too early) or store-data register overwritten before the store has read it shows up as a wrong value.
+    The second hazard hit ~0.1 % of the pixels of a full-size launch, different ones run to run: 32 x 128 x 128 maps, every dilation,
+    three launches each, plus one small ragged map."""
+    import ctypes
+    from ubdvss_amd import _lib
+    lib = _lib.load()
+    m = Model(NetConfig(grey=False), seed=1)
+    w = m.get_weights()
+    bias = np.arange(1, 25, dtype=np.float32) - 4.5             # some negative: relu
+    for i in range(9, 21, 2):
+        w[i] = np.zeros_like(w[i]); w[i + 1] = bias.copy()
+    m.set_weights(w)
+    ws = torch.empty(int(lib.ubd_forward_workspace_bytes(m._h, 1, 4, 4)), dtype=torch.uint8, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ubd_pack_weights(m._h, m.params.data_ptr(), ws.data_ptr(), ws.numel(), st), "pack")
+    want = torch.from_numpy(np.maximum(bias, 0.0)).cuda()
+    for shape in ((32, 128, 128), (3, 37, 91)):
+        x = torch.rand((*shape, 24), device="cuda") * 50.0
+        y = torch.empty_like(x)
+        for k in range(6):
+            for _ in range(3):
+                y.fill_(-1.0)
+                _lib.check(lib.ubd_dilated_layer(m._h, m.params.data_ptr(), k, x.data_ptr(), y.data_ptr(), *shape, ws.data_ptr(), st), "dil")
+                torch.cuda.synchronize()
+                bad = (y.reshape(-1, 24) != want).any(dim=1)
+                assert not bool(bad.any()), (shape, k, int(bad.sum()))
