@@ -299,7 +299,12 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
         const int gx1 = I.rx + I.sx0 * d;
         const int base = ((I.ry + I.sy0 * d) * w + gx1) * (UBD_C * 2);
         const int sx_lo = gx1 - d < 0 ? 1 : 0;
-        const int sx_span = (w - 1 - gx1 + d) / d - sx_lo;                  // sx_hi - sx_lo (gx1 <= w - 1: the tile starts inside the map)
+        const int sx_span = (w - 1 - gx1 + d) / d - sx_lo;                  // sx_hi - sx_lo where the tile starts inside the map (gx1 <= w - 1)
+        // A map NARROWER than the dilation has column phases without a single pixel (rx >= w: e.g. a 10-wide map at dilation 16).  Their
+        // tiles are all padding; without this test sx_span went negative, the unsigned compare below accepted every column, and the
+        // staged tiles held OTHER columns' pixels -- the layer's weight and bias gradients came out several times too large (found by the
+        // random-shape soak of round 6, 3 x 104 x 40 images; maps of the BASELINE shapes are never narrower than their dilation).
+        const bool inside = gx1 < w;
 #pragma unroll
         for (int rd = 0; rd < C::ROUNDS; ++rd) {
             const int piece = rd * 4 + wid;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256, W16_OCC(TW, DX)) void dil_wgrad16_kernel(const
             const int v = relsx[rd];
             unsigned off;
             if constexpr (PAIR) off = (v & 1) ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;      // both sub-grids are exactly 8 columns wide (host)
-            else off = (unsigned)((v & 31) - sx_lo) <= (unsigned)sx_span ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;
+            else off = (inside && (unsigned)((v & 31) - sx_lo) <= (unsigned)sx_span) ? (unsigned)(base + ((v >> 1) & ~15)) : 0x80000000u;
             ubd_blds16(piece < C::XR ? rx : rg, off, lds_smem + bufoff + piece * 1024);   // asm form (common.h): hipcc drained the builtin in front of the tr reads
         }
     };
