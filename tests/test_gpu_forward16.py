@@ -146,7 +146,9 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
         cin, fml = int(rng.choice([1, 3])), bool(rng.integers(0, 2))
         n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, 37)), 4 * int(rng.integers(8, 37))
         mh, mw = hh // 4, ww // 4
+        ncls = 2 if case % 3 == 2 else 0                            # every third case with classes (labels 1..2 in vertical bands)
         labels = np.ones((n, mh, mw), np.int32)
+        if ncls: labels[:, :, mw // 2:] = 2
         for im in range(n):
             budget = int(0.45 * mh * mw)
             for _ in range(int(rng.integers(1, 4))):
@@ -159,9 +161,9 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
         assert (labels > 0).sum() >= (labels == 0).sum()
         for dtype, tol in (("bfloat16", 4e-2), ("float16", 3e-2)):
             try:
-                _train_step_16bit_case(dtype, tol, cin, 0, fml, n, hh, ww, labels=labels, seed=500 + case, tol32=2e-2)
+                _train_step_16bit_case(dtype, tol, cin, ncls, fml, n, hh, ww, labels=labels, seed=500 + case, tol32=2e-2)
             except AssertionError as e:
-                raise AssertionError(f"case {case} {dtype}: cin {cin} fml {fml} {n} x {hh} x {ww}: {e}")
+                raise AssertionError(f"case {case} {dtype}: cin {cin} classes {ncls} fml {fml} {n} x {hh} x {ww}: {e}")
 
 
 def _train_step_16bit_case(dtype, tol64, cin, ncls, fml, n, hh, ww, labels=None, seed=None, tol32=5e-3):
