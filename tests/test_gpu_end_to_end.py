@@ -104,3 +104,30 @@ def test_predict_stream_equals_predict(n_cls, u8):
             q, c = ocv.postprocess(plain[k][0][i, ..., 0].astype(np.uint8), lg[i, ..., 1:] if n_cls else None, 4, 5)
             assert np.array_equal(np.array([o.bbox for o in plain[k][2][i]]).reshape(-1, 8), q)
     assert n_obj >= 7 * 32, n_obj                       # about one object per image or more, not empty lists
+
+
+def test_predict_stream_argument_errors_and_early_exit():
+    """predict_stream with rescale=True and no meta_infos refuses up front (predict's rule); meta_infos shorter than the
+    batches surface as a ValueError naming the batch, not as 'generator raised StopIteration'; a consumer that stops after the first
+    result (its prefetched copies still in flight) leaves the runner and the model usable: the next stream gives the full, correct results."""
+    cfg = NetConfig(grey=False)
+    model = Model(cfg, seed=2)
+    runner = ModelRunner(cfg, pixel_threshold=0.5, max_objects_per_image=256)
+    batches = [synthetic.noise_images(50 + k, 8, 128, 128, 3) for k in range(5)]
+
+    class Meta:
+        xscale, yscale = 1.0, 1.0
+    with pytest.raises(AssertionError):
+        list(runner.predict_stream(model, batches, rescale=True))
+    with pytest.raises(ValueError, match="meta_infos ended"):
+        list(runner.predict_stream(model, batches, rescale=True, meta_infos=[[Meta()] * 8] * 2))
+    want = [runner.predict(model, b) for b in batches]
+    gen = runner.predict_stream(model, batches)
+    first = next(gen)
+    gen.close()                                            # early exit with batches 1, 2 prefetched
+    assert np.array_equal(first[0], want[0][0])
+    got = list(runner.predict_stream(model, batches))
+    assert len(got) == 5
+    for k in range(5):
+        assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1])
+        assert [[tuple(int(v) for v in o.bbox) for o in img] for img in got[k][2]] == [[tuple(int(v) for v in o.bbox) for o in img] for img in want[k][2]]

@@ -144,7 +144,9 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
     rng = np.random.default_rng(2026)
     for case in range(int(os.environ.get("UBD_TRAIN16_SOAK_CASES", "8"))):
         cin, fml = int(rng.choice([1, 3])), bool(rng.integers(0, 2))
-        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, 37)), 4 * int(rng.integers(8, 37))
+        top = int(os.environ.get("UBD_TRAIN16_SOAK_MAXSIDE", "144")) // 4 + 1
+        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, top)), 4 * int(rng.integers(8, top))
+        if top > 64 and case % 4 == 3: ww = 512                       # big runs: the 128-wide maps of the BASELINE shapes (paired sub-grids at dilation 16)
         mh, mw = hh // 4, ww // 4
         ncls = 2 if case % 3 == 2 else 0                            # every third case with classes (labels 1..2 in vertical bands)
         labels = np.ones((n, mh, mw), np.int32)

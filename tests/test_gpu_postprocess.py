@@ -443,3 +443,30 @@ def test_crowded_maps_vs_oracle():
     _compare(model, lg, 0, cap=256)
     _, out, counts = _run(model, lg, cap=256)
     assert 40 <= int(counts.min()) and int(counts.max()) <= 64
+
+
+def test_pipelined_runner_random_shapes_changing_between_calls():
+    """The pipelined runner fed batches whose shape CHANGES from call to call (batch 1..40, sides 32..256 in steps of 4, maps wider /
+    narrower than the stem's tiles): the postprocess job that rides in a stem kernel then belongs to logits of another shape than the
+    pass's own, small batches take the back-to-back fallback, big ones the one-kernel stem.  Every batch's results equal the serial
+    runner's (logits bit for bit, maps, lists up to their counts)."""
+    rng = np.random.default_rng(31)
+    for n_cls in (0, 2):
+        cfg = NetConfig(class_names=[f"c{i}" for i in range(n_cls)] if n_cls else None, grey=False)
+        model = Model(cfg, seed=5)
+        model.set_weights(onet.init_weights(41, 3, n_cls, bias_scale=0.3))
+        serial, piped = ModelRunner(cfg), ModelRunner(cfg, pipelined=True)
+        prev = None
+        for k in range(int(os.environ.get("UBD_PIPE_SOAK_STEPS", "14"))):
+            n = int(rng.choice([1, 2, 3, 8, 20, 40])) if k % 3 else int(rng.integers(1, 6))
+            hh, ww = 4 * int(rng.integers(8, 65)), 4 * int(rng.integers(8, 65))
+            labels = synthetic.rectangle_maps(300 + k, n, hh // 4, ww // 4, n_classes=n_cls)
+            b = torch.from_numpy(synthetic.textured_images(400 + k, labels, 4, 3).astype(np.float32) / 127.5 - 1.0).cuda()
+            ref = [t.clone() if t is not None else None for t in serial.predict_on_device(model, b)]
+            got = piped.predict_on_device(model, b)
+            if prev is not None:                                  # the previous batch is complete once this call has been enqueued
+                torch.cuda.synchronize()
+                assert _same_results(prev[0], prev[1]), (n_cls, k - 1, prev[2])
+            prev = (got, ref, (n, hh, ww))
+        piped.synchronize()
+        assert _same_results(prev[0], prev[1]), (n_cls, "last", prev[2])
