@@ -141,6 +141,7 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
     tensor here (5e-3 on the fixed shapes): on maps of a few hundred pixels the nine-value depthwise gradient of a grey L1 moves by 1e-2
     with single 16-bit ulp flips further up (case 15: 3 x 60 x 80, l1.dw 1.0e-2) -- a defect is orders of magnitude beyond that.  Its first run found a real defect: column phases without a pixel
     (map narrower than the dilation) staged other columns' pixels in the bf16 dilated backward (bwd16.h, fixed)."""
+    import soak_labels
     rng = np.random.default_rng(2026)
     for case in range(int(os.environ.get("UBD_TRAIN16_SOAK_CASES", "8"))):
         cin, fml = int(rng.choice([1, 3])), bool(rng.integers(0, 2))
@@ -149,18 +150,7 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
         if top > 64 and case % 4 == 3: ww = 512                       # big runs: the 128-wide maps of the BASELINE shapes (paired sub-grids at dilation 16)
         mh, mw = hh // 4, ww // 4
         ncls = 2 if case % 3 == 2 else 0                            # every third case with classes (labels 1..2 in vertical bands)
-        labels = np.ones((n, mh, mw), np.int32)
-        if ncls: labels[:, :, mw // 2:] = 2
-        for im in range(n):
-            budget = int(0.45 * mh * mw)
-            for _ in range(int(rng.integers(1, 4))):
-                rh, rw = int(rng.integers(1, max(2, mh // 2))), int(rng.integers(1, max(2, mw // 2)))
-                if rh * rw > budget: continue
-                y0, x0 = int(rng.integers(0, mh - rh + 1)), int(rng.integers(0, mw - rw + 1))
-                labels[im, y0:y0 + rh, x0:x0 + rw] = 0
-                budget -= rh * rw
-        labels[0, 0, 0] = 0                                       # at least one negative
-        assert (labels > 0).sum() >= (labels == 0).sum()
+        labels = soak_labels.mostly_positive_maps(rng, n, mh, mw, ncls)
         for dtype, tol in (("bfloat16", 4e-2), ("float16", 3e-2)):
             try:
                 _train_step_16bit_case(dtype, tol, cin, ncls, fml, n, hh, ww, labels=labels, seed=500 + case, tol32=2e-2)

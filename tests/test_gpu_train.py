@@ -12,14 +12,15 @@ from ubdvss_amd import NetConfig, Model, Trainer, Adam, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cin, ncls, fml, n, hh, ww, seed):
+def _setup(cin, ncls, fml, n, hh, ww, seed, labels=None):
     cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml)
     model = Model(cfg, seed=0)
     w = onet.init_weights(seed, cin, ncls, bias_scale=0.2)
     # larger head so that the detection logits are not all tiny
     w[-2] = (w[-2] * 4).astype(np.float32)
     model.set_weights(w)
-    labels = synthetic.rectangle_maps(seed + 1, n, hh // 4, ww // 4, n_classes=ncls)
+    if labels is None:
+        labels = synthetic.rectangle_maps(seed + 1, n, hh // 4, ww // 4, n_classes=ncls)
     x = synthetic.textured_images(seed + 2, labels, 4, cin).astype(np.float32) / 127.5 - 1.0
     return model, w, x, labels
 
@@ -29,8 +30,8 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("cin,ncls,fml,n,hh,ww", [(3, 0, True, 2, 64, 64), (1, 3, True, 2, 64, 96), (3, 2, False, 1, 128, 64), (3, 0, True, 3, 72, 104)])
-def test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww):
-    model, w, x, labels = _setup(cin, ncls, fml, n, hh, ww, 7 + cin + ncls)
+def test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww, labels=None):
+    model, w, x, labels = _setup(cin, ncls, fml, n, hh, ww, 7 + cin + ncls, labels)
     tr = Trainer(model, Adam())
     tr.backward_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
     loss_ref, _, _, grads_ref = otorch.loss_and_grads(x, labels[..., None], w, ncls > 0, fml)
@@ -51,12 +52,17 @@ def test_gradients_random_shape_soak():
     """fp32 train step on random small shapes (sides multiples of 4 from 32 to 128, 1-3 images, grey / RGB, with / without classes, both
     padding rules) against the fp64 autograd oracle, same gates as above.  UBD_TRAIN_SOAK_CASES scales it (default 4)."""
     import os
+    import soak_labels
     rng = np.random.default_rng(123)
     for case in range(int(os.environ.get("UBD_TRAIN_SOAK_CASES", "4"))):
         cin, ncls, fml = int(rng.choice([1, 3])), int(rng.choice([0, 0, 2])), bool(rng.integers(0, 2))
-        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, 33)), 4 * int(rng.integers(8, 33))
+        top = int(os.environ.get("UBD_TRAIN_SOAK_MAXSIDE", "128")) // 4 + 1        # bigger runs: maps wider than the 16-pixel tiles at every dilation
+        n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(8, top)), 4 * int(rng.integers(8, top))
+        if top > 64 and case % 4 == 3: ww = 512                                     # ... and the 128-wide maps of the BASELINE shapes
+        # big maps: labels with k = n_neg (tests/soak_labels.py): thousands of negatives make near-ties at the k-th value likely even in fp32
+        lab = soak_labels.mostly_positive_maps(rng, n, hh // 4, ww // 4, ncls) if top > 33 else None
         try:
-            test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww)
+            test_gradients_vs_autograd(cin, ncls, fml, n, hh, ww, lab)
         except AssertionError as e:
             raise AssertionError(f"case {case}: cin {cin} classes {ncls} fml {fml} {n} x {hh} x {ww}: {e}")
 
