@@ -153,12 +153,12 @@ def test_train_step_bf16_random_shape_soak_with_every_negative_mined():
         labels = soak_labels.mostly_positive_maps(rng, n, mh, mw, ncls)
         for dtype, tol in (("bfloat16", 4e-2), ("float16", 3e-2)):
             try:
-                _train_step_16bit_case(dtype, tol, cin, ncls, fml, n, hh, ww, labels=labels, seed=500 + case, tol32=2e-2)
+                _train_step_16bit_case(dtype, tol, cin, ncls, fml, n, hh, ww, labels=labels, seed=500 + case, tol32=2e-2, u8=(case % 4 == 1))
             except AssertionError as e:
                 raise AssertionError(f"case {case} {dtype}: cin {cin} classes {ncls} fml {fml} {n} x {hh} x {ww}: {e}")
 
 
-def _train_step_16bit_case(dtype, tol64, cin, ncls, fml, n, hh, ww, labels=None, seed=None, tol32=5e-3):
+def _train_step_16bit_case(dtype, tol64, cin, ncls, fml, n, hh, ww, labels=None, seed=None, tol32=5e-3, u8=False):
     """configs[2] (bf16 train step) on small shapes: 16-bit activations, kernels and depthwise intermediates, 16-bit
     MFMA forward, fp32 accumulation / weight gradients / master weights; bf16 mode also keeps the gradient tensors
     between L3..L9 and the depthwise-output gradients of L2/L3 in bf16 (fp16 mode keeps them fp32).
@@ -174,16 +174,19 @@ def _train_step_16bit_case(dtype, tol64, cin, ncls, fml, n, hh, ww, labels=None,
     case).  The top-k choice is discontinuous; fp32 logits agree to 1e-6 and the fp32 soak (test_gpu_train.py) has no such cases."""
     from oracle import net_torch as otorch
     from ubdvss_amd import Trainer, Adam
-    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml)
+    from ubdvss_amd.net import PreprocessingType
+    cfg = NetConfig(class_names=[f"c{i}" for i in range(ncls)] if ncls else None, grey=(cin == 1), fml_compatible=fml,
+                    preprocessing=PreprocessingType.MOBILENET_LIKE if u8 else PreprocessingType.NONE)
     model = Model(cfg, dtype=dtype, seed=0)
     w = onet.init_weights(90 + cin, cin, ncls, bias_scale=0.2)
     w[-2] = (w[-2] * 4).astype(np.float32)
     model.set_weights(w)
     if labels is None:
         labels = synthetic.rectangle_maps(91, n, hh // 4, ww // 4, n_classes=ncls)
-    x = synthetic.textured_images(92 if seed is None else seed, labels, 4, cin).astype(np.float32) / 127.5 - 1.0
+    x8 = synthetic.textured_images(92 if seed is None else seed, labels, 4, cin)
+    x = x8.astype(np.float32) / 127.5 - 1.0                     # what the oracle sees; u8: the device applies (x - 127.5) / 127.5 itself (net.py:217-218)
     tr = Trainer(model, Adam())
-    tr.backward_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda())
+    tr.backward_on_device(torch.from_numpy(x8 if u8 else x).cuda(), torch.from_numpy(labels).cuda())
     l = tr.loss.cpu().numpy()
     g = tr.grads.cpu().numpy().astype(np.float64)
     gdt = "bfloat16" if dtype == "bfloat16" else None
