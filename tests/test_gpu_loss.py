@@ -117,3 +117,102 @@ def test_batch_metrics_and_loss_components():
     assert abs(got["hard_negative_loss"] - parts["hard"]) < 1e-4 * parts["hard"]
     assert keras_metrics.get_all_metrics(True)[:5] == ["detection_pixel_acc", "detection_pixel_precision",
                                                        "detection_pixel_recall", "detection_pixel_f1", "classification_pixel_acc"]
+
+
+def _both_forms(yt, yp, num_cus=None):
+    """(loss vector, gradient) of the one-launch kernel and of the five-launch chain (UBD_LOSS=chain; the switch is read when a handle is made)"""
+    out = []
+    for form in ("one", "chain"):
+        old = {k: os.environ.get(k) for k in ("UBD_LOSS", "UBD_TEST_NUM_CUS")}
+        try:
+            os.environ.pop("UBD_LOSS", None); os.environ.pop("UBD_TEST_NUM_CUS", None)
+            if form == "chain": os.environ["UBD_LOSS"] = "chain"
+            if num_cus: os.environ["UBD_TEST_NUM_CUS"] = str(num_cus)
+            losses._handles.clear()
+            l, g = losses.loss_and_grad(yt, yp)
+            out.append((l.cpu().numpy(), g.cpu().numpy()))
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+            losses._handles.clear()
+    return out
+
+
+def _assert_forms_equal(yt, yp, tag, num_cus=None):
+    (l1, g1), (l5, g5) = _both_forms(yt, yp, num_cus)
+    assert np.array_equal(g1, g5), (tag, "gradients differ", float(np.abs(g1 - g5).max()), int((g1 != g5).sum()))
+    assert np.array_equal(l1[7:14], l5[7:14]) and l1[3] == l5[3], (tag, l1, l5)            # counters and k: integers
+    assert np.allclose(l1[:7], l5[:7], rtol=2e-6, atol=1e-9), (tag, l1[:7], l5[:7])         # sums taken over different block partitions
+
+
+def test_one_launch_form_equals_the_chain():
+    """The default one-launch kernel (registers-resident pixels, two 16 / 15-bit radix levels, grid-wide barriers) against the five dependent
+    launches it replaced: the same threshold, the same tie ranks, the same per-pixel arithmetic -> gradients BIT-EQUAL, counters equal, sums
+    to the last bits.  Shapes from one pixel to 1 M pixels (1, 2 and 4 pixels per thread), with classes, saturated and quantised logits
+    (the tie barrier), all-positive / all-negative labels, and a 4-CU handle (few blocks; beyond 16 384 pixels it falls back to the chain)."""
+    rng = np.random.default_rng(77)
+    cases = [(1, 1, 1, 0), (1, 7, 9, 0), (2, 32, 32, 3), (3, 96, 96, 0), (16, 128, 128, 0), (40, 128, 128, 1), (64, 128, 128, 0)]
+    for ci, (n, h, w, n_cls) in enumerate(cases):
+        for style in range(4):
+            yt = (rng.random((n, h, w)) < rng.uniform(0.02, 0.6)).astype(np.int32)
+            if n_cls: yt = yt * rng.integers(1, n_cls + 1, (n, h, w)).astype(np.int32)
+            yp = rng.normal(-1.0, [0.05, 2.0, 12.0, 3.0][style], (n, h, w, 1 + n_cls)).astype(np.float32)
+            if style == 3: yp[..., 0] = np.round(yp[..., 0])                    # quantised: the k-th value repeats
+            _assert_forms_equal(yt, yp, (n, h, w, n_cls, style))
+    yp = rng.normal(0, 1, (2, 16, 16, 1)).astype(np.float32)
+    for fill in (0, 1):
+        _assert_forms_equal(np.full((2, 16, 16), fill, np.int32), yp, ("fill", fill))
+    yt = np.zeros((4, 64, 64), np.int32); yt[:, 8:40, 8:40] = 1
+    _assert_forms_equal(yt, np.full((4, 64, 64, 1), 0.25, np.float32), "constant logits")
+    _assert_forms_equal(yt, np.full((4, 64, 64, 1), -40.0, np.float32), "all clipped")
+    for n, h, w in [(1, 16, 16), (2, 64, 64), (4, 64, 64), (2, 128, 128)]:          # 4 CUs: 1, 2, 4 pixels per thread, then the chain
+        yt = (rng.random((n, h, w)) < 0.3).astype(np.int32)
+        yp = np.round(rng.normal(-1.0, 2.0, (n, h, w, 1)) * 2).astype(np.float32) / 2
+        _assert_forms_equal(yt, yp, ("4 CUs", n, h, w), num_cus=4)
+
+
+def test_one_launch_form_repeated_calls_are_identical():
+    """400 evaluations of one 1 M-pixel batch on one workspace: a barrier that lets a block run ahead of a histogram, or a header word read
+    before it is written, shows up as a different gradient or loss on SOME call."""
+    rng = np.random.default_rng(3)
+    yt = torch.from_numpy(synthetic.rectangle_maps(51, 64, 128, 128, n_classes=0)).cuda()
+    yp = torch.from_numpy(np.round(rng.normal(-1.0, 2.0, (64, 128, 128, 1)) * 4).astype(np.float32) / 4).cuda()
+    l0, g0 = losses.loss_and_grad(yt, yp)
+    l0, g0 = l0.clone(), g0.clone()
+    for it in range(400):
+        l, g = losses.loss_and_grad(yt, yp)
+        assert torch.equal(g, g0) and torch.equal(l, l0), it
+
+
+def test_one_launch_form_from_two_streams_at_once():
+    """Two threads, each with its own stream and workspace, evaluate 1 M-pixel batches at the same time.  Every block of the one-launch kernel
+    spins at its barriers until the whole grid is resident: two such kernels must never share the CUs half and half (loss.hip orders
+    launches from different streams by an event).  Results bit-equal to the single-stream ones, no NaN (the spin limit's alarm).
+    (A build without the ordering, -DLOSS1_NO_STREAM_ORDER, passes this test too: a grid is dispatched within microseconds, the window for
+    a half-and-half dispatch is narrow -- the test checks the ordered path's results, it cannot show the deadlock.)"""
+    import threading
+    rng = np.random.default_rng(8)
+    data, ref = [], []
+    for i in range(2):
+        yt = torch.from_numpy(synthetic.rectangle_maps(70 + i, 64, 128, 128, n_classes=0)).cuda()
+        yp = torch.from_numpy(rng.normal(-1.0, 2.0, (64, 128, 128, 1)).astype(np.float32)).cuda()
+        l, g = losses.loss_and_grad(yt, yp)
+        data.append((yt, yp)); ref.append((l.clone(), g.clone()))
+    torch.cuda.synchronize()
+    bad = [None, None]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            wrong = torch.zeros((), dtype=torch.int64, device="cuda")
+            for _ in range(300):
+                l, g = losses.loss_and_grad(*data[i])
+                wrong += ((l != ref[i][0]).any() | (g != ref[i][1]).any() | torch.isnan(l).any()).long()
+            st.synchronize()
+            bad[i] = int(wrong)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert bad == [0, 0], bad

@@ -1,5 +1,6 @@
-"""Time of the loss chain alone (ubd_loss: stats -> two histogram levels -> tie count -> gradient) on the train step's shape, 64 x 128 x 128 x 1
-logits (1 M pixels), rocprof-free: HIP events around 400 calls after 100.  UBD_LIB_PATH selects another build (A/B)."""
+"""Time of the loss alone (ubd_loss) on the train step's shape, 64 x 128 x 128 x 1 logits (1 M pixels), rocprof-free: HIP events around 400
+calls after 100.  Default: the one-launch kernel (+ the workspace memset); UBD_LOSS=chain: stats -> two histogram levels -> tie count ->
+gradient as five launches.  UBD_LIB_PATH selects another build (A/B)."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,4 +25,4 @@ for blk in range(4):
     for _ in range(400): call()
     e1.record(); torch.cuda.synchronize()
     out.append(round(e0.elapsed_time(e1) / 400 * 1e3, 2))
-print(os.environ.get("UBD_LIB_PATH", "product"), "loss chain us per call (incl. the workspace memset):", out, "loss", float(loss[0]), "k", float(loss[3]))
+print(os.environ.get("UBD_LIB_PATH", "product"), "UBD_LOSS=" + os.environ.get("UBD_LOSS", "one-launch"), "us per call (incl. the workspace memset):", out, "loss", float(loss[0]), "k", float(loss[3]))

@@ -95,6 +95,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         { const char *b = getenv("UBD_HEADBWD"); h->split_headbwd = (b && strcmp(b, "split") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_SEPB16_X"); h->sepb_x_regs = (b && strcmp(b, "regs") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_REDUCE"); h->chain_reduce = (b && strcmp(b, "batched") == 0) ? 0 : 1; }
+        { const char *b = getenv("UBD_LOSS"); h->loss_chain = (b && strcmp(b, "chain") == 0) ? 1 : 0; }
         { const char *b = getenv("UBD_DILCONV16"); h->direct_dil16 = (b && strcmp(b, "direct") == 0) ? 1 : 0; }
     }
     // Keras model.get_weights() order

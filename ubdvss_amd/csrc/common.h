@@ -33,6 +33,7 @@ struct ubd_handle {
     int direct_dil16;         // UBD_DILCONV16=direct: 16-bit forward dilated layers with the direct (unstaged) kernel (diagnostics / tests)
     int fuse_stem;            // inference stem: 2 = L1 -> L2 -> L3 in one kernel (default with fml padding), 1 = L2 -> L3 fused, 0 = three kernels (UBD_STEM=fused123|fused|unfused)
     int use_wino;             // 1: Winograd F(2x2,3x3) dilated layers (default), 0: direct implicit GEMM (UBD_DILCONV=direct)
+    int loss_chain;           // UBD_LOSS=chain: the loss as its five dependent launches (the batch-global mode's form) instead of the one-launch kernel (diagnostics / tests)
     int wino_x6;              // forward Winograd products as three-way bf16 split products on the bf16 MFMA (wino6.hip; default), 0: on the fp32 MFMA (UBD_DILCONV=wino32)
 };
 

@@ -13,6 +13,7 @@
 // ce*(1-z) (non-negative => monotone), ties at the k-th value resolved toward the lower flat index
 // like tf.nn.top_k.
 #include "common.h"
+#include <mutex>
 
 #define LOSS_BLOCK 256
 #define LOSS_MAX_BLOCKS 256      // one block per CU: every block ends with ~50 same-address global atomics (header sums, non-empty bins)
@@ -30,6 +31,7 @@ struct loss_hdr {
     unsigned pad[3];
 };
 #define LOSS_HDR_BYTES 256
+#define LOSS1_COPIES 8            // one-launch form: blocks b, b + 8, ... share a copy of the histograms (same-address atomics of 256 blocks are carried out one after the other)
 
 // Per-block partial sums of the statistics kernel.  Every block used to end with six atomic adds on the header: 256 blocks x 6
 // read-modify-writes on ONE cache line are carried out one after the other at the memory side (~10 ns each) -- 15 of the statistics
@@ -38,7 +40,7 @@ struct loss_hdr {
 struct loss_part { double a, b; int i0, i1, i2, i3; };          // sum_pos, sum_neg, n_pos, tp, tn, fp
 
 struct loss_layout {
-    size_t off_hdr, off_hist, off_blockties, off_rankties, off_part, off_ce, total;
+    size_t off_hdr, off_hist, off_histk, off_rec, off_blockties, off_rankties, off_part, off_ce, total;
 };
 
 static void loss_layout_compute(long npix, loss_layout *L)
@@ -46,6 +48,8 @@ static void loss_layout_compute(long npix, loss_layout *L)
     size_t off = 0;
     L->off_hdr = off;       off += LOSS_HDR_BYTES;
     L->off_hist = off;      off += 3 * 2048 * sizeof(unsigned);
+    L->off_histk = off;     off += LOSS1_COPIES * 4096 * sizeof(unsigned);  // the one-launch form's histograms: LOSS1_COPIES copies of (2048 + 1024 + 1024) bins, zeroed with the header
+    L->off_rec = off;       off += LOSS_MAX_BLOCKS * 64;                        // the one-launch form's per-block records + barrier flags (zeroed with the header)
     L->off_blockties = off; off += ubd_align_up((LOSS_MAX_BLOCKS + 1) * sizeof(unsigned), 256);
     L->off_rankties = off;  off += 1024;                       // batch-global mode: tie counts of every rank (<= 256 ranks)
     L->off_part = off;      off += ubd_align_up(LOSS_MAX_BLOCKS * sizeof(loss_part), 256);
@@ -83,27 +87,29 @@ __device__ __forceinline__ double block_reduce_sum(double v, double *sh)
     return r;       // valid in thread 0
 }
 
-// six sums at once: one pair of barriers instead of six (results valid in thread 0); sh: (blockDim.x / 64) * 6 doubles
-__device__ __forceinline__ void block_reduce6(double (&v)[6], double *sh)
+// NV sums at once: one pair of barriers instead of NV (results valid in thread 0); sh: (blockDim.x / 64) * NV doubles
+template <int NV>
+__device__ __forceinline__ void block_reduce_n(double (&v)[NV], double *sh)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] += __shfl_down(v[k], o, 64);
+        for (int k = 0; k < NV; ++k) v[k] += __shfl_down(v[k], o, 64);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
     if (lane == 0)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sh[wid * 6 + k] = v[k];
+        for (int k = 0; k < NV; ++k) sh[wid * NV + k] = v[k];
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = 0;
+        for (int k = 0; k < NV; ++k) v[k] = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] += sh[w * 6 + k];
+            for (int k = 0; k < NV; ++k) v[k] += sh[w * NV + k];
     }
 }
+__device__ __forceinline__ void block_reduce6(double (&v)[6], double *sh) { block_reduce_n<6>(v, sh); }
 
 // The block's six sums (valid in thread 0) go to its record; returns (block-uniformly) whether this block was the last one out --
 // then v holds, in thread 0, the totals over all blocks, added in block order.  Stores and loads of the records go past the caches
@@ -380,6 +386,43 @@ __global__ void loss_finalize_kernel(const loss_hdr *hdr, long npix, int n_cls, 
     loss_finalize_body(hdr, hdr->sum_hard, hdr->sum_cls, hdr->cls_correct, npix, n_cls, loss4);
 }
 
+// one pixel of the gradient pass: hard-negative sum, gradient of the detection logit, classification part
+struct loss_w { float w_pos, w_neg, w_hard, w_cls; int k_out, n_cls; };
+__device__ __forceinline__ void loss_grad_pixel(const loss_w &W, const float *__restrict__ logits, float *__restrict__ dlogits, long p, unsigned bits,
+                                                bool sel, float x, int yt, double &s_hard, double &s_cls, int &c_correct)
+{
+    const int k_out = W.k_out, n_cls = W.n_cls;
+    const float z = yt > 0 ? 1.f : 0.f;
+    if (sel) s_hard += (double)__uint_as_float(bits);
+    const float xc = fminf(fmaxf(x, LOGIT_LO), LOGIT_HI);
+    const bool inside = (x >= LOGIT_LO) && (x <= LOGIT_HI);
+    if (dlogits) {
+        const float sig = 1.f / (1.f + expf(-xc));
+        const float coef = z * W.w_pos + (1.f - z) * (W.w_neg + (sel ? W.w_hard : 0.f));
+        dlogits[p * k_out] = inside ? (sig - z) * coef : 0.f;
+    }
+    if (n_cls > 0) {
+        const float *lg = logits + p * k_out + 1;
+        if (yt > 0) {
+            float mx = lg[0];
+            int amax = 0;
+            for (int c = 1; c < n_cls; ++c)
+                if (lg[c] > mx) { mx = lg[c]; amax = c; }         // first maximum, like tf.argmax
+            float sum = 0.f;
+            for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
+            const float lse = mx + logf(sum);
+            const int lab = yt - 1 < n_cls ? yt - 1 : n_cls - 1;
+            c_correct += (amax == lab);
+            s_cls += (double)(lse - lg[lab]);
+            if (dlogits)
+                for (int c = 0; c < n_cls; ++c)
+                    dlogits[p * k_out + 1 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * W.w_cls;
+        } else if (dlogits) {
+            for (int c = 0; c < n_cls; ++c) dlogits[p * k_out + 1 + c] = 0.f;
+        }
+    }
+}
+
 // ---- gradient + hard-negative / classification sums --------------------------------------------
 #define LOSS_GRAD_BLOCK 1024       // as loss_stats: four waves per SIMD on the one block a CU gets
 __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float *__restrict__ logits, int k_out,
@@ -405,38 +448,8 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double s_hard = 0, s_cls = 0;
     int c_correct = 0;
-    // one pixel: hard-negative sum, gradient of the detection logit, classification part
-    auto pixel = [&](long p, unsigned bits, bool sel, float x, int yt) {
-        const float z = yt > 0 ? 1.f : 0.f;
-        if (sel) s_hard += (double)__uint_as_float(bits);
-        const float xc = fminf(fmaxf(x, LOGIT_LO), LOGIT_HI);
-        const bool inside = (x >= LOGIT_LO) && (x <= LOGIT_HI);
-        if (dlogits) {
-            const float sig = 1.f / (1.f + expf(-xc));
-            const float coef = z * w_pos + (1.f - z) * (w_neg + (sel ? w_hard : 0.f));
-            dlogits[p * k_out] = inside ? (sig - z) * coef : 0.f;
-        }
-        if (n_cls > 0) {
-            const float *lg = logits + p * k_out + 1;
-            if (yt > 0) {
-                float mx = lg[0];
-                int amax = 0;
-                for (int c = 1; c < n_cls; ++c)
-                    if (lg[c] > mx) { mx = lg[c]; amax = c; }         // first maximum, like tf.argmax
-                float sum = 0.f;
-                for (int c = 0; c < n_cls; ++c) sum += expf(lg[c] - mx);
-                const float lse = mx + logf(sum);
-                const int lab = yt - 1 < n_cls ? yt - 1 : n_cls - 1;
-                c_correct += (amax == lab);
-                s_cls += (double)(lse - lg[lab]);
-                if (dlogits)
-                    for (int c = 0; c < n_cls; ++c)
-                        dlogits[p * k_out + 1 + c] = (expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * w_cls;
-            } else if (dlogits) {
-                for (int c = 0; c < n_cls; ++c) dlogits[p * k_out + 1 + c] = 0.f;
-            }
-        }
-    };
+    const loss_w Wt = {w_pos, w_neg, w_hard, w_cls, k_out, n_cls};
+    auto pixel = [&](long p, unsigned bits, bool sel, float x, int yt) { loss_grad_pixel(Wt, logits, dlogits, p, bits, sel, x, yt, s_hard, s_cls, c_correct); };
     // Every element equal to the threshold is selected when the threshold bin of the last histogram holds exactly the number still
     // needed (always, unless the k-th value repeats, e.g. an exact 0): then no tie needs a rank, and the pass is a plain stream --
     // no ballots, no two block barriers per trip, no prefix over the blocks' tie counts (loss_tiecount_kernel has returned early on
@@ -517,13 +530,482 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
     }
 }
 
+// ================================== the whole evaluation in ONE launch ==================================================
+// One GPU / per-replica loss (the batch-global mode keeps the chain above: its collectives are enqueued by the host between the
+// stages).  A block of 1024 threads owns a contiguous chunk of R * 1024 pixels and keeps them IN REGISTERS (logit, bit pattern of
+// ce * (1 - z), label sign) from the first load to the gradient store: nothing is written and read back in between.  The radix
+// select keeps the chain's three levels (11 / 10 / 10 bits; a 16 / 15-bit split was built first: two stages, but ~3000 non-empty
+// bins per block = 770 k global atomics = 60 us).  The stages are separated by grid-wide barriers (every block is resident: grid <=
+// CUs, one block per CU); the LAST block to arrive does the serial part of a stage (totals in block order, the selection scan)
+// before it releases the others.  A fourth barrier exists only when the k-th value repeats and not all of its copies are selected
+// (tie ranks in flat-index order need the counts of the blocks in front).  Everything one block hands to another goes through
+// agent-scope atomics / cache-bypassing loads and stores ordered by s_waitcnt -- no release / acquire fences: on this part each
+// one is an L2 write-back + invalidate (measured: 19 us per barrier with them).
+// losses.py:99-116; same tie rule, same gradient arithmetic as the chain (gradients bit-equal, test_gpu_loss.py).
+#define LOSS1_BLOCK 1024
+#define LOSS1_MAX_R 4              // 8 pixels per thread spill (49 registers at the 128-register bound of a 1024-thread block)
+#define LOSS1_DIRECT_MAX 512       // a block with at most this many elements in the selected bin adds them to the next histogram one global atomic each
+#define LOSS1_SPIN_LIMIT (1u << 21)
+
+// lives at header + 128: the arrival counter on its own line; rel[j]: the word that releases barrier j AND carries what the stage decided
+// (bit 63: valid) -- a block learns "released" and the selection in ONE memory round trip:
+//   rel[0] = prefix0 [10:0] | k_rem0 [31:11] | n_pos [52:32]      rel[1] = prefix1 [20:0] | k_rem1 [41:21]
+//   rel[2] = T [30:0] | need_eq [51:31] | ties [52]                rel[3] = the tie barrier          (counts <= 2^20: npix <= 256 * 4096)
+struct loss_sync { unsigned arrive, pad0[15]; unsigned long long rel[4]; unsigned timeout, pad1[7]; };
+static_assert(sizeof(loss_hdr) <= 128 && sizeof(loss_sync) == 128, "loss header layout");
+#define LOSS1_VALID (1ull << 63)
+
+#define LOSS1_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LOSS1_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// A block's record: its sums for the gathering block and its barrier flag, on a line of its own (64 bytes).  Arrival is a plain store of the
+// stage number -- no read-modify-write on one counter: 256 same-address atomics are carried out one after the other (~2.5 us per barrier).
+// counts: bit 63 = stage 0 finished (the flag of barrier 1: the counters decide k, one round trip); hard: sign bit = the block is done (its value is >= 0)
+struct loss1_rec { double a, b; unsigned long long counts; unsigned flag, ties; unsigned long long hard; double cls; unsigned correct, pad[3]; };
+static_assert(sizeof(loss1_rec) == 64, "loss1_rec");
+// every thread of the block calls it after its last global atomic / store of the stage
+__device__ __forceinline__ void loss1_signal(loss1_rec *rec, unsigned stage)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // this wave's atomics and record stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) LOSS1_ST(&rec[blockIdx.x].flag, stage);
+}
+// block 0: until every block has signalled `stage` (thread t watches block t: one memory round trip per look)
+__device__ __forceinline__ void loss1_gather(const loss1_rec *rec, unsigned stage, unsigned grid, loss_sync *sy)
+{
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned f = threadIdx.x < grid ? LOSS1_LD(&rec[threadIdx.x].flag) : stage;
+        if (__syncthreads_and(f >= stage)) break;
+        if (++spins > LOSS1_SPIN_LIMIT) {
+            if (threadIdx.x == 0) LOSS1_ST(&sy->timeout, 1u);
+            break;
+        }
+    }
+}
+// thread 0 of every block but block 0: polls the stage's word; the payload comes back in *s_word (valid after the barrier)
+__device__ __forceinline__ void loss1_wait(loss_sync *sy, int j, unsigned long long *s_word)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        unsigned long long w;
+        while (!((w = LOSS1_LD(&sy->rel[j])) & LOSS1_VALID)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > LOSS1_SPIN_LIMIT) {                            // a block that never became resident: give up loudly (NaN loss), never hang the queue
+                LOSS1_ST(&sy->timeout, 1u);
+                break;
+            }
+        }
+        *s_word = w;
+    }
+    __syncthreads();
+}
+
+// the bin that holds the k_rem-th largest element of a finished NB-bin histogram, by the 1024 threads of one block (descending scan);
+// s_out[0] = bin, s_out[1] = rank inside the bin, s_out[2] = the bin's count
+template <int NB>
+__device__ __forceinline__ void loss1_select(const unsigned *hist, unsigned k_rem, unsigned *s_w, unsigned *s_out)
+{
+    constexpr int per = NB / LOSS1_BLOCK;          // 2 or 1
+    const int top = NB - 1 - (int)threadIdx.x * per;                       // this thread's bins: top, top - 1
+    unsigned c[per], mine = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        c[j] = 0;
+#pragma unroll
+        for (int cp = 0; cp < LOSS1_COPIES; ++cp) c[j] += LOSS1_LD(hist + cp * 4096 + top - j);
+        mine += c[j];
+    }
+    unsigned incl = mine;
+    const int ln = threadIdx.x & 63, wd = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o, 64);
+        if (ln >= o) incl += v;
+    }
+    __syncthreads();
+    if (ln == 63) s_w[wd] = incl;
+    __syncthreads();
+    for (int w2 = 0; w2 < wd; ++w2) incl += s_w[w2];
+    const unsigned excl = incl - mine;
+    const bool winner = (excl < k_rem && k_rem <= incl) || (threadIdx.x == LOSS1_BLOCK - 1 && incl < k_rem);
+    if (winner) {
+        unsigned acc = excl;
+        int j = 0;
+#pragma unroll
+        for (; j < per - 1; ++j) {
+            if (acc + c[j] >= k_rem) break;
+            acc += c[j];
+        }
+        s_out[0] = (unsigned)(top - j); s_out[1] = k_rem - acc; s_out[2] = c[j];
+    }
+    __syncthreads();
+}
+
+// histogram of the next 10 bits over this block's elements whose leading bits equal `prefix`: a handful of elements per block as a rule
+// (one global atomic each), an LDS histogram when the selected bin is crowded (quantised / saturated logits)
+template <int R>
+__device__ __forceinline__ void loss1_refine(const unsigned (&bits)[R], int match_shift, unsigned prefix, int bin_shift, unsigned *hist,
+                                             unsigned *s_h, unsigned *s_cnt)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned mine = 0;
+#pragma unroll
+    for (int u = 0; u < R; ++u) mine += (bits[u] != 0xffffffffu && ((bits[u] & 0x7fffffffu) >> match_shift) == prefix);
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0 && mine) atomicAdd(s_cnt, mine);
+    __syncthreads();
+    const unsigned in_block = *s_cnt;
+    __syncthreads();
+    if (tid == 0) *s_cnt = 0;
+    if (in_block && in_block <= LOSS1_DIRECT_MAX) {
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (bits[u] != 0xffffffffu && ((bits[u] & 0x7fffffffu) >> match_shift) == prefix) atomicAdd(&hist[(bits[u] >> bin_shift) & 1023u], 1u);
+    } else if (in_block) {
+        s_h[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (bits[u] != 0xffffffffu && ((bits[u] & 0x7fffffffu) >> match_shift) == prefix) {
+                // one wave's elements of one bin (all of them, when the logits are constant) as ONE LDS atomic
+                const unsigned bin = (bits[u] >> bin_shift) & 1023u;
+                const unsigned first = __builtin_amdgcn_readfirstlane(bin);
+                const unsigned long long same = __ballot(bin == first);
+                if (bin != first) atomicAdd(&s_h[bin], 1u);
+                else if (lane == __builtin_ctzll(same)) atomicAdd(&s_h[bin], (unsigned)__popcll(same));
+            }
+        __syncthreads();
+        if (s_h[tid]) atomicAdd(&hist[tid], s_h[tid]);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(LOSS1_BLOCK) void loss_one_kernel(const float *__restrict__ logits, int k_out, const int *__restrict__ y_true, long npix,
+                                                               loss_hdr *hdr, unsigned *hist, unsigned *blockties,
+                                                               loss1_rec *rec, float *__restrict__ dlogits, float *__restrict__ loss4, unsigned long long *dbg)
+{
+#ifdef LOSS1_STAMPS
+#define STAMP(i) do { if (threadIdx.x == 0) dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    STAMP(0);
+    __shared__ unsigned s_h[2048];
+    __shared__ double s_red[LOSS1_BLOCK / 64 * 6];
+    __shared__ unsigned s_w[LOSS1_BLOCK / 64];
+    __shared__ unsigned s_misc[8];
+    __shared__ unsigned long long s_word, s_word_tie;
+    __shared__ unsigned s_cnt;
+    loss_sync *sy = (loss_sync *)((char *)hdr + 128);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned grid = gridDim.x;
+    const long lo = (long)blockIdx.x * (R * LOSS1_BLOCK);
+    const int n_cls = k_out - 1;
+    unsigned *mycopy = hist + (blockIdx.x & (LOSS1_COPIES - 1)) * 4096;       // [0, 2048): level 0, [2048, 3072): level 1, [3072, 4096): level 2
+
+    // ---- stage 0: per-pixel BCE, batch sums, level-0 histogram
+    s_h[tid] = 0; s_h[tid + LOSS1_BLOCK] = 0;
+    if (tid == 0) { s_cnt = 0; s_misc[1] = 0; }
+    float x[R];
+    unsigned bits[R];                 // bit 31: positive label; 0xffffffff: no pixel
+    {
+        int yt[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const long p = lo + u * LOSS1_BLOCK + tid;
+            const bool valid = p < npix;
+            x[u] = valid ? logits[p * k_out] : 0.f;
+            yt[u] = valid ? y_true[p] : -1;
+        }
+        __syncthreads();
+        STAMP(1);
+        double sp = 0, sn = 0;
+        unsigned long long cnt = 0;                                      // n_pos | tp << 16 | tn << 32 | fp << 48: a block has <= 4096 pixels
+        unsigned zeros = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (lo + u * LOSS1_BLOCK + tid < npix) {
+                const float z = yt[u] > 0 ? 1.f : 0.f;
+                const bool pred = x[u] > 0.f;                            // keras_metrics.py:112
+                cnt += (unsigned long long)(z > 0.f) | ((unsigned long long)(pred && z > 0.f) << 16) |
+                       ((unsigned long long)(!pred && z == 0.f) << 32) | ((unsigned long long)(pred && z == 0.f) << 48);
+                float xc;
+                const float ce = bce_from_logit(x[u], z, xc);
+                const float cn = ce * (1.f - z);
+                sp += (double)(ce * z);
+                sn += (double)cn;
+                const unsigned b = __float_as_uint(cn);
+                bits[u] = b | (z > 0.f ? 0x80000000u : 0u);
+                if (b == 0u) ++zeros;                                    // every positive and every exact zero: counted, not one LDS atomic each on ONE address
+                else atomicAdd(&s_h[b >> 20], 1u);
+            } else bits[u] = 0xffffffffu;
+        }
+        // wave totals (fixed shuffle tree: the sums are reproducible), then the 16 wave records through LDS to the first 16 lanes
+        for (int o = 32; o > 0; o >>= 1) {
+            sp += __shfl_down(sp, o, 64); sn += __shfl_down(sn, o, 64);
+            cnt += __shfl_down(cnt, o, 64); zeros += __shfl_down(zeros, o, 64);
+        }
+        if (lane == 0) { s_red[wid * 4] = sp; s_red[wid * 4 + 1] = sn; ((unsigned long long *)s_red)[wid * 4 + 2] = cnt; ((unsigned long long *)s_red)[wid * 4 + 3] = zeros; }
+        __syncthreads();
+        STAMP(2);
+        for (int t = tid; t < 2048; t += LOSS1_BLOCK)
+            if (s_h[t]) atomicAdd(&mycopy[t], s_h[t]);
+        if (wid == 0) {
+            const int w2 = lane & 15;
+            sp = s_red[w2 * 4]; sn = s_red[w2 * 4 + 1]; cnt = ((unsigned long long *)s_red)[w2 * 4 + 2]; unsigned long long zz = ((unsigned long long *)s_red)[w2 * 4 + 3];
+            for (int o = 8; o > 0; o >>= 1) {
+                sp += __shfl_down(sp, o, 64); sn += __shfl_down(sn, o, 64);
+                cnt += __shfl_down(cnt, o, 64); zz += __shfl_down(zz, o, 64);
+            }
+            if (lane == 0) {
+                if (zz) atomicAdd(&mycopy[0], (unsigned)zz);
+                loss1_rec *mine = rec + blockIdx.x;
+                LOSS1_ST(&mine->a, sp); LOSS1_ST(&mine->b, sn);
+                s_word = cnt;
+            }
+        }
+    }
+    STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // this wave's histogram atomics (and the two sums) have been performed
+    __syncthreads();
+    if (tid == 0) LOSS1_ST(&rec[blockIdx.x].counts, s_word | LOSS1_VALID);
+    if (blockIdx.x == 0) {
+        // gather: thread t watches block t's counters; n_pos decides k -- the sums wait until the end of the kernel
+        unsigned long long c = LOSS1_VALID;
+        for (unsigned spins = 0;; ++spins) {
+            if ((unsigned)tid < grid) c = LOSS1_LD(&rec[tid].counts);
+            if (__syncthreads_and((c & LOSS1_VALID) != 0)) break;
+            if (spins > LOSS1_SPIN_LIMIT) { if (tid == 0) LOSS1_ST(&sy->timeout, 1u); break; }
+        }
+        STAMP(12);
+        unsigned np = (unsigned)tid < grid ? (unsigned)(c & 0xffffu) : 0u;
+        for (int o = 32; o > 0; o >>= 1) np += __shfl_down(np, o, 64);
+        if (lane == 0 && np) atomicAdd(&s_misc[1], np);
+        __syncthreads();
+        if (tid == 0) {
+            const long n_pos = (long)s_misc[1], n_neg = npix - n_pos;
+            const long a = n_pos > 1 ? n_pos : 1, b = n_neg > 1 ? n_neg : 1;
+            s_misc[0] = (unsigned)(a < b ? a : b);                       // k, losses.py:110
+        }
+        __syncthreads();
+        loss1_select<2048>(hist, s_misc[0], s_w, s_misc + 4);
+        if (tid == 0) {
+            s_word = LOSS1_VALID | (unsigned long long)s_misc[4] | ((unsigned long long)s_misc[5] << 11) | ((unsigned long long)s_misc[1] << 32);
+            LOSS1_ST(&sy->rel[0], s_word);
+            LOSS1_ST(&hdr->k, s_misc[0]); LOSS1_ST(&hdr->prefix_l[0], s_misc[4]); LOSS1_ST(&hdr->k_rem_l[0], s_misc[5]);
+        }
+        __syncthreads();
+    } else {
+        loss1_wait(sy, 0, &s_word);
+    }
+    const unsigned prefix0 = (unsigned)s_word & 2047u, k_rem0 = (unsigned)(s_word >> 11) & 0x1fffffu;
+    const long n_pos_l = (long)((s_word >> 32) & 0x1fffffu);
+    STAMP(4);
+
+    // ---- stage 1: bits [19:10] of the elements inside the selected level-0 bin
+    loss1_refine<R>(bits, 20, prefix0, 10, mycopy + 2048, s_h, &s_cnt);
+    STAMP(5);
+    loss1_signal(rec, 2u);
+    if (blockIdx.x == 0) {
+        loss1_gather(rec, 2u, grid, sy);
+        STAMP(13);
+        loss1_select<1024>(hist + 2048, k_rem0, s_w, s_misc + 4);
+        if (tid == 0) {
+            s_word = LOSS1_VALID | (unsigned long long)((prefix0 << 10) | s_misc[4]) | ((unsigned long long)s_misc[5] << 21);
+            LOSS1_ST(&sy->rel[1], s_word);
+            LOSS1_ST(&hdr->prefix_l[1], (prefix0 << 10) | s_misc[4]); LOSS1_ST(&hdr->k_rem_l[1], s_misc[5]);
+        }
+        __syncthreads();
+    } else {
+        loss1_wait(sy, 1, &s_word);
+    }
+    const unsigned prefix1 = (unsigned)s_word & 0x1fffffu, k_rem1 = (unsigned)(s_word >> 21) & 0x1fffffu;
+    STAMP(6);
+
+    // ---- stage 2: bits [9:0] inside the selected level-1 bin
+    loss1_refine<R>(bits, 10, prefix1, 0, mycopy + 3072, s_h, &s_cnt);
+    STAMP(7);
+    loss1_signal(rec, 3u);
+    if (blockIdx.x == 0) {
+        loss1_gather(rec, 3u, grid, sy);
+        STAMP(14);
+        loss1_select<1024>(hist + 3072, k_rem1, s_w, s_misc + 4);
+        if (tid == 0) {
+            const unsigned Tb = (prefix1 << 10) | s_misc[4];
+            s_word = LOSS1_VALID | (unsigned long long)Tb | ((unsigned long long)s_misc[5] << 31) | ((unsigned long long)(s_misc[6] != s_misc[5]) << 52);
+            LOSS1_ST(&sy->rel[2], s_word);
+            LOSS1_ST(&hdr->T, Tb); LOSS1_ST(&hdr->need_eq, s_misc[5]);
+        }
+        __syncthreads();
+    } else {
+        loss1_wait(sy, 2, &s_word);
+    }
+    const unsigned T = (unsigned)s_word & 0x7fffffffu, need_eq = (unsigned)(s_word >> 31) & 0x1fffffu;
+    const bool ties = ((s_word >> 52) & 1ull) != 0;
+    const unsigned k = (unsigned)((n_pos_l > 1 ? n_pos_l : 1) < (npix - n_pos_l > 1 ? npix - n_pos_l : 1) ? (n_pos_l > 1 ? n_pos_l : 1) : (npix - n_pos_l > 1 ? npix - n_pos_l : 1));
+    __syncthreads();
+    STAMP(8);
+
+    // ---- stage 3 (only when the k-th value repeats and not every copy is selected): ranks of the ties in flat-index order
+    unsigned tie_rank[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) tie_rank[u] = 0;
+    if (ties) {
+        unsigned c = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) c += (bits[u] != 0xffffffffu && (bits[u] & 0x7fffffffu) == T);
+        const double tot = block_reduce_sum((double)c, s_red);
+        if (tid == 0) LOSS1_ST(&blockties[blockIdx.x], (unsigned)tot);
+        loss1_signal(rec, 4u);
+        if (blockIdx.x == 0) { loss1_gather(rec, 4u, grid, sy); if (tid == 0) LOSS1_ST(&sy->rel[3], LOSS1_VALID); }
+        else loss1_wait(sy, 3, &s_word_tie);
+        const double before = block_reduce_sum((unsigned)tid < blockIdx.x ? (double)LOSS1_LD(&blockties[tid]) : 0.0, s_red);
+        if (tid == 0) s_misc[5] = (unsigned)before;
+        __syncthreads();
+        unsigned tie_base = s_misc[5];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const bool is_tie = bits[u] != 0xffffffffu && (bits[u] & 0x7fffffffu) == T;
+            const unsigned long long bal = __ballot(is_tie);
+            __syncthreads();
+            if (lane == 0) s_w[wid] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before_waves = 0, total_iter = 0;
+            for (int w2 = 0; w2 < LOSS1_BLOCK / 64; ++w2) {
+                const unsigned cw = s_w[w2];
+                if (w2 < wid) before_waves += cw;
+                total_iter += cw;
+            }
+            tie_rank[u] = tie_base + before_waves + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            tie_base += total_iter;
+        }
+    }
+
+    // ---- stage 4: gradient, hard-negative / classification sums, loss values by the last block out
+    {
+        const double n_pos = n_pos_l > 1 ? (double)n_pos_l : 1.0;
+        const long n_neg_l = npix - n_pos_l;
+        const double n_neg = n_neg_l > 1 ? (double)n_neg_l : 1.0;
+        const loss_w Wt = {(float)(15.0 / n_pos), (float)(1.0 / n_neg), (float)(5.0 / (double)k), (float)(1.0 / n_pos), k_out, n_cls};
+        double s_hard = 0, s_cls = 0;
+        int c_correct = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (bits[u] != 0xffffffffu) {
+                const long p = lo + u * LOSS1_BLOCK + tid;
+                const unsigned b = bits[u] & 0x7fffffffu;
+                const bool sel = ties ? ((b > T) || (b == T && tie_rank[u] < need_eq)) : (b >= T);
+                const int yt = n_cls > 0 ? y_true[p] : (int)(bits[u] >> 31);
+                loss_grad_pixel(Wt, logits, dlogits, p, b, sel, x[u], yt, s_hard, s_cls, c_correct);
+            }
+        STAMP(9);
+        double v[3] = {s_hard, s_cls, (double)c_correct};
+        block_reduce_n<3>(v, s_red);
+        if (tid == 0) {
+            loss1_rec *mine = rec + blockIdx.x;
+            if (n_cls > 0) {
+                LOSS1_ST(&mine->cls, v[1]); LOSS1_ST(&mine->correct, (unsigned)v[2]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            LOSS1_ST(&mine->hard, (unsigned long long)__double_as_longlong(v[0]) | LOSS1_VALID);       // a sum of non-negative values: the sign bit says "done"
+        }
+        if (blockIdx.x == 0) {
+            // block 0 stays for the loss values: every block's sums added in block order (the loss is bit-reproducible from run to run).
+            // The first look also fetches the stage-0 sums, final since barrier 1.
+            double t[6] = {0, 0, 0, 0, 0, 0};
+            if ((unsigned)tid < grid) {
+                const loss1_rec *r = rec + tid;
+                t[0] = LOSS1_LD(&r->a); t[1] = LOSS1_LD(&r->b);
+                const unsigned long long c = LOSS1_LD(&r->counts);
+                t[2] = (double)(c & 0xffffu); t[3] = (double)((c >> 16) & 0xffffu); t[4] = (double)((c >> 32) & 0xffffu); t[5] = (double)((c >> 48) & 0x7fffu);
+            }
+            unsigned long long hw = LOSS1_VALID;
+            for (unsigned spins = 0;; ++spins) {
+                if ((unsigned)tid < grid) hw = LOSS1_LD(&rec[tid].hard);
+                if (__syncthreads_and((hw & LOSS1_VALID) != 0)) break;
+                if (spins > LOSS1_SPIN_LIMIT) { if (tid == 0) LOSS1_ST(&sy->timeout, 1u); break; }
+            }
+            // nine totals in one pass; only the first four waves hold records (grid <= 256)
+            double e[9] = {t[0], t[1], t[2], t[3], t[4], t[5], (unsigned)tid < grid ? __longlong_as_double((long long)(hw & ~LOSS1_VALID)) : 0.0, 0, 0};
+            if (n_cls > 0 && (unsigned)tid < grid) { e[7] = LOSS1_LD(&rec[tid].cls); e[8] = (double)LOSS1_LD(&rec[tid].correct); }
+            if (wid < 4) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) e[q] += __shfl_down(e[q], o, 64);
+                if (lane == 0)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) s_red[wid * 9 + q] = e[q];
+            }
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) e[q] = ((s_red[q] + s_red[9 + q]) + s_red[18 + q]) + s_red[27 + q];
+                loss_hdr snap;
+                snap.sum_pos = e[0]; snap.sum_neg = e[1]; snap.n_pos = (int)e[2]; snap.tp = (int)e[3]; snap.tn = (int)e[4]; snap.fp = (int)e[5]; snap.k = k;
+                hdr->sum_pos = e[0]; hdr->sum_neg = e[1]; hdr->n_pos = snap.n_pos; hdr->tp = snap.tp; hdr->tn = snap.tn; hdr->fp = snap.fp;
+                hdr->sum_hard = e[6]; hdr->sum_cls = e[7]; hdr->cls_correct = (int)e[8];
+                loss_finalize_body(&snap, e[6], e[7], (int)e[8], npix, n_cls, loss4);
+                if (LOSS1_LD(&sy->timeout))
+                    for (int j = 0; j < 7; ++j) loss4[j] = __uint_as_float(0x7fc00000u);
+            }
+        }
+    }
+    STAMP(10);
+#undef STAMP
+}
+#undef LOSS1_LD
+#undef LOSS1_ST
+
+struct loss1_dev_state { std::mutex mu; hipStream_t last = nullptr; bool any = false, multi = false; hipEvent_t ev = nullptr; };
+static loss1_dev_state g_loss1_dev[16];          // by device ordinal
+
+// the one-launch form applies when every block can be resident (grid <= CUs) with its chunk in registers (<= 4 pixels per thread: 1 M pixels on 256 CUs)
+static bool loss_one_launch(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits, loss_hdr *hdr,
+                            unsigned *hist, unsigned *blockties, loss1_rec *rec, int max_grid, hipStream_t st, void *dbg)
+{
+    if (max_grid > LOSS_MAX_BLOCKS) max_grid = LOSS_MAX_BLOCKS;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }   // a graph replays anywhere: the chain has no barrier
+    for (int r = 1; r <= LOSS1_MAX_R; r *= 2) {
+        const long g = (npix + (long)r * LOSS1_BLOCK - 1) / ((long)r * LOSS1_BLOCK);
+        if (g > max_grid) continue;
+#define LOSS1_LAUNCH(RR) hipLaunchKernelGGL((loss_one_kernel<RR>), dim3((int)g), dim3(LOSS1_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, blockties, rec, dlogits, loss, (unsigned long long *)dbg)
+        // Two of these kernels on two streams could each hold a part of the CUs and wait for the rest for ever (every block spins at the
+        // barriers until all of its grid is resident; the spin limit would end it with a NaN loss after seconds).  Launches on ONE stream are
+        // ordered anyway (the train step, bench.py: no cost); the first launch from a second stream of this process drains the device once,
+        // and from then on every launch waits for the previous one's event.  Processes sharing a GPU: UBD_LOSS=chain.
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        loss1_dev_state &S = g_loss1_dev[dev & 15];
+        std::lock_guard<std::mutex> lk(S.mu);
+#ifdef LOSS1_NO_STREAM_ORDER          // experiment build: shows that tests/test_gpu_loss.py::test_one_launch_form_from_two_streams_at_once has power
+        if (false) {
+#else
+        if (S.any && S.last != st) {
+#endif
+            if (!S.multi) {
+                if (hipDeviceSynchronize() != hipSuccess || hipEventCreateWithFlags(&S.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+                S.multi = true;
+            } else if (hipStreamWaitEvent(st, S.ev, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+        if (r == 1) LOSS1_LAUNCH(1); else if (r == 2) LOSS1_LAUNCH(2); else LOSS1_LAUNCH(4);
+#undef LOSS1_LAUNCH
+        if (S.multi) (void)hipEventRecord(S.ev, st);
+        S.last = st; S.any = true;
+        return true;
+    }
+    return false;
+}
+
 // h != nullptr with a UBD_COMM_GLOBAL_LOSS communicator: the reductions of losses.py:86-126 (n_pos, n_neg, the two means, the
 // top-k over the flattened batch, the classification mean) run over the images of ALL ranks -- the reference's semantics at
 // the global batch (option 2).  Rank r holds the flat indices [r * npix, (r + 1) * npix) (equal shards).
 // Eight small collectives on the caller's stream: (sums, counters, level-0 histogram), the two refined histograms, the tie
 // counts (all-gather), (hard-negative / classification sums, class hits).  Integer histograms make every rank select the
 // same threshold bit pattern; ties at the threshold go to the lower GLOBAL flat index like tf.nn.top_k.
-size_t ubd_loss_zero_bytes(void) { return LOSS_HDR_BYTES + 3 * 2048 * sizeof(unsigned); }   // header + the three histograms: zero before every evaluation
+size_t ubd_loss_zero_bytes(void) { return LOSS_HDR_BYTES + (3 * 2048 + LOSS1_COPIES * 4096) * sizeof(unsigned) + LOSS_MAX_BLOCKS * 64; }   // header + the three histograms: zero before every evaluation
 
 int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long npix, float *loss, float *dlogits,
                   char *ws, hipStream_t st, ubd_handle *h, bool prezeroed)
@@ -548,6 +1030,11 @@ int ubd_loss_impl(const float *logits, int k_out, const int32_t *y_true, long np
     chunk = (chunk + LOSS_BLOCK - 1) / LOSS_BLOCK * LOSS_BLOCK;
     const int cgrid = (int)((npix + chunk - 1) / chunk);
     int rc;
+    if (!glob && !(h && h->loss_chain) &&
+        loss_one_launch(logits, k_out, y_true, npix, loss, dlogits, hdr, (unsigned *)(ws + L.off_histk), blockties, (loss1_rec *)(ws + L.off_rec), h ? h->num_cus : LOSS_MAX_BLOCKS, st, ce)) {    // ce: unused by this form (stamps of a -DLOSS1_STAMPS build)
+        UBD_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(loss_stats_kernel, dim3(grid), dim3(LOSS_STATS_BLOCK), 0, st, logits, k_out, y_true, npix, hdr, hist, ce, part);
     if (glob) {
         if ((rc = ubd_comm_allreduce_raw(h, &hdr->sum_pos, 2, UBD_RED_F64, st))) return rc;
