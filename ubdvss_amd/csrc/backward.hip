@@ -1304,7 +1304,7 @@ static int launch_sep_bwd(const ubd_handle *h, const void *x, int in_u8, const f
 }
 
 template <int CIN, int STRIDE, int GSRC, typename T>
-static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const unsigned short *D, const unsigned short *maskact,
+static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const unsigned short *D, const unsigned *mbits, unsigned *xbits,
                           unsigned short *dDW, const float *dw_own, const float *pw_own, const float *dw_up, float *g_dw, float *g_pw,
                           float *g_b, rp_queue *rq, int n, int H, int W, int OH, int OW, int pad_lo, int DH, int DWd, int pad_up,
                           float sub, float div, hipStream_t st)
@@ -1324,14 +1324,14 @@ static int launch_sepb16(const ubd_handle *h, const void *x, int in_u8, const un
     if (!partials) return -1;
     if constexpr (CIN != UBD_C) {
         if (xdma) {
-            hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 2, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
+            hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 2, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, mbits, xbits, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
             return 0;
         }
     }
     if (in_u8)
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 1, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, mbits, xbits, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
     else
-        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, maskact, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
+        hipLaunchKernelGGL((sepb16_kernel<CIN, STRIDE, 0, GSRC, T>), dim3(grid), dim3(C::NT), 0, st, x, D, mbits, xbits, dDW, dw_own, pw_own, dw_up, partials, n, H, W, OH, OW, pad_lo, DH, DWd, pad_up, sub, div, prev SB_STAMP_ARG);
     return 0;
 }
 
@@ -1491,20 +1491,22 @@ static int backward_impl(ubd_handle *h, const float *params, const void *images,
         const float *dw0 = params + h->off_sep_dw[0], *dw1 = params + h->off_sep_dw[1], *dw2 = params + h->off_sep_dw[2];
         const float *pw0 = params + h->off_sep_pw[0], *pw1 = params + h->off_sep_pw[1], *pw2 = params + h->off_sep_pw[2];
         unsigned short *ddw3 = (unsigned short *)(ws + T.off_ddw3), *ddw2 = (unsigned short *)(ws + T.off_gb[0]);
-        if (launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
+        // ReLU bits of a2 and a1 (one word per pixel, sepbwd16.h): written by the kernel that reads the activation as its input, read by the next one
+        unsigned *bits2 = (unsigned *)(ws + T.off_gb[1]), *bits1 = bits2 + ubd_align_up((size_t)n * H2 * W2, 64);
+        if (launch_sepb16<UBD_C, 2, 0, TX>(h, a2, 0, g16[cur], nullptr, bits2, ddw3, dw2, pw2, dw2, grads + h->off_sep_dw[2], grads + h->off_sep_pw[2],
                                        grads + h->off_sep_b[2], &rq, n, H2, W2, H4, W4, pad2, H4, W4, 0, 0.f, 1.f, st)) return -1;
         if (h->chain_reduce && ubd_comm_fused(h)) { const int rc = ubd_comm_begin_tail(h, grads, st); if (rc) return rc; }   // dilated + head gradients are final
-        if (launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, (const unsigned short *)a2, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
+        if (launch_sepb16<UBD_C, 1, 2, TX>(h, a1, 0, ddw3, bits2, bits1, ddw2, dw1, pw1, dw2, grads + h->off_sep_dw[1], grads + h->off_sep_pw[1],
                                        grads + h->off_sep_b[1], &rq, n, H2, W2, H2, W2, 1, H4, W4, pad2, 0.f, 1.f, st)) return -1;
         float sub = 0.f, div = 1.f;
         if (preprocessing == UBD_PRE_MOBILENET) { sub = 127.5f; div = 127.5f; }
         const int u8 = in_dtype == UBD_IN_U8;
         int rc1;
         if (h->cfg.c_in == 1)
-            rc1 = launch_sepb16<1, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+            rc1 = launch_sepb16<1, 2, 1, TX>(h, images, u8, ddw2, bits1, nullptr, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
                                              grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
         else
-            rc1 = launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, (const unsigned short *)a1, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
+            rc1 = launch_sepb16<3, 2, 1, TX>(h, images, u8, ddw2, bits1, nullptr, nullptr, dw0, pw0, dw1, grads + h->off_sep_dw[0], grads + h->off_sep_pw[0],
                                              grads + h->off_sep_b[0], &rq, n, H, W, H2, W2, pad2, H2, W2, 1, sub, div, st);
         if (rc1) return -1;
         rp_flush(&rq, st);

@@ -10,9 +10,15 @@
 //   GSRC 1  (L1)  G = dwT(dDW of L2; stride 1, pad 1)            * (a1 > 0)
 //   GSRC 2  (L2)  G = dwT(dDW of L3; stride 2, pad_up top/left)  * (a2 > 0)
 //
+// The ReLU masks are read as BITS (round 6): one 32-bit word per pixel -- bit d = (channel 2d of the saved activation > 0), bit 16 + d =
+// (channel 2d + 1 > 0), d = 0..11: the two halves of the word mirror the two halves of the 16-bit pairs, so a pair's 0 / 1 factors are
+// (word >> d) & 0x00010001 -- 4 bytes per pixel instead of the 48 of the activation itself.  The words are a by-product of the kernel that runs before: a 24-channel kernel
+// reads the layer's INPUT activation as its X patch anyway (L3's kernel reads a2, L2's reads a1) and writes the words of the pixels
+// its tile owns.  Per 64-image batch: -188 MB read in L2's kernel and in L1's, +17 MB written in L3's and in L2's.
+//
 // Phase 0: LDS-DMA of the input patch (24 channels; 1/3 channels go through registers one tile ahead), of the raw bf16 D
-// tile (G3 tile, or dDW-above tile with halo) and of the ReLU-mask tile (this layer's saved output; GSRC 1, 2): clamped
-// addresses, out-of-map pixels zero-fixed.  D and mask of the NEXT tile are requested right after phase 1; the stride-1
+// tile (G3 tile, or dDW-above tile with halo) and of the ReLU-bit tile (one word per pixel of this layer's output; GSRC 1, 2);
+// out-of-map pixels read as zeros (buffer range).  D and mask of the NEXT tile are requested right after phase 1; the stride-1
 // 24-channel layer double-buffers its X patch and requests the next one under phase 2.
 // Phase 1 (L1, L2): the G tile [pixel][24] in T from the raw tiles (lane = pixel column i, channels {4q..4q+3, 16+2q,
 // 17+2q}); every G tensor of the bf16 train step is a bf16 tensor, these two just never leave LDS.  L1 (stride-1
@@ -51,18 +57,18 @@ template <int CIN, int STRIDE, int GSRC, int XDMA = 0> struct sepb16_cfg {
     static constexpr int DCOLS = GSRC == 0 ? 16 : (GSRC == 1 ? 18 : 10);
     static constexpr int DPIX = DROWS * DCOLS;
     // DMA regions (16-byte chunks, 3 per bf16 pixel; each region is a whole number of 1 KiB wave-instructions):
-    // [X patch (24 ch only) x XBUF] [D tile] [ReLU-mask tile = this layer's saved output (GSRC 1, 2)]
+    // [X patch (24 ch only) x XBUF] [D tile] [ReLU-bit tile: one word per G pixel (GSRC 1, 2), 4-byte DMA, 64 words per wave-instruction]
     // XBUF 2 (the stride-1 24-channel layer, 8-row tiles): the NEXT tile's X patch is fetched under phase 2 into the other
     // buffer -- with one buffer the patch was requested at the top of the tile and the wave sat out a memory round trip
     // there (7.7 k of 25 k cycles per tile in the stamps: the CU had ~16 KB in flight on average, 2-3 TB/s chip-wide).
     static constexpr int XBUF = (CIN == UBD_C && STRIDE == 1) ? 2 : 1;
     static constexpr int XCHUNKS = (CIN == UBD_C) ? XPIX * 3 : 0;
     static constexpr int XI = (XCHUNKS + 63) / 64, DI = (DPIX * 3 + 63) / 64;        // wave-instructions
-    static constexpr int MI = (GSRC != 0) ? (GPIX * 3 + 63) / 64 : 0;
+    static constexpr int MI = (GSRC != 0) ? (GPIX + 63) / 64 : 0;
     static constexpr int XK = (XI + NW - 1) / NW, DK = (DI + NW - 1) / NW, MK = (MI + NW - 1) / NW;   // per wave
     static constexpr int OFF_D = XBUF * XI * 1024;                                  // byte offsets inside the DMA area
     static constexpr int OFF_M = OFF_D + DI * 1024;
-    static constexpr int DMA_BYTES = OFF_M + MI * 1024;
+    static constexpr int DMA_BYTES = OFF_M + ((MI * 256 + 1023) / 1024) * 1024;
     static constexpr int XREGS = (CIN == UBD_C || XDMA) ? 1 : (XPIX * CIN + NT - 1) / NT;                  // staged input elements per thread
     // XDMA (1/3-channel fp32 input that needs no preprocessing, image rows a whole number of 16-byte chunks): the patch rows are
     // fetched by LDS-DMA from the 16-byte boundary at or below their first float (skew 0..3 floats: pad_lo channels back from a
@@ -115,13 +121,20 @@ template <typename T> __device__ __forceinline__ void widen2b(unsigned w, float 
     hi = (float)__builtin_bit_cast(T, (unsigned short)(w >> 16));
 }
 
-// g (two 16-bit values) with each half zeroed where the matching half of the saved activation m is +0 / -0
-__device__ __forceinline__ unsigned relu_mask2(unsigned g, unsigned m)
+// g (two 16-bit values: channel pair d) with each half kept where the pixel's ReLU word has bit d / bit 16 + d set
+__device__ __forceinline__ unsigned relu_bits2(unsigned g, unsigned word, int d)
 {
-    unsigned k, r;                                   // asm: hipcc rewrites the vector form into two compares, two selects and a v_perm
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(m & 0x7FFF7FFFu), "v"(0x00010001u));
+    const unsigned k = (word >> d) & 0x00010001u;    // 0 / 1 factor per half
+    unsigned r;
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(g), "v"(k));
     return r;
+}
+// 0 / 1 per half of a pair of saved 16-bit activations (never negative: > 0 iff the 15 magnitude bits are non-zero)
+__device__ __forceinline__ unsigned relu_pair_bits(unsigned m)
+{
+    unsigned k;                                      // asm: hipcc rewrites the vector form into two compares, two selects and a v_perm
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(k) : "v"(m & 0x7FFF7FFFu), "v"(0x00010001u));
+    return k;
 }
 
 template <int D, int NMAX> using sepb16_magic = ubd_magic24<D, NMAX>;      // (common.h)
@@ -155,10 +168,26 @@ __device__ __forceinline__ void sepb16_stage_ar(const char *__restrict__ tensor,
     }
 }
 
+// the ReLU-bit tile [TH][16] words of image img at (y0, x0): 4-byte LDS-DMA, 64 words (four tile rows) per wave-instruction
+template <int NK, int NINSTR, int NW>
+__device__ __forceinline__ void sepb16_stage_bits(const unsigned *__restrict__ bits, int img, int th, int tw, int y0, int x0, unsigned lds_dst, int lane, int wid)
+{
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bits + (size_t)img * th * tw), 0, (int)((unsigned)th * tw * 4u), 0x00020000);   // wave-uniform
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int instr = k * NW + wid;
+        if (instr >= NINSTR) break;                                       // wave-uniform
+        const int w = instr * 64 + lane, gy = y0 + (w >> 4), gx = x0 + (w & 15);
+        const unsigned off = (unsigned)gx < (unsigned)tw ? (unsigned)((gy * tw + gx) * 4) : 0x80000000u;   // rows below the map: past the range by themselves
+        ubd_blds4(rsrc, off, lds_dst + instr * 256);
+    }
+}
+
 // IN_MODE (1/3-channel layers): 0 fp32 input through registers (preprocessed here), 1 uint8 input through registers, 2 fp32 input by LDS-DMA
 template <int CIN, int STRIDE, int IN_MODE, int GSRC, typename T>
 __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::BLOCKS_PER_CU >= 3) ? (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::BLOCKS_PER_CU) : 2) void sepb16_kernel(const void *__restrict__ xin, const unsigned short *__restrict__ D,
-                                                        const unsigned short *__restrict__ maskact, unsigned short *__restrict__ dDW,
+                                                        const unsigned *__restrict__ mbits, unsigned *__restrict__ xbits, unsigned short *__restrict__ dDW,
                                                         const float *__restrict__ dw_own, const float *__restrict__ pw_own,
                                                         const float *__restrict__ dw_up, float *__restrict__ partials, int n, int H,
                                                         int W, int OH, int OW, int pad_lo, int DH, int DW_, int pad_up, float pre_sub,
@@ -187,7 +216,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
     const int i = lane & 15, q = lane >> 4;
     float *xf32 = (float *)lds;                                                  // 1/3-channel patch (fp32)
     char *dma = lds + C::OFF_DMA;
-    const char *draw = dma + C::OFF_D, *mraw = dma + C::OFF_M;                   // D tile, ReLU-mask tile (raw 16-bit activations)
+    const char *draw = dma + C::OFF_D, *mraw = dma + C::OFF_M;                   // D tile, ReLU-bit tile (one word per G pixel)
     char *g16 = (GSRC == 0) ? dma + C::OFF_D : lds + C::OFF_G;              // G tile [pixel][24] in T
     char *sdw = lds + C::OFF_SDW + wid * C::SDW_BYTES;                      // this wave's [32 pixels][SDW_W] depthwise outputs
     char *sdd = lds + C::OFF_SDD + wid * C::SDW_BYTES;                      // ... and dDW values (24-channel layers)
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
     auto stage_dm = [&](const geom &g) {
         sepb16_stage_ar<C::DK, C::DI, C::DPIX * 3, C::DCOLS, C::NW>((const char *)D, g.img, DH, DW_, g.dy0, g.dx0, lds_dma + C::OFF_D, lane, wid);
         if constexpr (GSRC != 0)
-            sepb16_stage_ar<C::MK, C::MI, C::GPIX * 3, 16, C::NW>((const char *)maskact, g.img, OH, OW, g.oy0, g.ox0, lds_dma + C::OFF_M, lane, wid);
+            sepb16_stage_bits<C::MK, C::MI, C::NW>(mbits, g.img, OH, OW, g.oy0, g.ox0, lds_dma + C::OFF_M, lane, wid);
     };
     auto stage_x = [&](const geom &g, int buf) {
         if constexpr (CIN == UBD_C)
@@ -511,14 +540,35 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // ... for every wave; LDS writes visible
         SBSTAMP(3);
+        // ---- ReLU bits of the X pixels this tile owns (24-channel layers: X is the saved output of the layer below, whose kernel runs
+        //      next and needs nothing else of it).  Owned = the TH*STRIDE x 16*STRIDE pixels at patch (pad_lo, pad_lo); pixels outside the
+        //      map are zero in the patch.  The store is older than the next tile's DMA requests: the vmcnt(4) accounting stays.
+        if constexpr (CIN == UBD_C) {
+            if (xbits) {                                                // kernel-uniform
+                constexpr int OWNW = 16 * STRIDE, OWN = C::TH * STRIDE * OWNW;
+#pragma unroll
+                for (int k = 0; k < (OWN + C::NT - 1) / C::NT; ++k) {
+                    const int p = k * C::NT + (int)threadIdx.x;
+                    if (OWN % C::NT != 0 && p >= OWN) break;            // wave-uniform (OWN is a multiple of 64)
+                    const int rr = p / OWNW, cc = p % OWNW;
+                    const char *px = xraw + ((rr + pad_lo) * C::PW + cc + pad_lo) * 48;
+                    const u32x4 v0 = *(const u32x4 *)px, v1 = *(const u32x4 *)(px + 16), v2 = *(const u32x4 *)(px + 32);
+                    unsigned word = 0;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        word |= (relu_pair_bits(v0[d]) << d) | (relu_pair_bits(v1[d]) << (4 + d)) | (relu_pair_bits(v2[d]) << (8 + d));
+                    const int y = oy0 * STRIDE + rr, x = ox0 * STRIDE + cc;
+                    if (y < H && x < W) xbits[((size_t)img * H + y) * W + x] = word;
+                }
+            }
+        }
         // ---- phase 1: G tile in T (GSRC 0: the staged G3 tile is used as it is)
         if constexpr (GSRC != 0) {
 #pragma unroll
         for (int kr = 0; kr < C::TH / C::NW; ++kr) {
             const int r = wid + C::NW * kr;
             float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const u32x2 ma = *(const u32x2 *)(mraw + (r * 16 + i) * 48 + 8 * q);
-            const unsigned mb = *(const unsigned *)(mraw + (r * 16 + i) * 48 + 32 + 4 * q);
+            const unsigned mword = *(const unsigned *)(mraw + (r * 16 + i) * 4);   // this pixel's ReLU bits; the lane's channels: 4q .. 4q+3, 16+2q, 17+2q
             if constexpr (UREG) {
                 const char *rowb = draw + r * (C::DCOLS * 48);
                 u32x4 b0[5], b1[3];
@@ -579,9 +629,8 @@ __global__ __launch_bounds__(256, (sepb16_cfg<CIN, STRIDE, GSRC, IN_MODE == 2>::
 
             u32x2 g4 = {pack2b<T>(acc[0], acc[1]), pack2b<T>(acc[2], acc[3])};
             unsigned g2 = pack2b<T>(acc[4], acc[5]);
-            // ReLU mask: the saved activation (never negative) is > 0 iff its 15 magnitude bits are non-zero; per 16-bit half
-            // min(magnitude, 1) is the 0 / 1 factor of a packed integer multiply (three instructions per channel pair)
-            g4[0] = relu_mask2(g4[0], ma[0]); g4[1] = relu_mask2(g4[1], ma[1]); g2 = relu_mask2(g2, mb);
+            // ReLU mask: the pair's two bits become the 0 / 1 factors of a packed integer multiply
+            g4[0] = relu_bits2(g4[0], mword, 2 * q); g4[1] = relu_bits2(g4[1], mword, 2 * q + 1); g2 = relu_bits2(g2, mword, 8 + q);   // pairs 2q, 2q + 1, 8 + q
             char *pg = g16 + (r * 16 + i) * 48;
             *(u32x2 *)(pg + 8 * q) = g4;
             *(unsigned *)(pg + 32 + 4 * q) = g2;
