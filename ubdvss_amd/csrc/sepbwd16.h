@@ -89,7 +89,7 @@ template <int CIN, int STRIDE, int GSRC, int XDMA = 0> struct sepb16_cfg {
     // blocks per CU = waves per SIMD: three when the LDS clearly allows it (a grid that is not fully resident runs in two
     // uneven waves of blocks) and the kernel fits 168 VGPRs (24 channels), else two
 #ifndef SEPB16_XD_BLOCKS
-#define SEPB16_XD_BLOCKS 3
+#define SEPB16_XD_BLOCKS 4      // round 6: with the ReLU masks as bits the DMA-fed L1 kernel needs 125 registers: four blocks per CU hide more of its exposed DMA wait (1.3-1.7 k of 6 k cycles per tile in the stamps)
 #endif
     static constexpr int BLOCKS_PER_CU = LDS_BYTES > 78 * 1024 ? 1 : ((CIN == UBD_C && 3 * LDS_BYTES <= 150 * 1024) ? 3 : (CIN != UBD_C ? (XDMA ? SEPB16_XD_BLOCKS : SEPB16_L1_BLOCKS) : 2));
     static constexpr int PART = 9 * CIN + CIN * UBD_C + UBD_C;
