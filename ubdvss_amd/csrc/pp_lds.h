@@ -207,7 +207,15 @@ __device__ __forceinline__ int hull_finish_wave(int &X, int &Y, int nl, int nr, 
     };
     if (nr > 0 && pp_rl(X, nl - 1) == pp_rl(X, nl) && pp_rl(Y, nl - 1) == pp_rl(Y, nl)) remove_at(nl);      // bottom junction
     if (n > 1 && pp_rl(X, n - 1) == pp_rl(X, 0) && pp_rl(Y, n - 1) == pp_rl(Y, 0)) --n;                    // top junction
-    bool changed = true;
+    // The chains come out of the gift wrapping without collinear triples; one can only appear where the chains meet.  ALL triples are tested
+    // at once (vertex v in lane v, neighbours by lane exchange): the serial removal loop below -- n dependent steps per sweep, at least one
+    // sweep, ~10 cycles per dependent instruction on a lone wave -- runs only when some triple IS collinear (it then does what it always did).
+    bool changed = false;
+    if (n > 2) {
+        const int lp = lane == 0 ? n - 1 : lane - 1, ln = lane + 1 >= n ? 0 : lane + 1;
+        const ipt a = {__shfl(X, lp, 64), __shfl(Y, lp, 64)}, b = {X, Y}, c = {__shfl(X, ln, 64), __shfl(Y, ln, 64)};
+        changed = __ballot(lane < n && cross3(a, b, c) == 0) != 0ull;
+    }
     while (changed && n > 2) {
         changed = false;
         for (int k = 0; k < n && n > 2; ++k) {
