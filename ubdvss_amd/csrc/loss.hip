@@ -536,8 +536,9 @@ __global__ __launch_bounds__(LOSS_GRAD_BLOCK) void loss_grad_kernel(const float 
 // ce * (1 - z), label sign) from the first load to the gradient store: nothing is written and read back in between.  The radix
 // select keeps the chain's three levels (11 / 10 / 10 bits; a 16 / 15-bit split was built first: two stages, but ~3000 non-empty
 // bins per block = 770 k global atomics = 60 us).  The stages are separated by grid-wide barriers (every block is resident: grid <=
-// CUs, one block per CU); the LAST block to arrive does the serial part of a stage (totals in block order, the selection scan)
-// before it releases the others.  A fourth barrier exists only when the k-th value repeats and not all of its copies are selected
+// CUs, one block per CU): a block signals a stage by a plain store to its own record, block 0 watches the records, does the serial
+// part of the stage (the selection scan; at the end the totals in block order) and releases the others through a word that carries
+// what it decided.  A fourth barrier exists only when the k-th value repeats and not all of its copies are selected
 // (tie ranks in flat-index order need the counts of the blocks in front).  Everything one block hands to another goes through
 // agent-scope atomics / cache-bypassing loads and stores ordered by s_waitcnt -- no release / acquire fences: on this part each
 // one is an L2 write-back + invalidate (measured: 19 us per barrier with them).
