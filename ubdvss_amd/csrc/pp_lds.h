@@ -399,32 +399,42 @@ __device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ 
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     int cnt[2] = {0, 0};
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {            // 0: left chain (min x), 1: right chain (max x)
-        // Gift wrapping down the chain: from vertex row c the next vertex is the later row with the
-        // extreme slope dx/dy (min for the left chain, max for the right one; farthest on ties, which
-        // drops collinear points).  Candidates are spread over the 64 lanes, fractions compared
-        // exactly by int32 cross-multiplication (|dx|, dy < 2^15), then a xor-butterfly reduction.
-        ipt *out = pts + (side ? cnt[0] : 0);
+    ipt *ptsr = pts + h;                               // the right chain is built here (second half of the 2 h point slots)
+    {
+        // Gift wrapping down BOTH chains at once: lanes 0-31 wrap the left chain (min x), lanes 32-63 the right one (max x).  From
+        // vertex row c the next vertex is the later row with the extreme slope dx/dy (min for the left chain, max for the right one;
+        // farthest on ties, which drops collinear points).  A chain's candidates are spread over its 32 lanes, fractions compared exactly
+        // by int32 cross-multiplication (|dx|, dy < 2^15), then a xor-butterfly inside the half.  A step is ~1.2 k cycles of dependent
+        // lane exchanges whoever takes part: with the chains one after the other (round 1-5) the object paid for the SUM of their vertex
+        // counts, now for the larger one (the box fit was 75 k of the front end's 170 k cycles, tools/stamps_pp.py).
+        const int side = lane >> 5, hl = lane & 31;
+        ipt *out = side ? ptsr : pts;
         int nout = 0, c = 0;
+        bool done = false;                            // uniform within a half
         for (;;) {
-            const int xc = rws[2 * c + side];
-            if (lane == 0) out[nout] = (ipt){xc, y0 + c};
-            ++nout;
-            if (c >= nrows - 1) break;
-            int bn = 0, bd = 0, br = -1;
-            for (int r = c + 1 + lane; r < nrows; r += 64) {
-                const int nn = rws[2 * r + side] - xc, dd = r - c;
-                bool better = true;
-                if (bd != 0) {
-                    const int lhs = nn * bd, rhs = bn * dd;
-                    better = side ? (lhs >= rhs) : (lhs <= rhs);      // later row wins ties
-                }
-                if (better) { bn = nn; bd = dd; br = r; }
+            int xc = 0;
+            if (!done) {
+                xc = rws[2 * c + side];
+                if (hl == 0) out[nout] = (ipt){xc, y0 + c};
+                ++nout;
+                if (c >= nrows - 1) done = true;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int on = __shfl_xor(bn, o, 64), od = __shfl_xor(bd, o, 64), orr = __shfl_xor(br, o, 64);
+            if (__ballot(!done) == 0ull) break;       // wave-uniform: both chains have reached the last row
+            int bn = 0, bd = 0, br = -1;
+            if (!done)
+                for (int r = c + 1 + hl; r < nrows; r += 32) {
+                    const int nn = rws[2 * r + side] - xc, dd = r - c;
+                    bool better = true;
+                    if (bd != 0) {
+                        const int lhs = nn * bd, rhs = bn * dd;
+                        better = side ? (lhs >= rhs) : (lhs <= rhs);      // later row wins ties
+                    }
+                    if (better) { bn = nn; bd = dd; br = r; }
+                }
+            // The best of the half's 32 candidates (a maximum under a total order -- slope, then row -- so any exchange pattern that
+            // joins groups which already agree will do): inside a row of 16 lanes by DPP (quad permutes, then the mirrors of 8 and of 16 --
+            // no LDS crossbar round trip), then one exchange between the half's two rows.
+            auto join = [&](int on, int od, int orr) {
                 bool take;
                 if (od == 0) take = false;
                 else if (bd == 0) take = true;
@@ -433,17 +443,25 @@ __device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ 
                     take = lhs == rhs ? (orr > br) : (side ? (lhs > rhs) : (lhs < rhs));
                 }
                 if (take) { bn = on; bd = od; br = orr; }
-            }
-            c = br;
+            };
+#define PP_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
+            join(PP_DPP(bn, 0xB1), PP_DPP(bd, 0xB1), PP_DPP(br, 0xB1));            // quad_perm [1,0,3,2]
+            join(PP_DPP(bn, 0x4E), PP_DPP(bd, 0x4E), PP_DPP(br, 0x4E));            // quad_perm [2,3,0,1]
+            join(PP_DPP(bn, 0x141), PP_DPP(bd, 0x141), PP_DPP(br, 0x141));         // row_half_mirror
+            join(PP_DPP(bn, 0x140), PP_DPP(bd, 0x140), PP_DPP(br, 0x140));         // row_mirror
+#undef PP_DPP
+            join(__shfl_xor(bn, 16, 64), __shfl_xor(bd, 16, 64), __shfl_xor(br, 16, 64));
+            if (!done) c = br;
         }
-        cnt[side] = nout;
+        cnt[0] = __builtin_amdgcn_readlane(nout, 0);
+        cnt[1] = __builtin_amdgcn_readlane(nout, 32);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     if (cnt[0] + cnt[1] <= 64 && !serial_tail) {                  // wave-uniform: the polygon fits the wave's lanes (the usual case)
         int X = 0, Y = 0;
         if (lane < cnt[0] + cnt[1]) {
-            const ipt pv = pts[lane < cnt[0] ? lane : cnt[0] + (cnt[1] - 1 - (lane - cnt[0]))];   // the right chain reversed
+            const ipt pv = lane < cnt[0] ? pts[lane] : ptsr[cnt[1] - 1 - (lane - cnt[0])];   // the right chain reversed
             X = pv.x; Y = pv.y;
         }
         const int nh = hull_finish_wave(X, Y, cnt[0], cnt[1], lane);
@@ -456,6 +474,17 @@ __device__ __forceinline__ void pp_box_object(int *rws, const int *__restrict__ 
         }
         __builtin_amdgcn_wave_barrier();
         return;
+    }
+    // the one-lane form wants the right chain right behind the left one: moved down in pieces of 64 (a piece's targets lie below every later source)
+    for (int e0 = 0; e0 < cnt[1]; e0 += 64) {
+        const int e = e0 + lane;
+        ipt t = {0, 0};
+        if (e < cnt[1]) t = ptsr[e];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (e < cnt[1]) pts[cnt[0] + e] = t;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
     }
     int nh = 0;
     if (lane == 0) hull_finish(pts, cnt[0], cnt[1], nh);
