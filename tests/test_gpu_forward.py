@@ -71,7 +71,7 @@ def test_random_shape_soak_vs_oracle(monkeypatch):
         cin, ncls, fml = int(rng.choice([1, 3])), int(rng.choice([0, 0, 2])), bool(rng.integers(0, 2))
         n, hh, ww = int(rng.integers(1, 4)), 4 * int(rng.integers(4, 41)), 4 * int(rng.integers(4, 41))
         u8 = bool(rng.integers(0, 2))
-        stem = str(rng.choice(["fused123", "fused", "unfused", ""]))
+        stem = str(rng.choice(["fused123", "fused", "unfused", "cold123", ""]))
         if stem: monkeypatch.setenv("UBD_STEM", stem)
         else: monkeypatch.delenv("UBD_STEM", raising=False)
         w = onet.init_weights(300 + case, cin, ncls, bias_scale=0.25)
@@ -342,17 +342,19 @@ def test_net_manager_loads_reference_files(tmp_path, golden_dir):
 def test_fused_stem_path(monkeypatch):
     """Inference stem variants (UBD_STEM): "fused123" = L1 -> L2 -> L3 in ONE kernel, neither intermediate activation ever in
     memory (stem123.h; the default with the fml padding), "fused" = L1, then L2 -> L3 fused (stem23.h), "unfused" = three
-    kernels (what training runs).  Same oracle, same bounds, all variants agree to fp32 rounding; UBD_TEST_NUM_CUS=2 makes every
+    kernels (what training runs), "cold123" = the one kernel with single cold-started tiles as work units.  Same oracle, same bounds, all variants agree to fp32 rounding; UBD_TEST_NUM_CUS=2 makes every
     block walk several strips of tiles (register prefetch of the next input patch, the carried 33rd column across tiles and strip
     starts); uint8 input with the fused preprocessing and grey input go through the one-kernel stem too."""
     from ubdvss_amd import PreprocessingType
     cases = ((3, 0, True, 2, 128, 128), (1, 2, False, 1, 72, 100), (3, 1, True, 3, 64, 200), (3, 0, False, 1, 8, 8), (1, 0, True, 2, 4, 36),
              (3, 0, True, 2, 96, 512), (3, 0, False, 2, 40, 264), (1, 1, True, 2, 136, 72))
     outs = {}
-    for mode in ("unfused", "fused", "fused123", "fused123_few_cus"):
+    for mode in ("unfused", "fused", "fused123", "fused123_few_cus", "cold123", "cold123_few_cus"):
         monkeypatch.setenv("UBD_STEM", mode.replace("_few_cus", ""))
         if mode.endswith("few_cus"):
             monkeypatch.setenv("UBD_TEST_NUM_CUS", "2")
+        else:
+            monkeypatch.delenv("UBD_TEST_NUM_CUS", raising=False)
         for cin, ncls, fml, n, hh, ww in cases:
             w = onet.init_weights(400 + cin + ncls, cin, ncls, bias_scale=0.25)
             x = synthetic.noise_images(19, n, hh, ww, cin)
@@ -372,6 +374,11 @@ def test_fused_stem_path(monkeypatch):
         for mode in ("fused", "fused123"):
             assert np.abs(outs[(mode, cin, ncls, fml, n, hh, ww)] - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), (mode, cin, fml, hh, ww)
         assert np.array_equal(outs[("fused123", cin, ncls, fml, n, hh, ww)], outs[("fused123_few_cus", cin, ncls, fml, n, hh, ww)])   # tile -> block assignment is irrelevant
+        # "cold123" (round 6; the default of launches too small for strips): the same kernel with one cold-started tile per work unit, the
+        # tiles of a row 15 columns apart -- every output by the same instructions on the same values as in the strip walk: bit-identical
+        if fml:                                                          # both are forms of the fml-padding kernel; other models take the separate kernels
+            assert np.array_equal(outs[("cold123", cin, ncls, fml, n, hh, ww)], outs[("fused123", cin, ncls, fml, n, hh, ww)]), (cin, fml, hh, ww)
+            assert np.array_equal(outs[("cold123_few_cus", cin, ncls, fml, n, hh, ww)], outs[("fused123", cin, ncls, fml, n, hh, ww)]), (cin, fml, hh, ww)
 
 
 @pytest.mark.parametrize("few_cus", [False, True])
@@ -473,3 +480,27 @@ def test_zero_kernel_layer_writes_exactly_the_bias_at_full_size():
                 torch.cuda.synchronize()
                 bad = (y.reshape(-1, 24) != want).any(dim=1)
                 assert not bool(bad.any()), (shape, k, int(bad.sum()))
+
+
+def test_cold_tiles_equal_the_strip_walk_at_every_width(monkeypatch):
+    """stem123.h COLD (the default of launches too small for strips; forced here with UBD_STEM=cold123): single cold-started tiles 15 L3
+    columns apart against the strip walk (UBD_STEM=fused123) at the widths where the number of tiles per row, the last tile's share and the
+    16-byte alignment of the patch rows change (W4 = 1 .. 129), fp32 (LDS-DMA and register staging) and uint8 input, grey and RGB, heights
+    that cut the last tile row: logits BIT-EQUAL."""
+    from ubdvss_amd import PreprocessingType
+    rng = np.random.default_rng(5)
+    for k, w4 in enumerate((1, 2, 15, 16, 17, 30, 31, 32, 33, 45, 46, 47, 61, 76, 127, 128, 129)):
+        cin, u8 = (1 if k % 2 else 3), (k % 3 == 1)
+        n, hh, ww = 1 + k % 2, 4 * int(rng.integers(1, 12)), 4 * w4
+        w = onet.init_weights(900 + k, cin, 0, bias_scale=0.25)
+        cfg = NetConfig(grey=(cin == 1), fml_compatible=True, preprocessing=PreprocessingType.MOBILENET_LIKE if u8 else PreprocessingType.NONE)
+        x = rng.integers(0, 256, (n, hh, ww, cin), dtype=np.uint8) if u8 else synthetic.noise_images(60 + k, n, hh, ww, cin)
+        if not u8 and k % 4 == 0: x = x[:, :, :, :] * np.float32(1.0) + np.float32(0.0)      # a fresh, 16-byte aligned array either way
+        outs = {}
+        for mode in ("fused123", "cold123"):
+            monkeypatch.setenv("UBD_STEM", mode)
+            m = Model(cfg); m.set_weights(w)
+            outs[mode] = m.predict(x)
+        assert np.array_equal(outs["cold123"], outs["fused123"]), (w4, hh, cin, u8, float(np.abs(outs["cold123"] - outs["fused123"]).max()))
+        ref = onet.forward(((x.astype(np.float64) - 127.5) / 127.5) if u8 else x.astype(np.float64), w, True)
+        _check(outs["cold123"], ref)

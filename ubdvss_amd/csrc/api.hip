@@ -80,6 +80,7 @@ extern "C" int ubd_create(const ubd_config *cfg, ubd_handle **out)
         h->fuse_stem = cfg->fml_compatible != 0 ? 2 : 0;        // 2: L1 -> L2 -> L3 in one kernel (stem123.h; fml padding only)
         if (s && strcmp(s, "fused") == 0) { h->fuse_stem = 1; h->fuse_force = 1; }      // 1: L1, then L2 -> L3 fused (stem23.h)
         if (s && strcmp(s, "fused123") == 0) { h->fuse_stem = 2; h->fuse_force = 1; }   // forced at any launch size (tests)
+        if (s && strcmp(s, "cold123") == 0 && cfg->fml_compatible != 0) { h->fuse_stem = 3; h->fuse_force = 1; }   // one kernel, one cold-started tile per work unit, at any launch size (tests; default for small launches)
         if (s && strcmp(s, "unfused") == 0) h->fuse_stem = 0;
         // test hooks: pretend the device has fewer CUs, so that every persistent kernel walks many tiles per block even on
         // the small shapes the CPU oracle can check (tests/test_gpu_persistent.py; ubd_num_cus reports what was taken)

@@ -93,7 +93,7 @@ __device__ __forceinline__ void store_tile_relu_t(float *__restrict__ y, size_t 
 
 // same with the bias already in the accumulators (it rode in as the MFMA's C operand): ReLU in one instruction per value
 __device__ __forceinline__ void store_tile_relu_nb(float *__restrict__ y, size_t row_base_elems, int x0, int ow,
-                                                   int lane, f32x4 acc0, f32x4 acc1)
+                                                   int lane, f32x4 acc0, f32x4 acc1, bool drop = false /* this lane's pixel is not stored */)
 {
     const int i = lane & 15, q = lane >> 4;
     const unsigned long long rp = (unsigned long long)(y + (row_base_elems + (size_t)x0) * UBD_C);
@@ -104,8 +104,8 @@ __device__ __forceinline__ void store_tile_relu_nb(float *__restrict__ y, size_t
     npx = npx < 0 ? 0 : npx;
     const unsigned bytes = (unsigned)__builtin_amdgcn_readfirstlane(npx * UBD_C * 4);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, (int)bytes, 0x00020000);
-    const unsigned base = (unsigned)i * (UBD_C * 4u) + 16u * (unsigned)q;
-    const unsigned base1 = q < 2 ? base + 64u : 0x40000000u;
+    const unsigned base = drop ? 0x40000000u : (unsigned)i * (UBD_C * 4u) + 16u * (unsigned)q;
+    const unsigned base1 = (q < 2 && !drop) ? base + 64u : 0x40000000u;
     const float cap = __builtin_inff();
     f32x4 o0, o1;
 #pragma unroll
@@ -744,7 +744,15 @@ static bool fused_stem_applies(const ubd_handle *h, int n, int H)
     const int H4 = H / 4;
     const long stem_strips = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
     const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
-    return stem_big && h->fuse_stem >= 2 && h->cfg.fml_compatible != 0;
+    return stem_big && h->fuse_stem == 2 && h->cfg.fml_compatible != 0;
+}
+// launches too small for strips (one image: 32 strips for 256 CUs): the same kernel with ONE tile as its work unit (stem123.h, COLD) instead of
+// three separate launches; UBD_STEM=cold123 forces it at any size (tests)
+static bool cold_stem_applies(const ubd_handle *h, int n, int H)
+{
+    if (h->cfg.fml_compatible == 0) return false;
+    if (h->fuse_stem == 3) return true;
+    return h->fuse_stem == 2 && !h->fuse_force && !fused_stem_applies(h, n, H);
 }
 bool ubd_forward_uses_fused_stem(const ubd_handle *h, int n, int H, int W) { (void)W; return h->cfg.dtype == UBD_F32 && fused_stem_applies(h, n, H); }
 
@@ -785,7 +793,27 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
     const bool stem_big = h->fuse_force || stem_strips >= 2L * h->num_cus;
     const bool fuse_all = inference && fused_stem_applies(h, n, H);
     UBD_REQUIRE(!pp_job || fuse_all, "ubd_forward: a postprocess job needs the fused stem kernel (internal error)");
-    if (fuse_all) {
+    const bool cold_all = inference && !fuse_all && !pp_job && cold_stem_applies(h, n, H);
+    if (cold_all) {
+        // L1 -> L2 -> L3 in one kernel, one cold-started tile per work unit (stem123.h COLD): tiles of a row 15 L3 columns apart
+        const long tiles = (long)n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3) * (W4 <= 16 ? 1 : 1 + (W4 - 16 + 14) / 15);
+        int grid = h->num_cus;
+        if (grid > tiles) grid = (int)tiles;
+        pp_lds_args pj;
+        memset(&pj, 0, sizeof(pj));
+        const float *b0 = params + h->off_sep_b[0], *b1 = params + h->off_sep_b[1], *b2 = params + h->off_sep_b[2];
+        int *ticket = (int *)(ws + L.off_tickets);               // not touched by this form
+#ifdef UBD_STAMPS
+#define S123C_STAMP_ARG , (unsigned long long *)nullptr
+#else
+#define S123C_STAMP_ARG
+#endif
+#define UBD_LAUNCH_S123C(CINV, U8V, PLV) hipLaunchKernelGGL((stem123_kernel<CINV, U8V, PLV, true>), dim3(grid), dim3(s23_cfg::NT), 0, st, images, cur, sf0, b0, sf1, b1, sf2, b2, n, H, W, H2, W2, H4, W4, sc, sh, ticket, pj S123C_STAMP_ARG)
+        const bool plain = !u8 && sc == 0.f && sh == 1.f && (size_t)H * W * h->cfg.c_in * 4 < (1ull << 30) && ((uintptr_t)images & 15) == 0;
+        if (h->cfg.c_in == 1) { if (u8) UBD_LAUNCH_S123C(1, 1, 0); else if (plain) UBD_LAUNCH_S123C(1, 0, 1); else UBD_LAUNCH_S123C(1, 0, 0); }
+        else { if (u8) UBD_LAUNCH_S123C(3, 1, 0); else if (plain) UBD_LAUNCH_S123C(3, 0, 1); else UBD_LAUNCH_S123C(3, 0, 0); }
+#undef UBD_LAUNCH_S123C
+    } else if (fuse_all) {
         // L1 -> L2 -> L3 in one kernel (stem123.h): neither a1 nor a2 is touched
         const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);
         int grid = h->num_cus;
@@ -809,7 +837,7 @@ int ubd_forward_impl(ubd_handle *h, const float *params, const void *images, int
         launch_sep<1, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
     else
         launch_sep<3, 2>(h, images, u8, a1, sf0, params + h->off_sep_b[0], n, H, W, H2, W2, pad_s2, sc, sh, st);
-    if (fuse_all) {
+    if (fuse_all || cold_all) {
     } else if (inference && stem_big && h->fuse_stem) {
         // L2 -> L3 in one kernel: L2's activation stays in LDS (stem23.h); the a2 buffer is not touched
         const int strips = n * ((H4 + s23_cfg::TH3 - 1) / s23_cfg::TH3);   // a block walks whole row strips of tiles

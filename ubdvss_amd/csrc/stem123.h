@@ -55,7 +55,14 @@ template <int CIN> struct s123_cfg {
 // PLAIN: fp32 input that is fed as it is (no preprocessing): the patch goes straight from memory into LDS by 4-byte LDS-DMA through a
 // buffer descriptor (zeros outside the image = L1's padding), requested right after phase 0b of the previous tile -- no staging
 // registers and no phase 0a.
-template <int CIN, int IN_U8, int PLAIN>
+// COLD (round 6, launches too small to give every CU strips of tiles -- one image): the work unit is ONE tile, started cold.  A tile
+// inside a row has nobody to inherit L2 position 0 from, so it does not produce its first L3 column: the tiles of a row sit 15 L3
+// columns apart (tile k > 0 at column 15 k covers columns 15 k + 1 .. 15 k + 15; tile 0 covers 0 .. 15 -- the image edge is its
+// padding), nine tiles for 128 columns instead of eight.  Everything else -- patch, L1, L2, L3 of a tile -- is the code of the strip
+// walk, so every output is computed by the same instructions on the same values: bit-identical (tests/test_gpu_forward.py).  Tiles
+// are dealt out statically (block b takes b, b + grid, ...): no tickets, no ring.  One 512 x 512 image: 288 tiles on 256 CUs, one
+// launch of ~8 us instead of three of 5.6 + 6.6 + 7.2 us.
+template <int CIN, int IN_U8, int PLAIN, bool COLD = false>
 __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__restrict__ xin, float *__restrict__ y,
                                                                 const float *__restrict__ frag1, const float *__restrict__ bias1,
                                                                 const float *__restrict__ frag2, const float *__restrict__ bias2,
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     const int njob = pj.n > 0 ? (pj.n < (int)gridDim.x ? pj.n : (int)gridDim.x) : 0;
     auto ticket_ls = [&](int k) { return k < njob * Dc ? k : k + ((int)gridDim.x - njob) * Dc; };   // ticket -> logical strip
     int t0_early = 0;
-    if (threadIdx.x == 0 && (int)blockIdx.x < njob) t0_early = __hip_atomic_fetch_add(ticket, Dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!COLD && threadIdx.x == 0 && (int)blockIdx.x < njob) t0_early = __hip_atomic_fetch_add(ticket, Dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float *a1p = smem;
     float *l2 = a1p + X::A1_FLOATS;
     float *xp = l2 + C::L2_FLOATS;
@@ -132,14 +139,25 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // below: one for rows of three or more tiles) -- every strip claimed early by a late block ends after everybody else.
     // The ids live in a four-entry LDS ring: entry j + D is requested when strip j starts and published at the end of that
     // tile, at least one full tile (three barriers) before anybody reads it.
-    const int tiles_x = (W4 + 15) >> 4, tiles_y = (H4 + C::TH3 - 1) / C::TH3;
-    const int strips = n * tiles_y;
+    const int cold_kx = W4 <= 16 ? 1 : 1 + (W4 - 16 + 14) / 15;                     // COLD: tiles per row, 15 columns apart
+    const int tiles_x = COLD ? 1 : (W4 + 15) >> 4, tiles_y = (H4 + C::TH3 - 1) / C::TH3;
+    const int strips = COLD ? n * tiles_y * cold_kx : n * tiles_y;                  // COLD: a "strip" is one tile
     const int D = tiles_x >= 3 ? 1 : 4 - tiles_x;                                   // strips claimed ahead of the current one
     int *ring = (int *)(bt + 64);                                                   // logical strip id of the block's strip ordinal j at [j & 3]
     float *lut = bt + 64 + 4;                                                       // uint8 input: ((float)b - pre_sub) / pre_div for b = 0 .. 255, filled with the weight tables
     struct tpos { int tx, ty, img, ord, ls; };                                      // ord: ordinal of the strip in this block's sequence
     auto strip_pos = [&](int ord, int tx) {
         tpos p;
+        if constexpr (COLD) {                                                        // tile b, b + grid, ...: (image, tile row, tile of the row)
+            const int ls = (int)blockIdx.x + ord * (int)gridDim.x;
+            const int sidx = ubd_xcd_tile(ls < strips ? ls : strips - 1, strips);
+            const int rowi = (int)((unsigned)sidx / (unsigned)cold_kx);
+            p.tx = sidx - rowi * cold_kx;
+            p.ty = (int)((unsigned)rowi % (unsigned)tiles_y);
+            p.img = (int)((unsigned)rowi / (unsigned)tiles_y);
+            p.ord = ord; p.ls = ls;
+            return p;
+        }
         const int ls = __builtin_amdgcn_readfirstlane(ring[ord & 3]);
         const int sidx = ubd_xcd_tile(ls < strips ? ls : strips - 1, strips);
         p.ty = (int)((unsigned)sidx % (unsigned)tiles_y);
@@ -148,9 +166,10 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         return p;
     };
     auto advance = [&](tpos p) {
-        if (p.tx + 1 < tiles_x) { ++p.tx; return p; }
+        if (!COLD && p.tx + 1 < tiles_x) { ++p.tx; return p; }
         return strip_pos(p.ord + 1, 0);
     };
+    auto xo3 = [&](const tpos &p) { return (COLD ? 15 : 16) * p.tx; };              // first L3 column of the tile
 
     // ---- input patch of a tile: rows 4*oy0 - 5 .. + 22, columns 4*ox0 - 3 .. + 68, raw bits into registers (fp32 pattern
     //      or zero-extended byte; 0x100 / pre_sub bits = "outside the image", exactly 0 after the preprocessing)
@@ -164,11 +183,11 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // (block-uniform) load unconditionally; border tiles load from the clamped position and the elements outside the image
     // are replaced where the registers are consumed (a select next to the load would wait for it).
     auto tile_interior = [&](tpos p) {
-        const int iy0 = 4 * p.ty * C::TH3 - 5, ix0 = 64 * p.tx - 3;
+        const int iy0 = 4 * p.ty * C::TH3 - 5, ix0 = 4 * xo3(p) - 3;
         return (iy0 >= 0) && (ix0 >= 0) && (iy0 + X::XH <= H) && (ix0 + X::XW <= W);
     };
     auto load_x = [&](tpos p) {
-        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (4 * xo3(p) - 3) * CIN, WC = W * CIN;
         const unsigned char *img8 = (const unsigned char *)xin + (size_t)p.img * H * WC * (IN_U8 ? 1 : 4);   // wave-uniform
         const bool interior = tile_interior(p);                                      // block-uniform
         int pr = e0_row, pcf = e0_col;
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
         }
     };
     auto fix_border = [&](tpos p) {                                                  // outside the image = exactly 0 after the preprocessing
-        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 3) * CIN, WC = W * CIN;
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (4 * xo3(p) - 3) * CIN, WC = W * CIN;
         int pr = e0_row, pcf = e0_col;
 #pragma unroll
         for (int k = 0; k < X::XREGS; ++k) {
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
 
     const unsigned lds_xp = ubd_lds_addr(xp);
     auto dma_x = [&](tpos p) {                                                       // PLAIN: the patch of tile p, one 16-byte LDS-DMA piece per patch row
-        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (64 * p.tx - 4) * CIN, WC = W * CIN;   // one column left of the patch: 16-byte aligned
+        const int iy0 = 4 * p.ty * C::TH3 - 5, fx0 = (4 * xo3(p) - 4) * CIN, WC = W * CIN;   // one column left of the patch: 16-byte aligned (COLD: 60 k - 4 columns)
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)xin + (size_t)p.img * H * WC * 4), 0,
                                                                         (int)((unsigned)H * WC * 4u), 0x00020000);
         // Row r of the patch = XCH chunks of 16 bytes from image row iy0 + r: a wave-uniform term plus 16 * lane.  Rows above /
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     const int l2w = (rb * C::LC + pos) * C::LP + 4 * q;
     const int l2r = (2 * (wid & 3) * C::LC + 2 * i) * C::LP;
 
-    if (threadIdx.x == 0) {                                                          // the block's first D strips (requested at the top)
+    if (!COLD && threadIdx.x == 0) {                                                 // the block's first D strips (requested at the top)
         const bool had_job = (int)blockIdx.x < njob;
 #pragma unroll
         for (int j = 0; j < 3; ++j) ring[j] = had_job ? ticket_ls(t0_early + j) : (int)blockIdx.x * D + j;   // only the first D are this block's: the rest are overwritten before use
@@ -259,6 +278,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // tickets any more -- zeroes both for the next launch on this workspace (stream order; the host zeroes them only before
     // the first launch on a workspace: the per-pass memset was a 5 us kernel of its own between two forward passes).
     auto check_out = [&]() {
+        if constexpr (COLD) return;                                                  // no tickets drawn
         __syncthreads();
         if (threadIdx.x == 0) {
             const int left = __hip_atomic_fetch_add(ticket + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     };
     auto l1_finish = [&](tpos p, auto nunits, auto &tap, int k0) {                  // units k0 .. k0 + NU - 1 of the wave
         constexpr int NU = decltype(nunits)::value;
-        const int A0y = 2 * p.ty * C::TH3 - 2, A0x = 32 * p.tx - 2;                  // a1 pixel of patch (0, 0)
+        const int A0y = 2 * p.ty * C::TH3 - 2, A0x = 2 * xo3(p) - 2;                 // a1 pixel of patch (0, 0)
         float dwk1[9], pwf1[2];
         {
             const f32x4 wa = *(const f32x4 *)(w1t + lane * 12), wb = *(const f32x4 *)(w1t + lane * 12 + 4), wc = *(const f32x4 *)(w1t + lane * 12 + 8);
@@ -405,10 +425,10 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
     // have no L3 row do not idle through phase B.
     for (int it = 0;; ++it) {
         S123_STAMP(0);
-        const bool new_strip = cur.tx == 0;                                          // block-uniform
+        const bool new_strip = !COLD && cur.tx == 0;                                 // block-uniform
         if (new_strip) S123_BLOCK_STAMP(4 + cur.ord);
         if (new_strip && threadIdx.x == 0) pending = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the raw ticket: arithmetic on it here would wait for the round trip
-        const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = cur.tx * 16;
+        const int img = cur.img, oy0 = cur.ty * C::TH3, ox0 = xo3(cur);
         const bool has_next = nx1.ls < strips;                                       // block-uniform
         const int R0 = 2 * oy0 - 1, C0 = 2 * ox0 - 1;                                // L2 pixel of position (0, 0)
         if (has_next) { if constexpr (PLAIN) dma_x(nx1); else load_x(nx1); }        // phase 0b(t) has read the patch: the next tile's may land
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
             // L2 position 0 (column 2*ox0 - 1): the previous tile's position 32, or L3's zero padding at the left image edge
             const int row = lane / 6, ch4 = lane - row * 6;
             f32x4 v = z4;
-            if (cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);
+            if (!COLD && cur.tx > 0) v = *(const f32x4 *)(carry_buf + (((it + 1) & 1) * C::LR + row) * C::LP + 4 * ch4);   // COLD: nobody to inherit from -- the tile's first L3 column is not stored
             *(f32x4 *)(l2 + (row * C::LC) * C::LP + 4 * ch4) = v;
         }
         S123_STAMP(1);
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(s23_cfg::NT, 1) void stem123_kernel(const void *__r
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa0[s] : pb0[s - 4], dv[s], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 4 ? pa1[s] : pb1[s - 4], dv[s], acc1, 0, 0, 0);
             }
-            store_tile_relu_nb(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1);          // bias already in
+            store_tile_relu_nb(y, ((size_t)img * H4 + oy) * W4, ox0, oy < H4 ? W4 : 0, lane, acc0, acc1, COLD && cur.tx > 0 && i == 0);   // bias already in
             S123_STAMP(5);
             if (!has_next) break;
             float tap[2][9];
