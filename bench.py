@@ -678,7 +678,7 @@ def main():
         gm = Model(gcfg, seed=1)
         res = {"protocol": "predict.py:73-78: model.predict(zeros(1,S,S,1)) once as warm-up, second call timed with time.time(); "
                            "numpy in / numpy out (H2D + D2H included); *_on_device = same with the image resident in HBM; one image per call replays a "
-                           "captured HIP graph of the pass (Model.graphed_forward), *_launch_by_launch = the same nine launches issued one by one",
+                           "captured HIP graph of the pass (Model.graphed_forward), *_launch_by_launch = the same seven launches (one stem kernel of cold-started tiles + six dilated layers) issued one by one",
                "reference_claim_ms": {"512": 50, "1024": 150, "source": "README_RU.md:9-10, 'cpu (4 cores)', unverified"}}
         for side in (512, 1024):
             xz = np.zeros((1, side, side, 1), np.float32)
@@ -693,7 +693,7 @@ def main():
                 t0 = time.time(); gm.predict(xz); more.append((time.time() - t0) * 1e3)
             xd = torch.from_numpy(xz).to(dev)
             gm.predict_on_device(xd); torch.cuda.synchronize()
-            launches = []                                                  # the nine launches issued one by one
+            launches = []                                                  # the seven launches issued one by one
             for _ in range(20):
                 t0 = time.time(); gm.predict_on_device(xd); torch.cuda.synchronize(); launches.append((time.time() - t0) * 1e3)
             gf = gm.graphed_forward(1, side, side)                       # the same launches replayed as ONE captured graph (what predict() does at batch 1)

@@ -433,8 +433,9 @@ class Model:
 
 
 class GraphedForward:
-    """``Model.predict_on_device`` of one fixed shape, captured once into a HIP graph and replayed: one host call instead of nine
-    launches (the stem's three kernels + six dilated layers at batch 1).  Owns a static input and a static output tensor; ``__call__``
+    """``Model.predict_on_device`` of one fixed shape, captured once into a HIP graph and replayed: one host call instead of seven
+    launches (the stem kernel + six dilated layers at batch 1; with so few launches the replay is no faster on the device -- 0.077
+    against 0.072 ms for a 512 x 512 image -- but it costs the host one call and allocates nothing).  Owns a static input and a static output tensor; ``__call__``
     copies the caller's images into the static input unless they ARE that tensor, makes sure the packed weight fragments are current
     (a parameter change re-packs through one ordinary call, then re-captures), replays, and returns the static output (valid until
     the next call).  The library allocates nothing inside a call and takes every pointer from the caller, which is what
