@@ -677,8 +677,8 @@ def main():
         gcfg = NetConfig(grey=True)
         gm = Model(gcfg, seed=1)
         res = {"protocol": "predict.py:73-78: model.predict(zeros(1,S,S,1)) once as warm-up, second call timed with time.time(); "
-                           "numpy in / numpy out (H2D + D2H included); *_on_device = same with the image resident in HBM; one image per call replays a "
-                           "captured HIP graph of the pass (Model.graphed_forward), *_launch_by_launch = the same seven launches (one stem kernel of cold-started tiles + six dilated layers) issued one by one",
+                           "numpy in / numpy out (H2D + D2H included; static input / output tensors, seven launches: one stem kernel of cold-started tiles + six dilated layers); "
+                           "*_on_device = the image resident in HBM, the pass replayed as ONE captured HIP graph (Model.graphed_forward); *_launch_by_launch = the same seven launches issued one by one",
                "reference_claim_ms": {"512": 50, "1024": 150, "source": "README_RU.md:9-10, 'cpu (4 cores)', unverified"}}
         for side in (512, 1024):
             xz = np.zeros((1, side, side, 1), np.float32)
@@ -696,7 +696,7 @@ def main():
             launches = []                                                  # the seven launches issued one by one
             for _ in range(20):
                 t0 = time.time(); gm.predict_on_device(xd); torch.cuda.synchronize(); launches.append((time.time() - t0) * 1e3)
-            gf = gm.graphed_forward(1, side, side)                       # the same launches replayed as ONE captured graph (what predict() does at batch 1)
+            gf = gm.graphed_forward(1, side, side)                       # the same launches replayed as ONE captured graph
             gf(xd); torch.cuda.synchronize()
             same = bool(torch.equal(gf(xd), gm.predict_on_device(xd)))
             dts = []

@@ -413,8 +413,8 @@ def test_unfused_call_then_prepacked_fused_call_on_a_poisoned_workspace(monkeypa
 
 
 def test_graphed_forward_equals_the_launches_and_follows_the_weights():
-    """Model.graphed_forward: the captured HIP graph of one shape is bit-identical to predict_on_device, Model.predict uses it for one image
-    per call (the reference's latency protocol, predict.py:73-78), a parameter change is picked up, and another shape in between (which
+    """Model.graphed_forward: the captured HIP graph of one shape is bit-identical to predict_on_device, Model.predict uses its static
+    tensors for one image per call (the reference's latency protocol, predict.py:73-78), a parameter change is picked up, and another shape in between (which
     moves the workspace) does not leave a stale graph behind."""
     cfg = NetConfig(grey=True)
     m = Model(cfg, seed=3)
