@@ -470,3 +470,30 @@ def test_pipelined_runner_random_shapes_changing_between_calls():
             prev = (got, ref, (n, hh, ww))
         piped.synchronize()
         assert _same_results(prev[0], prev[1]), (n_cls, "last", prev[2])
+
+
+def test_discs_ellipses_and_tall_objects_vs_oracle():
+    """The box fit's hull stage beyond rectangles (round 6: both chains are wrapped at once, one per half wave, the right chain staged in the
+    second half of the point slots): discs and rotated ellipses -- dozens of hull vertices per chain, polygons of more than 64 vertices (the
+    one-lane form with the right chain moved behind the left one) --, objects of more than 64 and more than 128 rows (a lane takes several
+    rows of a chain), thin tall slivers, one pixel columns; 128 x 128 maps (one-launch front end) and 400 x 96 / 96 x 400 maps (the
+    global-memory path at any setting).  Bit-exact against the oracle."""
+    rng = np.random.default_rng(17)
+    def shapes(h, w, k):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        m = np.zeros((h, w), bool)
+        for _ in range(k):
+            cy, cx = rng.uniform(0.2, 0.8) * h, rng.uniform(0.2, 0.8) * w
+            a, b, t = rng.uniform(0.05, 0.45) * h, rng.uniform(0.05, 0.45) * w, rng.uniform(0, np.pi)
+            u, v = (yy - cy) * np.cos(t) + (xx - cx) * np.sin(t), -(yy - cy) * np.sin(t) + (xx - cx) * np.cos(t)
+            m |= (u / a) ** 2 + (v / b) ** 2 <= 1.0
+        return m
+    maps128 = np.stack([shapes(128, 128, 1 + i % 3) for i in range(8)])
+    maps128[6] = False; maps128[6, 2:126, 60] = True; maps128[6, 5:120, 90:93] = True          # a one-pixel column, a sliver
+    yy, xx = np.mgrid[0:128, 0:128]
+    maps128[7] = (yy - 64) ** 2 + (xx - 64) ** 2 <= 61 ** 2                                    # a big disc: > 64 hull vertices
+    yy, xx = np.mgrid[0:400, 0:400]
+    big = np.stack([(yy - 200) ** 2 + (xx - 200) ** 2 <= 190 ** 2, ((yy - 200) / 195.0) ** 2 + ((xx - 200) / 120.0) ** 2 <= 1.0])   # ~110 hull vertices: the one-lane form
+    for maps in (maps128, np.stack([shapes(400, 96, 2) for _ in range(3)]), np.stack([shapes(96, 400, 2) for _ in range(3)]), big):
+        lg = np.where(maps[..., None], 1.0, -1.0).astype(np.float32)
+        _compare(_model(0), lg, 0, min_area=3, cap=64)
